@@ -1,0 +1,154 @@
+/*
+ * mimo_hip.h — C ABI of libmimo_hip.so, the MI355X (gfx950) E-step / sufficient-statistics
+ * engine that drops in behind hanyas/mimo's NumPy hot path.
+ *
+ * The reference has no FFI seam: its hot path is a set of Python methods that turn the
+ * (N,D) data array into (K,N) log-density tables, responsibilities / labels and
+ * responsibility-weighted sufficient statistics.  Every entry point
+ * below cites the reference method(s) it replaces (paths relative to the reference root).
+ *
+ * Canonical form evaluated on the device for every model in scope:
+ *
+ *     l[k,n] = c[k] + b[k,:]·z[n,:] − ½ z[n,:]ᵀ W[k,:,:] z[n,:]          (float64)
+ *
+ * with z the data row (GMM: x; mixture of linear-Gaussian experts: z=[x,y]) and (c,b,W) built on
+ * the host from point estimates (Gibbs/EM) or posterior expectations (mean-field VI).
+ *
+ * Conventions
+ *   - all floating point is IEEE float64; labels are int32; row counts int64.
+ *   - data Z is row-major (N, Dz).  Per-component tables are K-major (K, N).
+ *   - sufficient statistics are returned packed per component:
+ *         S[k] = [ n_k , sum_n r_kn z_n (Dz) , sum_n r_kn z_n z_nᵀ (Dz×Dz, row-major, symmetric) ]
+ *     i.e. K × (1 + Dz + Dz²) doubles  (mimo/distributions/gaussian.py:491-502,
+ *     mimo/distributions/lingauss.py:306-322: yxT/xxT/yyT/n_k are blocks of this for z=[x,y]).
+ *   - scalars[3] = { sum_n logsumexp_k l[k,n] , sum_n sum_k r_kn l[k,n] , −sum_n sum_k r_kn log r_kn }
+ *     (mimo/mixtures/gmm.py:338-356).
+ *   - every function returns 0 on success or a negative MIMO_E_* code; the message is
+ *     available from mimo_last_error().  No C++ exception crosses this boundary.
+ *   - pointers are HOST pointers unless MIMO_F_DEVICE_OUT is set in `flags`, in which case the
+ *     *output* pointers (S, scalars) are DEVICE pointers, nothing is copied to the host and the
+ *     call returns without synchronising the context's stream (used by the multi-GPU driver,
+ *     which all-reduces S with RCCL before the host reads it).
+ *   - one context per device, not thread-safe; the library owns all device memory behind it.
+ */
+#ifndef MIMO_HIP_H
+#define MIMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mimo_ctx mimo_ctx;
+
+/* error codes */
+#define MIMO_OK               0
+#define MIMO_E_INVALID       -1   /* bad argument (shape, NULL, flags)            */
+#define MIMO_E_HIP           -2   /* a HIP runtime call failed                    */
+#define MIMO_E_NODATA        -3   /* no data uploaded / attached                  */
+#define MIMO_E_UNSUPPORTED   -4   /* (K, Dz) outside the ranges the kernels cover */
+#define MIMO_E_STATE         -5   /* requested buffer was never produced          */
+
+/* flags */
+#define MIMO_F_KEEP_RESP      0x01  /* keep the (K,N) responsibility table on the device          */
+#define MIMO_F_KEEP_LOGP      0x02  /* keep the (K,N) log-density table l[k,n] on the device       */
+#define MIMO_F_KEEP_LSE       0x04  /* keep the (N,) per-datum log-normaliser on the device        */
+#define MIMO_F_NO_STATS       0x08  /* skip the sufficient-statistics accumulation                 */
+#define MIMO_F_DEVICE_OUT     0x10  /* S / scalars are device pointers; asynchronous               */
+#define MIMO_F_DEVICE_IN      0x20  /* `resp` / `labels` / `u` inputs are device pointers          */
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  Replaces nothing in the reference (it has no
+ * device state); the context plays the role of the Python objects' NumPy buffers. */
+int mimo_create(mimo_ctx** out, int device);
+int mimo_destroy(mimo_ctx* ctx);
+
+/* Last error message for `ctx` (or the last context-less error when ctx == NULL). */
+const char* mimo_last_error(const mimo_ctx* ctx);
+
+/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) instead of
+ * the context's own stream.  Pass NULL to return to the context's own stream. */
+int mimo_set_stream(mimo_ctx* ctx, void* hip_stream);
+
+/* ---- data ------------------------------------------------------------------------------ */
+
+/* Copy the (N,Dz) row-major observation matrix to the device once; it stays resident across
+ * sweeps.  Stands for the `obs` / `(x,y)` arrays every reference driver receives
+ * (mimo/mixtures/gmm.py:207,261; mimo/mixtures/ilr.py:134,196 — there hstack((x,y))). */
+int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz);
+
+/* Borrow an existing device buffer (e.g. a torch tensor) instead of copying. */
+int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz);
+
+/* Global index of local row 0; only enters the Philox counter so that labels drawn by a sharded
+ * run do not depend on the number of shards.  Default 0. */
+int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* Fused mean-field / EM E-step: log-densities, softmax over k, weighted sufficient statistics
+ * and ELBO scalars in ONE pass over Z.
+ * Replaces: StackedGaussiansWithNormalWisharts.expected_log_likelihood
+ *   (mimo/distributions/bayesian.py:287-301) or StackedGaussiansWithPrecision.log_likelihood
+ *   (mimo/distributions/gaussian.py:510-521) [+ the linear-Gaussian counterparts
+ *   bayesian.py:933-947, lingauss.py:330-345], the softmax of
+ *   expected_responsibilities / responsibilities (mimo/mixtures/gmm.py:72-75,256-259),
+ *   weighted_statistics (gaussian.py:491-502, lingauss.py:306-322, categorical.py:41-43) and the
+ *   data/label ELBO terms (gmm.py:338-356).
+ * c (K), b (K,Dz), W (K,Dz,Dz).  S: K×(1+Dz+Dz²) or NULL with MIMO_F_NO_STATS; scalars: 3 or NULL. */
+int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+               int flags, double* S, double* scalars);
+
+/* Fused Gibbs label step: log-densities, categorical draw per datum by inverse CDF, and the
+ * sufficient statistics of the labels just drawn (what the next sweep's resample_components /
+ * resample_gating consume) in ONE pass.
+ * Replaces: resample_labels (mimo/mixtures/gmm.py:227-230, ilr.py:161-164) =
+ *   log_complete_likelihood + sample_discrete_from_log (mimo/utils/stats.py:8-21), then
+ *   one_hot (mimo/utils/data.py:160-169) + weighted_statistics + Categorical.statistics
+ *   (categorical.py:35-37) of the following sweep.
+ * Uniforms: if `u` != NULL it holds N uniforms in [0,1) (reference-exact mode: the values
+ *   numpy.random.random((1,N)) returned); otherwise datum n uses the in-kernel counter-based
+ *   Philox4x32-10 stream keyed by `seed` with counter (row0+n, sweep).
+ * labels_out: N int32 on the host or NULL (labels always stay on the device as well). */
+int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                      uint64_t seed, uint64_t sweep, const double* u,
+                      int flags, int32_t* labels_out, double* S);
+
+/* Sufficient statistics for arbitrary weights resp (K,N), K-major.
+ * Replaces: weighted_statistics(data, weights) (gaussian.py:491-502, lingauss.py:306-322,
+ * categorical.py:41-43) when the weights do not come from mimo_estep (random initial
+ * responsibilities gmm.py:265-267, EM with user weights gmm.py:93). */
+int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, double* S);
+
+/* Sufficient statistics of hard labels without materialising one_hot(labels,K).
+ * Replaces: one_hot + weighted_statistics (gmm.py:235-237, data.py:160-169) and
+ * Categorical.statistics = bincount (categorical.py:35-37).  labels == NULL uses the labels the
+ * last mimo_gibbs_labels left on the device. */
+int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, double* S);
+
+/* ---- copy-outs of device-resident tables ----------------------------------------------- */
+int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
+int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);
+int mimo_get_lse(mimo_ctx* ctx, double* lse_host /* N */);
+int mimo_get_labels(mimo_ctx* ctx, int32_t* labels_host /* N */);
+
+/* ---- introspection --------------------------------------------------------------------- */
+
+/* Uniform the in-kernel Philox stream gives datum `row` at `sweep` (host-side mirror, used by
+ * tests to feed the same uniforms to the oracle). */
+double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep);
+
+/* Accumulated device time (ms, HIP events on the launch stream) and launch count of the
+ * dominant fused kernel since the last reset; enable with mimo_profile(ctx, 1). */
+int mimo_profile(mimo_ctx* ctx, int enable);
+int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset);
+
+/* Library version string. */
+const char* mimo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMO_HIP_H */

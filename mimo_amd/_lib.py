@@ -1,0 +1,68 @@
+"""ctypes binding of libmimo_hip.so (C ABI declared in include/mimo_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded
+this module raises, and so does every engine call.  Build it with
+``make -C mimo_amd/csrc`` (or ``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
+
+# error codes / flags (mirror include/mimo_hip.h)
+OK = 0
+E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
+F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN = 1, 2, 4, 8, 0x10, 0x20
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# every exported symbol with its signature; tests check the .so exports exactly these
+SIGNATURES = {
+    "mimo_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "mimo_destroy": (C.c_int, [_vp]),
+    "mimo_last_error": (C.c_char_p, [_vp]),
+    "mimo_set_stream": (C.c_int, [_vp, _vp]),
+    "mimo_upload": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mimo_attach": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mimo_set_row_offset": (C.c_int, [_vp, C.c_int64]),
+    "mimo_estep": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "mimo_gibbs_labels": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _vp,
+                                    C.c_int, _vp, _vp]),
+    "mimo_weighted_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "mimo_label_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "mimo_get_resp": (C.c_int, [_vp, _vp]),
+    "mimo_get_logp": (C.c_int, [_vp, _vp]),
+    "mimo_get_lse": (C.c_int, [_vp, _vp]),
+    "mimo_get_labels": (C.c_int, [_vp, _vp]),
+    "mimo_philox_uniform": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    "mimo_profile": (C.c_int, [_vp, C.c_int]),
+    "mimo_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.c_int]),
+    "mimo_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class MimoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmimo_hip.so once; raise loudly if it is absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MimoHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `make -C mimo_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,492 @@
+// C-ABI layer of libmimo_hip.so (see include/mimo_hip.h for the contract and the reference
+// call sites each entry point replaces).  Host-side work here is O(K D^2): converting the
+// canonical (c, b, W) parameters to the feature-space MFMA operand image, and launching /
+// sequencing the gfx950 kernels of mimo_kernels.hip on the context's stream.
+#include "../../include/mimo_hip.h"
+#include "mimo_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mimo;
+
+struct mimo_ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // data
+  const double* Z = nullptr;  // device
+  double* Z_owned = nullptr;
+  int64_t N = 0;
+  int D = 0;
+  int64_t row0 = 0;
+
+  // feature map for the current D
+  int feat_D = -1;
+  int F = 0, F16 = 0;
+  std::vector<uint8_t> feat_h;
+  uint8_t* feat_d = nullptr;
+
+  // parameter image
+  double* theta_d = nullptr;  size_t theta_cap = 0;
+  double* theta_h = nullptr;  size_t theta_hcap = 0;   // pinned staging
+
+  // workspaces
+  double* partials = nullptr; size_t partials_cap = 0;
+  double* reduced = nullptr;  size_t reduced_cap = 0;
+  double* S_d = nullptr;      size_t S_cap = 0;         // packed stats + 3 scalars
+  double* S_h = nullptr;      size_t S_hcap = 0;        // pinned staging
+
+  // optional device-resident tables
+  double* resp = nullptr;  size_t resp_cap = 0;  int resp_K = 0;  bool resp_valid = false;
+  double* logp = nullptr;  size_t logp_cap = 0;  int logp_K = 0;  bool logp_valid = false;
+  double* lse = nullptr;   size_t lse_cap = 0;   bool lse_valid = false;
+  int32_t* labels = nullptr; size_t labels_cap = 0; bool labels_valid = false;
+  double* u_d = nullptr;   size_t u_cap = 0;
+  double* win = nullptr;   size_t win_cap = 0;    // staged host weights
+  int32_t* lin = nullptr;  size_t lin_cap = 0;    // staged host labels
+
+  // profiling of the fused kernel
+  bool prof = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double prof_ms = 0.0;
+  int64_t prof_n = 0;
+};
+
+static std::string g_err;
+
+static int fail(mimo_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(ctx, MIMO_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+template <typename T>
+static int ensure_dev(mimo_ctx* ctx, T** p, size_t* cap, size_t count) {
+  if (*cap >= count && *p) return MIMO_OK;
+  if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  *cap = count;
+  return MIMO_OK;
+}
+
+template <typename T>
+static int ensure_pinned(mimo_ctx* ctx, T** p, size_t* cap, size_t count) {
+  if (*cap >= count && *p) return MIMO_OK;
+  if (*p) { HIP_TRY(ctx, hipHostFree(*p)); *p = nullptr; *cap = 0; }
+  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(p), count * sizeof(T), hipHostMallocDefault));
+  *cap = count;
+  return MIMO_OK;
+}
+
+static int bind(mimo_ctx* ctx) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return MIMO_OK;
+}
+
+// feature table for dimension D: pairs (a,b), a <= b <= D over z~ = [z, 1]; padding -> (D+1,D+1)
+static int prepare_features(mimo_ctx* ctx, int D) {
+  if (ctx->feat_D == D) return MIMO_OK;
+  ctx->F = feat_count(D);
+  ctx->F16 = feat_pad16(D);
+  ctx->feat_h.assign((size_t)ctx->F16 * 2, (uint8_t)(D + 1));
+  for (int a = 0; a <= D; ++a)
+    for (int b = a; b <= D; ++b) {
+      const int f = feat_index(D, a, b);
+      ctx->feat_h[2 * f] = (uint8_t)a;
+      ctx->feat_h[2 * f + 1] = (uint8_t)b;
+    }
+  if (ctx->feat_d) { HIP_TRY(ctx, hipFree(ctx->feat_d)); ctx->feat_d = nullptr; }
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->feat_d), ctx->feat_h.size()));
+  HIP_TRY(ctx, hipMemcpy(ctx->feat_d, ctx->feat_h.data(), ctx->feat_h.size(), hipMemcpyHostToDevice));
+  ctx->feat_D = D;
+  return MIMO_OK;
+}
+
+static int check_shapes(mimo_ctx* ctx, int K) {
+  if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "no data uploaded or attached");
+  if (K < 1) return fail(ctx, MIMO_E_INVALID, "K must be >= 1 (got %d)", K);
+  if (K > 256) return fail(ctx, MIMO_E_UNSUPPORTED, "K = %d > 256 is not covered by the fused kernels", K);
+  return MIMO_OK;
+}
+
+static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
+  memset(a, 0, sizeof *a);
+  a->Z = ctx->Z; a->N = ctx->N; a->D = ctx->D; a->K = K; a->K16 = (K + 15) / 16;
+  a->F16 = ctx->F16;
+  a->ZS = (ctx->D + 2) | 1;
+  a->RS = ctx->F16 + 2;
+  a->LS = a->K16 * 16 + 2;
+  a->feat = ctx->feat_d;
+  a->row0 = ctx->row0;
+  a->do_stats = 1;
+  a->ntiles = (ctx->N + kTile - 1) / kTile;
+}
+
+// (c, b, W) -> Theta[k][f] -> MFMA A-operand image [K16][F16/4][64] on the device.
+//   f = (D,D): c_k ; (a,D): b_k[a] ; (a,a): -W_aa/2 ; (a,b), a<b: -(W_ab + W_ba)/2
+static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  const int D = ctx->D, F16 = ctx->F16, K16 = (K + 15) / 16, NS = F16 / 4;
+  const size_t count = (size_t)K16 * NS * 64;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+  // the staging buffer may still be in flight from the previous call on this stream
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  double* img = ctx->theta_h;
+  memset(img, 0, count * sizeof(double));
+  for (int k = 0; k < K; ++k) {
+    const int rb = k / 16, i = k % 16;
+    const double* bk = b + (size_t)k * D;
+    const double* Wk = W + (size_t)k * D * D;
+    auto put = [&](int f, double v) {
+      const int s = f / 4, kk = f % 4;
+      img[((size_t)rb * NS + s) * 64 + kk * 16 + i] = v;
+    };
+    put(feat_index(D, D, D), c[k]);
+    for (int a = 0; a < D; ++a) {
+      put(feat_index(D, a, D), bk[a]);
+      put(feat_index(D, a, a), -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb)
+        put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+    }
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MIMO_OK;
+}
+
+static void drain_profile(mimo_ctx* ctx) {
+  for (auto& pr : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      ctx->prof_ms += ms;
+      ctx->prof_n += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->pending.clear();
+}
+
+// run fused kernel -> reduce -> unpack; deliver S / scalars to host or device pointers
+static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
+  const int K = a.K, D = a.D;
+  const int Kpad = a.K16 * 16;
+  const int grid = fused_grid(a, ctx->num_cu);
+  const size_t pstride = (size_t)Kpad * a.F16 + 4;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
+  if ((rc = ensure_dev(ctx, &ctx->reduced, &ctx->reduced_cap, pstride))) return rc;
+  a.partials = ctx->partials;
+
+  bool unsupported = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof) {
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
+  if (unsupported) {
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    return fail(ctx, MIMO_E_UNSUPPORTED,
+                "no fused kernel for K=%d, Dz=%d (covered: Dz<=%d with K<=64, or Dz<=9 with K<=256 "
+                "for the E-step; K<=256 for weighted/label statistics)", K, D, kMaxD);
+  }
+  HIP_TRY(ctx, he);
+  if (ctx->prof) {
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->pending.emplace_back(e0, e1);
+  }
+  const bool want_stats = a.do_stats && S;
+  const bool device_out = (flags & MIMO_F_DEVICE_OUT) != 0;
+  if (!want_stats && !scalars) return MIMO_OK;
+
+  HIP_TRY(ctx, launch_reduce(ctx->partials, grid, (int64_t)pstride, ctx->reduced, ctx->stream));
+  const size_t slen = (size_t)K * (1 + D + (size_t)D * D);
+  if (device_out) {
+    HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, a.F16, want_stats ? S : nullptr, scalars, ctx->stream));
+    return MIMO_OK;
+  }
+  if ((rc = ensure_dev(ctx, &ctx->S_d, &ctx->S_cap, slen + 4))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->S_h, &ctx->S_hcap, slen + 4))) return rc;
+  HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, a.F16, want_stats ? ctx->S_d : nullptr,
+                             ctx->S_d + slen, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (want_stats) memcpy(S, ctx->S_h, slen * sizeof(double));
+  if (scalars) memcpy(scalars, ctx->S_h + slen, 3 * sizeof(double));
+  return MIMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mimo_version(void) { return "mimo_hip 0.1 (gfx950, f64 MFMA feature-GEMM)"; }
+
+int mimo_create(mimo_ctx** out, int device) {
+  if (!out) return fail(nullptr, MIMO_E_INVALID, "mimo_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, MIMO_E_HIP, "mimo_create: no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return fail(nullptr, MIMO_E_INVALID, "mimo_create: device %d out of range [0,%d)", device, ndev);
+  mimo_ctx* ctx = new (std::nothrow) mimo_ctx();
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "mimo_create: out of host memory");
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return fail(nullptr, MIMO_E_HIP, "hipSetDevice failed"); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, MIMO_E_HIP, "hipStreamCreate failed");
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return MIMO_OK;
+}
+
+int mimo_destroy(mimo_ctx* ctx) {
+  if (!ctx) return MIMO_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  drain_profile(ctx);
+  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
+                  ctx->logp, ctx->lse, ctx->labels, ctx->u_d, ctx->win, ctx->lin};
+  for (void* p : bufs) if (p) (void)hipFree(p);
+  if (ctx->theta_h) (void)hipHostFree(ctx->theta_h);
+  if (ctx->S_h) (void)hipHostFree(ctx->S_h);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return MIMO_OK;
+}
+
+const char* mimo_last_error(const mimo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int mimo_set_stream(mimo_ctx* ctx, void* hip_stream) {
+  int rc = bind(ctx); if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return MIMO_OK;
+}
+
+static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
+  if (N < 0) return fail(ctx, MIMO_E_INVALID, "N must be >= 0");
+  if (Dz < 1 || Dz > kMaxD)
+    return fail(ctx, MIMO_E_UNSUPPORTED, "Dz = %d outside [1, %d]", Dz, kMaxD);
+  ctx->N = N; ctx->D = Dz;
+  ctx->resp_valid = ctx->logp_valid = ctx->lse_valid = ctx->labels_valid = false;
+  return prepare_features(ctx, Dz);
+}
+
+int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!Z_host && N > 0) return fail(ctx, MIMO_E_INVALID, "mimo_upload: Z is NULL");
+  if ((rc = set_data(ctx, N, Dz))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
+  const size_t bytes = (size_t)(N > 0 ? N : 1) * Dz * sizeof(double);
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->Z_owned), bytes));
+  if (N > 0) HIP_TRY(ctx, hipMemcpy(ctx->Z_owned, Z_host, (size_t)N * Dz * sizeof(double), hipMemcpyHostToDevice));
+  ctx->Z = ctx->Z_owned;
+  return MIMO_OK;
+}
+
+int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!Z_dev) return fail(ctx, MIMO_E_INVALID, "mimo_attach: Z is NULL");
+  if ((rc = set_data(ctx, N, Dz))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
+  ctx->Z = Z_dev;
+  return MIMO_OK;
+}
+
+int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  ctx->row0 = row0;
+  return MIMO_OK;
+}
+
+static int keep_tables(mimo_ctx* ctx, int K, int flags, KernelArgs* a) {
+  int rc;
+  const size_t kn = (size_t)K * (size_t)(ctx->N > 0 ? ctx->N : 1);
+  if (flags & MIMO_F_KEEP_RESP) {
+    if ((rc = ensure_dev(ctx, &ctx->resp, &ctx->resp_cap, kn))) return rc;
+    a->resp = ctx->resp; ctx->resp_K = K; ctx->resp_valid = true;
+  }
+  if (flags & MIMO_F_KEEP_LOGP) {
+    if ((rc = ensure_dev(ctx, &ctx->logp, &ctx->logp_cap, kn))) return rc;
+    a->logp = ctx->logp; ctx->logp_K = K; ctx->logp_valid = true;
+  }
+  if (flags & MIMO_F_KEEP_LSE) {
+    if ((rc = ensure_dev(ctx, &ctx->lse, &ctx->lse_cap, (size_t)(ctx->N > 0 ? ctx->N : 1)))) return rc;
+    a->lse = ctx->lse; ctx->lse_valid = true;
+  }
+  return MIMO_OK;
+}
+
+int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+               int flags, double* S, double* scalars) {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!c || !b || !W) return fail(ctx, MIMO_E_INVALID, "mimo_estep: c, b, W must be non-NULL");
+  const bool no_stats = (flags & MIMO_F_NO_STATS) != 0;
+  if (!no_stats && !S) return fail(ctx, MIMO_E_INVALID, "mimo_estep: S is NULL without MIMO_F_NO_STATS");
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  a.do_stats = no_stats ? 0 : 1;
+  if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
+  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  a.theta = ctx->theta_d;
+  return run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
+}
+
+int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                      uint64_t seed, uint64_t sweep, const double* u, int flags,
+                      int32_t* labels_out, double* S) {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!c || !b || !W) return fail(ctx, MIMO_E_INVALID, "mimo_gibbs_labels: c, b, W must be non-NULL");
+  const bool no_stats = (flags & MIMO_F_NO_STATS) != 0 || !S;
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  a.gibbs = 1;
+  a.do_stats = no_stats ? 0 : 1;
+  a.seed = seed; a.sweep = sweep;
+  const size_t n1 = (size_t)(ctx->N > 0 ? ctx->N : 1);
+  if ((rc = ensure_dev(ctx, &ctx->labels, &ctx->labels_cap, n1))) return rc;
+  a.labels = ctx->labels; ctx->labels_valid = true;
+  if ((rc = keep_tables(ctx, K, flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE), &a))) return rc;
+  if (u) {
+    if (flags & MIMO_F_DEVICE_IN) {
+      a.u = u;
+    } else {
+      if ((rc = ensure_dev(ctx, &ctx->u_d, &ctx->u_cap, n1))) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, u, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // u is pageable host memory
+      a.u = ctx->u_d;
+    }
+  }
+  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  a.theta = ctx->theta_d;
+  if ((rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr))) return rc;
+  if (labels_out && !(flags & MIMO_F_DEVICE_OUT)) {
+    HIP_TRY(ctx, hipMemcpyAsync(labels_out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MIMO_OK;
+}
+
+int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, double* S) {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!S) return fail(ctx, MIMO_E_INVALID, "mimo_weighted_stats: S is NULL");
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  if (!resp) {
+    if (!ctx->resp_valid || ctx->resp_K != K)
+      return fail(ctx, MIMO_E_STATE, "mimo_weighted_stats: resp is NULL and no (K=%d,N) table is resident", K);
+    a.resp = ctx->resp;
+  } else if (flags & MIMO_F_DEVICE_IN) {
+    a.resp = const_cast<double*>(resp);
+  } else {
+    const size_t kn = (size_t)K * (size_t)(ctx->N > 0 ? ctx->N : 1);
+    if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, kn))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->win, resp, (size_t)K * ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    a.resp = ctx->win;
+  }
+  return run_fused(ctx, a, kSrcWeights, flags, S, nullptr);
+}
+
+int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, double* S) {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!S) return fail(ctx, MIMO_E_INVALID, "mimo_label_stats: S is NULL");
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  if (!labels) {
+    if (!ctx->labels_valid) return fail(ctx, MIMO_E_STATE, "mimo_label_stats: labels is NULL and none are resident");
+    a.labels = ctx->labels;
+  } else if (flags & MIMO_F_DEVICE_IN) {
+    a.labels = const_cast<int32_t*>(labels);
+  } else {
+    const size_t n1 = (size_t)(ctx->N > 0 ? ctx->N : 1);
+    if ((rc = ensure_dev(ctx, &ctx->lin, &ctx->lin_cap, n1))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->lin, labels, (size_t)ctx->N * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    a.labels = ctx->lin;
+  }
+  return run_fused(ctx, a, kSrcLabels, flags, S, nullptr);
+}
+
+static int copy_out(mimo_ctx* ctx, void* dst, const void* src, size_t bytes, bool valid, const char* what) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!dst) return fail(ctx, MIMO_E_INVALID, "%s: destination is NULL", what);
+  if (!valid || !src) return fail(ctx, MIMO_E_STATE, "%s: table was never produced (pass the MIMO_F_KEEP_* flag)", what);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIMO_OK;
+}
+
+int mimo_get_resp(mimo_ctx* ctx, double* out) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  return copy_out(ctx, out, ctx->resp, (size_t)ctx->resp_K * ctx->N * sizeof(double), ctx->resp_valid, "mimo_get_resp");
+}
+int mimo_get_logp(mimo_ctx* ctx, double* out) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  return copy_out(ctx, out, ctx->logp, (size_t)ctx->logp_K * ctx->N * sizeof(double), ctx->logp_valid, "mimo_get_logp");
+}
+int mimo_get_lse(mimo_ctx* ctx, double* out) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  return copy_out(ctx, out, ctx->lse, (size_t)ctx->N * sizeof(double), ctx->lse_valid, "mimo_get_lse");
+}
+int mimo_get_labels(mimo_ctx* ctx, int32_t* out) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  return copy_out(ctx, out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), ctx->labels_valid, "mimo_get_labels");
+}
+
+double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep) {
+  return philox_uniform_host(seed, row, sweep);
+}
+
+int mimo_profile(mimo_ctx* ctx, int enable) {
+  if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
+  ctx->prof = enable != 0;
+  return MIMO_OK;
+}
+
+int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset) {
+  int rc = bind(ctx); if (rc) return rc;
+  drain_profile(ctx);
+  if (kernel_ms) *kernel_ms = ctx->prof_ms;
+  if (launches) *launches = ctx->prof_n;
+  if (reset) { ctx->prof_ms = 0.0; ctx->prof_n = 0; }
+  return MIMO_OK;
+}
+
+}  // extern "C"

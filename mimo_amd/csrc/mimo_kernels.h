@@ -1,0 +1,58 @@
+// Internal interface between the C-ABI layer (mimo_abi.cpp) and the gfx950 kernels
+// (mimo_kernels.hip).  Not installed; the public surface is include/mimo_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mimo {
+
+constexpr int kWG = 256;        // threads per workgroup (4 wavefronts of 64)
+constexpr int kTile = 32;       // data rows per tile
+constexpr int kMaxNCB = 10;     // 16-wide feature column blocks one launch accumulates
+constexpr int kMaxD = 16;       // largest Dz the fused kernels cover (F = 153 features)
+
+// Where the per-tile weight table R (rows x K) comes from.
+enum Source : int { kSrcEstep = 0, kSrcWeights = 1, kSrcLabels = 2 };
+
+struct KernelArgs {
+  const double* Z;        // (N, D) row-major observations
+  int64_t N;
+  int D;                  // data dimension Dz
+  int K;                  // true number of components
+  int K16;                // ceil(K / 16) row blocks
+  int F16;                // padded feature count (multiple of 16)
+  int ZS, RS, LS;         // LDS row strides (doubles) of the z / feature / weight tiles
+  const double* theta;    // MFMA A-operand image of the parameter block: [K16][F16/4][64]
+  const uint8_t* feat;    // [F16][2] index pairs (a,b) into z~ = [z, 1, 0]
+  double* partials;       // [G][K16*16*F16 + 4] per-workgroup partial statistics + scalars
+  double* resp;           // (K,N) table: output of the E-step / input of kSrcWeights; may be null
+  double* logp;           // (K,N) l[k,n] output; may be null
+  double* lse;            // (N,) output; may be null
+  int32_t* labels;        // (N,) output of the Gibbs draw / input of kSrcLabels; may be null
+  const double* u;        // (N,) uniforms or null (=> in-kernel Philox)
+  uint64_t seed, sweep;
+  int64_t row0;
+  int gibbs;              // 0: softmax responsibilities, 1: categorical draw (one-hot weights)
+  int do_stats;
+  int64_t ntiles;
+};
+
+// feature count helpers (z~ = [z,1]; features = upper-triangular pairs of z~)
+inline int feat_count(int D) { return (D + 1) * (D + 2) / 2; }
+inline int feat_pad16(int D) { return (feat_count(D) + 15) / 16 * 16; }
+inline int feat_index(int D, int a, int b) {  // a <= b <= D
+  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
+}
+
+size_t fused_lds_bytes(const KernelArgs& a);
+int fused_grid(const KernelArgs& a, int num_cu);
+// returns hipSuccess or an error; sets *unsupported when (K, D, src) has no kernel
+hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
+hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
+hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
+                         double* S_packed, double* scalars3, hipStream_t stream);
+
+// host mirror of the in-kernel counter-based generator
+double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep);
+
+}  // namespace mimo

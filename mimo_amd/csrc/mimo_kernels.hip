@@ -1,0 +1,464 @@
+// gfx950 (MI355X / CDNA4) kernels of the mimo E-step / sufficient-statistics engine.
+//
+// Formulation.  With z~ = [z, 1] and the F = (D+1)(D+2)/2 features phi_f(z) = z~_a z~_b (a <= b),
+// the canonical log-density  l[k,n] = c_k + b_k.z_n - 1/2 z_n' W_k z_n  is the dense product
+//
+//        L (K x N) = Theta (K x F) . Phi' (F x N)
+//
+// and the responsibility-weighted sufficient statistics (n_k, sum r z, sum r z z') are
+//
+//        S (K x F) = R (K x N) . Phi (N x F) .
+//
+// Both run on the float64 matrix cores (v_mfma_f64_16x16x4_f64) and execute 2F flops per
+// (datum, component) each, which is the symmetric-minimal algorithmic count; the softmax /
+// categorical draw over k sits between the two products and never leaves LDS.  A workgroup
+// (4 wavefronts) walks a grid-stride sequence of 32-row tiles:
+//
+//   1. coalesced read of the (32, D) tile of Z into LDS                      (only HBM read)
+//   2. feature tile Phi (32 x F16) built once in LDS, shared by all waves and both products
+//   3. L tile = Theta.Phi': Theta's MFMA A-operand slices live in registers for the whole
+//      kernel (wave w owns component row-blocks w, w+4, ...)
+//   4. per-datum normalisation over k (8 lanes per datum): softmax -> r, or inverse-CDF
+//      categorical draw (host uniforms or in-kernel Philox4x32-10) -> one-hot r
+//   5. S += R.Phi accumulated in registers across all tiles of the workgroup
+//
+// Per-workgroup partial S blocks are written once at the end and summed in a fixed order by
+// reduce_partials (no float atomics: results are run-to-run identical).
+//
+// LDS bank layout (MI355X_MICROARCH.md, LDS): ds_read_b64 is serviced per 32-lane half over
+// 64 dword banks.  The feature tile row stride RS = F16 + 2 doubles (RS = 2 mod 4) makes both
+// MFMA operand reads conflict-free: step 3 reads Phi[row j][4s + q] (16 rows x 2 features per
+// half), step 5 reads Phi[row 8q + s][16cb + j] (2 rows 8 apart x 16 features per half).
+//
+// Reference behaviour reproduced (paths relative to the reference root):
+//   mimo/distributions/gaussian.py:510-521, bayesian.py:287-301, lingauss.py:330-345,
+//   bayesian.py:933-947 (log-density tables); mimo/mixtures/gmm.py:72-75,256-259 (softmax);
+//   mimo/utils/stats.py:8-21 (inverse-CDF draw: label = #{k : u*cum_K > cum_k});
+//   gaussian.py:491-502, lingauss.py:306-322, categorical.py:35-43 (statistics).
+#include "mimo_kernels.h"
+
+#include <math.h>
+
+namespace mimo {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  key = (seed_lo, seed_hi), counter = (row_lo, row_hi,
+// sweep_lo, sweep_hi); the uniform is the 53-bit float built from the first two output words.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline double philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep) {
+  uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32);
+  uint32_t c2 = (uint32_t)sweep, c3 = (uint32_t)(sweep >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep) {
+  return philox_uniform(seed, row, sweep);
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused tile kernel.  NCB: 16-wide feature column blocks (F16 = 16*NCB); RBW: component
+// row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
+// ------------------------------------------------------------------------------------------
+template <int NCB, int RBW, int SRC>
+__global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const KernelArgs a) {
+  constexpr int NS = 4 * NCB;  // contraction steps of 4 features
+  constexpr int T = kTile;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* Zs = reinterpret_cast<double*>(smem);  // [T][ZS]   z~ rows (z, 1, 0)
+  double* Ph = Zs + T * a.ZS;                    // [T][RS]   feature tile
+  double* Lt = Ph + T * a.RS;                    // [T][LS]   l -> e -> r per (row, component)
+  double* red = Lt + T * a.LS;                   // [16]      block-reduction scratch
+  uint8_t* fe = reinterpret_cast<uint8_t*>(red + 16);  // [F16][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
+  const int ZS = a.ZS, RS = a.RS, LS = a.LS;
+  const int Kpad = K16 * 16;
+  const int64_t N = a.N;
+
+  for (int e = tid; e < F16 * 2; e += kWG) fe[e] = a.feat[e];
+
+  // Theta in MFMA A-operand layout: lane (i = lane&15, kk = lane>>4) of slice s holds
+  // Theta[16 rb + i][4 s + kk]; the image is prepared on the host so each slice is one
+  // coalesced 512-byte read.
+  double th[RBW][NS];
+  if constexpr (SRC == kSrcEstep) {
+#pragma unroll
+    for (int i = 0; i < RBW; ++i) {
+      const int rb = wave + 4 * i;
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        th[i][s] = rb < K16 ? a.theta[((size_t)rb * NS + s) * 64 + lane] : 0.0;
+    }
+  }
+
+  d4 sacc[RBW][NCB];
+#pragma unroll
+  for (int i = 0; i < RBW; ++i)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) sacc[i][cb] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double sc_lse = 0.0, sc_rl = 0.0;
+
+  for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const int64_t n0 = t * T;
+    __syncthreads();  // the previous tile's readers of Zs / Ph / Lt are done
+
+    // ---- 1. z~ tile ------------------------------------------------------------------
+    {
+      const int64_t base = n0 * D, total = N * D;
+      for (int e = tid; e < T * D; e += kWG) {
+        const int pt = e / D, d = e - pt * D;
+        Zs[pt * ZS + d] = (base + e) < total ? a.Z[base + e] : 0.0;
+      }
+      if (tid < T) {
+        Zs[tid * ZS + D] = (n0 + tid) < N ? 1.0 : 0.0;  // rows past N contribute nothing
+        Zs[tid * ZS + D + 1] = 0.0;                     // padded features read this slot
+      }
+    }
+    __syncthreads();
+
+    // ---- 2. feature tile (+ externally supplied weights) --------------------------------
+    for (int e = tid; e < T * F16; e += kWG) {
+      const int pt = e & (T - 1), f = e >> 5;
+      Ph[pt * RS + f] = Zs[pt * ZS + fe[2 * f]] * Zs[pt * ZS + fe[2 * f + 1]];
+    }
+    if constexpr (SRC == kSrcWeights) {
+      for (int e = tid; e < T * Kpad; e += kWG) {
+        const int pt = e & (T - 1), k = e >> 5;
+        const int64_t n = n0 + pt;
+        Lt[pt * LS + k] = (k < K && n < N) ? a.resp[(int64_t)k * N + n] : 0.0;
+      }
+    } else if constexpr (SRC == kSrcLabels) {
+      for (int e = tid; e < T * Kpad; e += kWG) {
+        const int pt = e & (T - 1), k = e >> 5;
+        const int64_t n = n0 + pt;
+        Lt[pt * LS + k] = (n < N && a.labels[n] == k) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+
+    if constexpr (SRC == kSrcEstep) {
+      // ---- 3. L tile = Theta . Phi' ------------------------------------------------------
+      // B operand: lane (kk = q, col = j) holds Phi[row 16 g + j][4 s + q].
+      // C/D layout of v_mfma_f64_16x16x4_f64: reg r of lane (q, j) = row q + 4 r, col j.
+#pragma unroll
+      for (int i = 0; i < RBW; ++i) {
+        const int rb = wave + 4 * i;
+        if (rb < K16) {
+          d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+          const double* p0 = Ph + j * RS + q;
+          const double* p1 = Ph + (16 + j) * RS + q;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(th[i][s], p0[4 * s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(th[i][s], p1[4 * s], acc1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Lt[j * LS + 16 * rb + q + 4 * r] = acc0[r];
+            Lt[(16 + j) * LS + 16 * rb + q + 4 * r] = acc1[r];
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- 4. normalise over k: 8 lanes per datum ------------------------------------------
+      {
+        const int pt = 8 * wave + (lane & 7), part = lane >> 3;
+        const int CPP = 2 * K16, k0 = part * CPP;  // Kpad / 8 components per lane
+        const int64_t n = n0 + pt;
+        const bool valid = n < N;
+        double* row = Lt + pt * LS;
+
+        double m = -INFINITY;
+        for (int c = 0; c < CPP; ++c) {
+          const int k = k0 + c;
+          if (k < K) m = fmax(m, row[k]);
+        }
+        m = fmax(m, __shfl_xor(m, 8));
+        m = fmax(m, __shfl_xor(m, 16));
+        m = fmax(m, __shfl_xor(m, 32));
+
+        double ssum = 0.0, sel = 0.0;
+        for (int c = 0; c < CPP; ++c) {
+          const int k = k0 + c;
+          if (k < K) {
+            const double l = row[k];
+            const double e = exp(l - m);
+            ssum += e;
+            sel += e * l;
+            if (a.logp && valid) a.logp[(int64_t)k * N + n] = l;
+            if (!a.gibbs) row[k] = e;
+          } else {
+            row[k] = a.gibbs ? -INFINITY : 0.0;
+          }
+        }
+        ssum += __shfl_xor(ssum, 8);  sel += __shfl_xor(sel, 8);
+        ssum += __shfl_xor(ssum, 16); sel += __shfl_xor(sel, 16);
+        ssum += __shfl_xor(ssum, 32); sel += __shfl_xor(sel, 32);
+        const double lse = m + log(ssum);
+
+        if (part == 0 && valid) {
+          sc_lse += lse;
+          sc_rl += sel / ssum;
+          if (a.lse) a.lse[n] = lse;
+        }
+
+        if (!a.gibbs) {
+          const double inv = 1.0 / ssum;
+          for (int c = 0; c < CPP; ++c) {
+            const int k = k0 + c;
+            if (k < K) {
+              const double r = valid ? row[k] * inv : 0.0;
+              row[k] = r;
+              if (a.resp && valid) a.resp[(int64_t)k * N + n] = r;
+            }
+          }
+        } else {
+          // inverse-CDF draw (mimo/utils/stats.py:10-17): p = exp(l - lse), cum = cumsum_k p,
+          // label = #{k : u * cum[K-1] > cum[k]}.
+          double cum = 0.0;
+          for (int c = 0; c < CPP; ++c) {
+            const int k = k0 + c;
+            if (k < K) cum += exp(row[k] - lse);
+            row[k] = cum;  // local inclusive cumulative sum
+          }
+          double incl = cum;  // inclusive scan over the 8 parts of this datum
+          {
+            double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
+            v = __shfl_up(incl, 16);        if (part >= 2) incl += v;
+            v = __shfl_up(incl, 32);        if (part >= 4) incl += v;
+          }
+          double excl = __shfl_up(incl, 8);
+          if (part == 0) excl = 0.0;
+          const double ctot = __shfl(excl + cum, 56 + (lane & 7));  // == last cum value
+          const double uu = a.u ? (valid ? a.u[n] : 0.0)
+                                : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+          const double thr = uu * ctot;
+          int cnt = 0;
+          for (int c = 0; c < CPP; ++c) {
+            const int k = k0 + c;
+            if (k < K) cnt += (thr > excl + row[k]) ? 1 : 0;
+          }
+          cnt += __shfl_xor(cnt, 8);
+          cnt += __shfl_xor(cnt, 16);
+          cnt += __shfl_xor(cnt, 32);
+          const int label = cnt < K ? cnt : K - 1;
+          for (int c = 0; c < CPP; ++c) {
+            const int k = k0 + c;
+            row[k] = (valid && k == label) ? 1.0 : 0.0;
+          }
+          if (part == 0 && valid && a.labels) a.labels[n] = label;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- 5. S += R . Phi ----------------------------------------------------------------
+    // step s contracts the 4 rows {s, s+8, s+16, s+24}: A lane (i = j, kk = q) = R[8q+s][16rb+j],
+    // B lane (kk = q, col = j) = Phi[8q+s][16cb+j].
+    if (a.do_stats) {
+#pragma unroll
+      for (int i = 0; i < RBW; ++i) {
+        const int rb = wave + 4 * i;
+        if (rb < K16) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const int pt = 8 * q + s;
+            const double av = Lt[pt * LS + 16 * rb + j];
+            const double* pb = Ph + pt * RS + j;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * cb], sacc[i][cb], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- per-workgroup partials ------------------------------------------------------------
+  const size_t pstride = (size_t)Kpad * F16 + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride;
+#pragma unroll
+  for (int i = 0; i < RBW; ++i) {
+    const int rb = wave + 4 * i;
+    if (rb < K16) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          P[(size_t)(16 * rb + q + 4 * r) * F16 + 16 * cb + j] = sacc[i][cb][r];
+    }
+  }
+  sc_lse = wave_sum(sc_lse);
+  sc_rl = wave_sum(sc_rl);
+  __syncthreads();
+  if (lane == 0) { red[2 * wave] = sc_lse; red[2 * wave + 1] = sc_rl; }
+  __syncthreads();
+  if (tid == 0) {
+    P[(size_t)Kpad * F16 + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+    P[(size_t)Kpad * F16 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    P[(size_t)Kpad * F16 + 2] = 0.0;
+    P[(size_t)Kpad * F16 + 3] = 0.0;
+  }
+}
+
+// out[e] = sum_g partials[g][e] in a fixed order (4 interleaved chains, then a fixed tree).
+__global__ void reduce_partials(const double* __restrict__ partials, int G, int64_t stride,
+                                double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= stride) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int g = 0;
+  for (; g + 3 < G; g += 4) {
+    s0 += partials[(int64_t)g * stride + e];
+    s1 += partials[(int64_t)(g + 1) * stride + e];
+    s2 += partials[(int64_t)(g + 2) * stride + e];
+    s3 += partials[(int64_t)(g + 3) * stride + e];
+  }
+  for (; g < G; ++g) s0 += partials[(int64_t)g * stride + e];
+  out[e] = (s0 + s1) + (s2 + s3);
+}
+
+// feature-space block [Kpad][F16] (+4 scalars) -> packed S[K][1 + D + D*D] and scalars[3]
+__global__ void unpack_stats(const double* __restrict__ red, const uint8_t* __restrict__ feat,
+                             int K, int D, int F16, double* __restrict__ S,
+                             double* __restrict__ scalars) {
+  const int F = (D + 1) * (D + 2) / 2;
+  const int Kpad = (K + 15) / 16 * 16;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (S && e < (int64_t)K * F) {
+    const int k = (int)(e / F), f = (int)(e - (int64_t)k * F);
+    const int aa = feat[2 * f], bb = feat[2 * f + 1];
+    const double v = red[(int64_t)k * F16 + f];
+    double* Sk = S + (int64_t)k * (1 + D + D * D);
+    if (aa == D) Sk[0] = v;                // (D,D): n_k
+    else if (bb == D) Sk[1 + aa] = v;      // (a,D): sum r z_a
+    else { Sk[1 + D + aa * D + bb] = v; Sk[1 + D + bb * D + aa] = v; }
+  }
+  if (scalars && e == 0) {
+    const double slse = red[(int64_t)Kpad * F16 + 0], srl = red[(int64_t)Kpad * F16 + 1];
+    scalars[0] = slse;        // sum_n logsumexp_k l
+    scalars[1] = srl;         // sum_n sum_k r l
+    scalars[2] = slse - srl;  // -sum r log r  (log r = l - lse, sum_k r = 1)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+size_t fused_lds_bytes(const KernelArgs& a) {
+  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16) + (size_t)a.F16 * 2;
+}
+
+static int rbw_for(int K16) { return K16 <= 4 ? 1 : 4; }
+
+int fused_grid(const KernelArgs& a, int num_cu) {
+  const int per_cu = rbw_for(a.K16) == 1 ? 2 : 1;
+  int64_t g = (int64_t)num_cu * per_cu;
+  if (g > a.ntiles) g = a.ntiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+typedef void (*fused_fn)(const KernelArgs);
+
+template <int NCB, int RBW>
+static fused_fn pick_src(int src) {
+  switch (src) {
+    case kSrcEstep: return fused_kernel<NCB, RBW, kSrcEstep>;
+    case kSrcWeights: return fused_kernel<NCB, RBW, kSrcWeights>;
+    case kSrcLabels: return fused_kernel<NCB, RBW, kSrcLabels>;
+  }
+  return nullptr;
+}
+
+template <int RBW>
+static fused_fn pick_ncb(int ncb, int src) {
+  switch (ncb) {
+    case 1: return pick_src<1, RBW>(src);
+    case 2: return pick_src<2, RBW>(src);
+    case 3: return pick_src<3, RBW>(src);
+    case 4: return pick_src<4, RBW>(src);
+    case 5: return pick_src<5, RBW>(src);
+    case 6: return pick_src<6, RBW>(src);
+    case 7: return pick_src<7, RBW>(src);
+    case 8: return pick_src<8, RBW>(src);
+    case 9: return pick_src<9, RBW>(src);
+    case 10: return pick_src<10, RBW>(src);
+  }
+  return nullptr;
+}
+
+// RBW = 4 with Theta in registers only fits the register file for NCB <= 4 (D <= 9).
+static fused_fn pick_rbw4(int ncb, int src) {
+  if (src == kSrcEstep) {
+    switch (ncb) {
+      case 1: return fused_kernel<1, 4, kSrcEstep>;
+      case 2: return fused_kernel<2, 4, kSrcEstep>;
+      case 3: return fused_kernel<3, 4, kSrcEstep>;
+      case 4: return fused_kernel<4, 4, kSrcEstep>;
+    }
+    return nullptr;
+  }
+  return pick_ncb<4>(ncb, src);
+}
+
+hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream,
+                        bool* unsupported) {
+  *unsupported = false;
+  const int ncb = a.F16 / 16;
+  fused_fn fn = nullptr;
+  if (a.K16 <= 16 && ncb >= 1 && ncb <= kMaxNCB)
+    fn = rbw_for(a.K16) == 1 ? pick_ncb<1>(ncb, src) : pick_rbw4(ncb, src);
+  if (!fn) { *unsupported = true; return hipSuccess; }
+  const size_t lds = fused_lds_bytes(a);
+  if (lds > 160 * 1024) { *unsupported = true; return hipSuccess; }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out,
+                         hipStream_t stream) {
+  const int bs = 256;
+  hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((stride + bs - 1) / bs)), dim3(bs), 0, stream,
+                     partials, G, stride, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
+                         double* S_packed, double* scalars3, hipStream_t stream) {
+  const int bs = 256;
+  const int64_t total = (int64_t)K * feat_count(D);
+  hipLaunchKernelGGL(unpack_stats, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, stream,
+                     reduced, feat, K, D, F16, S_packed, scalars3);
+  return hipGetLastError();
+}
+
+}  // namespace mimo

@@ -1,0 +1,218 @@
+"""HipEngine — the O(N) side of every mixture driver, on one MI355X.
+
+Thin NumPy-facing wrapper over the C ABI of libmimo_hip.so (include/mimo_hip.h).  The
+engine evaluates the canonical form  l[k,n] = c_k + b_k.z_n - 1/2 z_n' W_k z_n  (SURVEY.md §8
+row A0) for whatever (c, b, W) the host-side distribution classes derive from their point
+estimates (Gibbs / EM) or posterior expectations (mean-field VI), and returns the
+responsibility-weighted sufficient statistics those classes' conjugate updates consume.
+
+There is no CPU fallback here: constructing an engine without the HIP library or without a
+GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class SuffStats:
+    """Packed per-component statistics  n_k, sum_n r z, sum_n r z z'  (float64)."""
+
+    __slots__ = ("n", "sx", "sxx")
+
+    def __init__(self, n, sx, sxx):
+        self.n, self.sx, self.sxx = n, sx, sxx
+
+    @staticmethod
+    def from_packed(S, K, D):
+        S = np.asarray(S).reshape(K, 1 + D + D * D)
+        return SuffStats(S[:, 0].copy(), S[:, 1:1 + D].copy(), S[:, 1 + D:].reshape(K, D, D).copy())
+
+    def packed(self):
+        K, D = self.sx.shape
+        return np.concatenate([self.n[:, None], self.sx, self.sxx.reshape(K, D * D)], axis=1)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipEngine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.mimo_create(C.byref(self._ctx), int(device))
+        if rc != 0:
+            msg = self._lib.mimo_last_error(None).decode()
+            self._ctx = None
+            raise _lib.MimoHipError(f"mimo_create failed ({rc}): {msg}")
+        self.device = int(device)
+        self.N = 0
+        self.D = 0
+        self._keepalive = None
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.mimo_last_error(self._ctx).decode()
+            if rc == _lib.E_INVALID:
+                raise ValueError(msg)
+            raise _lib.MimoHipError(f"libmimo_hip error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mimo_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.mimo_set_stream(self._ctx, C.c_void_p(stream_ptr or 0)))
+
+    def set_row_offset(self, row0):
+        self._check(self._lib.mimo_set_row_offset(self._ctx, int(row0)))
+
+    def profile(self, enable=True):
+        self._check(self._lib.mimo_profile(self._ctx, 1 if enable else 0))
+
+    def profile_read(self, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.mimo_profile_read(self._ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    # -- data -----------------------------------------------------------------------------
+    def upload(self, Z):
+        """Z: (N, Dz) float64 host array (copied once) or a CUDA/HIP torch tensor (borrowed)."""
+        if hasattr(Z, "data_ptr") and getattr(Z, "is_cuda", False):
+            import torch
+            if Z.dtype != torch.float64 or not Z.is_contiguous() or Z.dim() != 2:
+                raise ValueError("device data must be a contiguous (N, Dz) float64 tensor")
+            self._keepalive = Z
+            self.N, self.D = int(Z.shape[0]), int(Z.shape[1])
+            self._check(self._lib.mimo_attach(self._ctx, C.c_void_p(Z.data_ptr()), self.N, self.D))
+            return
+        Z = _f64(Z)
+        if Z.ndim != 2:
+            raise ValueError("data must be (N, Dz)")
+        self.N, self.D = int(Z.shape[0]), int(Z.shape[1])
+        self._keepalive = None
+        self._check(self._lib.mimo_upload(self._ctx, _ptr(Z), self.N, self.D))
+
+    # -- hot path -------------------------------------------------------------------------
+    def _params(self, c, b, W):
+        c, b, W = _f64(c), _f64(b), _f64(W)
+        K = c.shape[0]
+        if b.shape != (K, self.D) or W.shape != (K, self.D, self.D):
+            raise ValueError(f"parameter shapes {c.shape}, {b.shape}, {W.shape} do not match K={K}, Dz={self.D}")
+        return c, b, W, K
+
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False):
+        """Fused E-step.  Returns (SuffStats | None, scalars[3])."""
+        c, b, W, K = self._params(c, b, W)
+        flags = ((_lib.F_KEEP_RESP if keep_resp else 0) | (_lib.F_KEEP_LOGP if keep_logp else 0)
+                 | (_lib.F_KEEP_LSE if keep_lse else 0) | (0 if stats else _lib.F_NO_STATS))
+        S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
+        sc = np.empty(3)
+        self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, flags,
+                                         _ptr(S) if stats else None, _ptr(sc)))
+        self._K = K
+        return (SuffStats.from_packed(S, K, self.D) if stats else None), sc
+
+    def estep_device(self, c, b, W, S_dev_ptr, scalars_dev_ptr):
+        """Asynchronous fused E-step writing packed S / scalars to device pointers."""
+        c, b, W, K = self._params(c, b, W)
+        self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_DEVICE_OUT,
+                                         C.c_void_p(S_dev_ptr), C.c_void_p(scalars_dev_ptr)))
+        self._K = K
+
+    def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True,
+                     keep_logp=False):
+        """Fused Gibbs label step.  Returns (labels int32 | None, SuffStats | None)."""
+        c, b, W, K = self._params(c, b, W)
+        flags = (0 if stats else _lib.F_NO_STATS) | (_lib.F_KEEP_LOGP if keep_logp else 0)
+        S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
+        labels = np.empty(self.N, dtype=np.int32) if return_labels else None
+        if u is not None:
+            u = _f64(u).reshape(-1)
+            if u.shape[0] != self.N:
+                raise ValueError("u must hold one uniform per datum")
+        self._check(self._lib.mimo_gibbs_labels(
+            self._ctx, _ptr(c), _ptr(b), _ptr(W), K, int(seed), int(sweep),
+            _ptr(u) if u is not None else None, flags,
+            _ptr(labels) if return_labels else None, _ptr(S) if stats else None))
+        self._K = K
+        return labels, (SuffStats.from_packed(S, K, self.D) if stats else None)
+
+    def gibbs_labels_device(self, c, b, W, seed, sweep, S_dev_ptr):
+        c, b, W, K = self._params(c, b, W)
+        self._check(self._lib.mimo_gibbs_labels(
+            self._ctx, _ptr(c), _ptr(b), _ptr(W), K, int(seed), int(sweep), None,
+            _lib.F_DEVICE_OUT, None, C.c_void_p(S_dev_ptr)))
+        self._K = K
+
+    def weighted_stats(self, resp=None, K=None):
+        """Statistics for arbitrary (K,N) weights; resp=None reuses the resident table."""
+        if resp is None:
+            K = int(K if K is not None else self._K)
+            p = None
+        else:
+            resp = _f64(resp)
+            if resp.ndim != 2 or resp.shape[1] != self.N:
+                raise ValueError("weights must be (K, N)")
+            K = resp.shape[0]
+            p = _ptr(resp)
+        S = np.empty((K, 1 + self.D + self.D * self.D))
+        self._check(self._lib.mimo_weighted_stats(self._ctx, p, K, 0, _ptr(S)))
+        return SuffStats.from_packed(S, K, self.D)
+
+    def label_stats(self, labels, K):
+        """Statistics of hard labels (no one-hot table); labels=None reuses the resident draw."""
+        K = int(K)
+        if labels is None:
+            p = None
+        else:
+            labels = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+            if labels.shape[0] != self.N:
+                raise ValueError("labels must hold one entry per datum")
+            if labels.size and (labels.min() < 0 or labels.max() >= K):
+                raise ValueError("labels out of range")  # mirrors the assert in one_hot (data.py:162)
+            p = _ptr(labels)
+        S = np.empty((K, 1 + self.D + self.D * self.D))
+        self._check(self._lib.mimo_label_stats(self._ctx, p, K, 0, _ptr(S)))
+        return SuffStats.from_packed(S, K, self.D)
+
+    # -- copy-outs ------------------------------------------------------------------------
+    def get_resp(self, K=None):
+        out = np.empty((int(K if K is not None else self._K), self.N))
+        self._check(self._lib.mimo_get_resp(self._ctx, _ptr(out)))
+        return out
+
+    def get_logp(self, K=None):
+        out = np.empty((int(K if K is not None else self._K), self.N))
+        self._check(self._lib.mimo_get_logp(self._ctx, _ptr(out)))
+        return out
+
+    def get_lse(self):
+        out = np.empty(self.N)
+        self._check(self._lib.mimo_get_lse(self._ctx, _ptr(out)))
+        return out
+
+    def get_labels(self):
+        out = np.empty(self.N, dtype=np.int32)
+        self._check(self._lib.mimo_get_labels(self._ctx, _ptr(out)))
+        return out
+
+
+def philox_uniforms(seed, rows, sweep):
+    """Host mirror of the in-kernel Philox4x32-10 stream (one uniform per global row index)."""
+    lib = _lib.load()
+    return np.array([lib.mimo_philox_uniform(int(seed), int(r), int(sweep)) for r in rows])
