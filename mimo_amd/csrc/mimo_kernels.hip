@@ -122,28 +122,61 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 
   double sc_lse = 0.0, sc_rl = 0.0;
 
+  // Z tile staging: every thread owns up to two elements of the (T, D) tile; the NEXT tile is
+  // fetched into registers while the current one is processed, so the HBM latency is off the
+  // critical path (T*D <= 512 for D <= 16).
+  int zoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + kWG * i;
+    const int pt = e / D;
+    zoff[i] = e < T * D ? pt * ZS + (e - pt * D) : -1;
+  }
+  double zr[2];
+  auto load_z = [&](int64_t t) {
+    const int64_t base = t * T * D, total = N * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t g = base + tid + kWG * i;
+      zr[i] = (zoff[i] >= 0 && g < total) ? a.Z[g] : 0.0;
+    }
+  };
+  auto store_z = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (zoff[i] >= 0) Zs[zoff[i]] = zr[i];
+    if (tid < T) {
+      Zs[tid * ZS + D] = (t * T + tid) < N ? 1.0 : 0.0;  // rows past N contribute nothing
+      Zs[tid * ZS + D + 1] = 0.0;                        // padded features read this slot
+    }
+  };
+  load_z(blockIdx.x);
+  store_z(blockIdx.x);
+  load_z((int64_t)blockIdx.x + gridDim.x);
+
+  // feature build: thread (row = tid & 31, g = tid >> 5) produces the 2*NCB consecutive features
+  // [g*2*NCB, (g+1)*2*NCB); their (a,b) byte pairs are NCB consecutive 32-bit words of the table.
+  const int frow = tid & (T - 1), fgrp = tid >> 5;
+  const uint32_t* few = reinterpret_cast<const uint32_t*>(fe) + fgrp * NCB;
+
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
-    __syncthreads();  // the previous tile's readers of Zs / Ph / Lt are done
-
-    // ---- 1. z~ tile ------------------------------------------------------------------
-    {
-      const int64_t base = n0 * D, total = N * D;
-      for (int e = tid; e < T * D; e += kWG) {
-        const int pt = e / D, d = e - pt * D;
-        Zs[pt * ZS + d] = (base + e) < total ? a.Z[base + e] : 0.0;
-      }
-      if (tid < T) {
-        Zs[tid * ZS + D] = (n0 + tid) < N ? 1.0 : 0.0;  // rows past N contribute nothing
-        Zs[tid * ZS + D + 1] = 0.0;                     // padded features read this slot
-      }
-    }
-    __syncthreads();
+    __syncthreads();  // z~ tile of this step is in LDS; the previous tile's readers are done
 
     // ---- 2. feature tile (+ externally supplied weights) --------------------------------
-    for (int e = tid; e < T * F16; e += kWG) {
-      const int pt = e & (T - 1), f = e >> 5;
-      Ph[pt * RS + f] = Zs[pt * ZS + fe[2 * f]] * Zs[pt * ZS + fe[2 * f + 1]];
+    {
+      const double* zrow = Zs + frow * ZS;
+      double* prow = Ph + frow * RS + fgrp * (2 * NCB);
+      uint32_t w[NCB];
+#pragma unroll
+      for (int jj = 0; jj < NCB; ++jj) w[jj] = few[jj];
+#pragma unroll
+      for (int jj = 0; jj < NCB; ++jj) {
+        const double za0 = zrow[w[jj] & 255u], zb0 = zrow[(w[jj] >> 8) & 255u];
+        const double za1 = zrow[(w[jj] >> 16) & 255u], zb1 = zrow[w[jj] >> 24];
+        prow[2 * jj] = za0 * zb0;
+        prow[2 * jj + 1] = za1 * zb1;
+      }
     }
     if constexpr (SRC == kSrcWeights) {
       for (int e = tid; e < T * Kpad; e += kWG) {
@@ -297,6 +330,10 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
         }
       }
     }
+
+    // ---- 1'. stage the next tile's z~ rows (Zs was last read before the barrier after step 2)
+    store_z(t + gridDim.x);
+    load_z(t + 2 * (int64_t)gridDim.x);
   }
 
   // ---- per-workgroup partials ------------------------------------------------------------

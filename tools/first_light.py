@@ -19,7 +19,9 @@ def stats(Z, R):
 
 
 def rel(a, b):
-    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
 
 
 def run(N, D, K, rng, eng):
@@ -35,7 +37,7 @@ def run(N, D, K, rng, eng):
     n, sx, sxx = stats(Z, R)
     errs = dict(logp=rel(eng.get_logp(), L), lse=rel(eng.get_lse(), lse), resp=rel(eng.get_resp(), R),
                 n=rel(S.n, n), sx=rel(S.sx, sx), sxx=rel(S.sxx, sxx),
-                s0=abs(sc[0] - lse.sum()) / abs(lse.sum()), s1=abs(sc[1] - (R * L).sum()) / abs((R * L).sum()))
+                s0=abs(sc[0] - lse.sum()) / max(1e-300, abs(lse.sum())), s1=abs(sc[1] - (R * L).sum()) / max(1e-300, abs((R * L).sum())))
     # weighted stats with arbitrary weights
     Wt = rng.random((K, N)); Wt /= Wt.sum(0)
     S2 = eng.weighted_stats(Wt)
