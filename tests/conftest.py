@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+GMM_CASES = ["gmm_c1_d2_k4_dir", "gmm_c2_d16_k16_dir", "gmm_c2_d16_k64_dir", "gmm_c3_d8_k32_stick",
+             "gmm_c5_d32_k16_dir", "gmm_tail_d5_k7_stick"]
+ILR_CASES = ["ilr_c4_dx8_dy4_k16_stick", "ilr_dx1_dy1_k6_dir"]
+GIBBS_CASES = ["gibbs_c1_trace", "gibbs_stick_trace"]
+
+
+def gating_of(g, prefix):
+    kind = str(g["gating_kind"])
+    if kind == "dirichlet":
+        return kind, g[prefix + "_alphas"]
+    return kind, (g[prefix + "_gammas"], g[prefix + "_deltas"])
+
+
+def nw_of(g, prefix):
+    return tuple(g[f"{prefix}_{k}"] for k in ("mus", "kappas", "psis", "nus"))
+
+
+def mnw_of(g, prefix):
+    return tuple(g[f"{prefix}_{k}"] for k in ("Ms", "Ks", "psis", "nus"))
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One HIP engine for the whole GPU session (fails loudly if the library / GPU is missing)."""
+    from mimo_amd.engine import HipEngine
+    return HipEngine(0)

@@ -1,0 +1,299 @@
+"""Generate golden vectors by importing the REFERENCE (hanyas/mimo) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz (inputs and the reference's outputs only — no reference code).  The
+reference lives at /root/reference, is read-only, and never travels to the GPU box; the committed
+.npz files do.  Seeds are fixed, so the files are reproducible bit-for-bit on this image
+(numpy 2.2.6 / scipy 1.15.3 / OpenBLAS 0.3.29).
+"""
+import copy
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import numpy.random as npr
+
+import mimo.utils.stats as ref_stats
+from mimo.distributions import (Dirichlet, TruncatedStickBreaking, CategoricalWithDirichlet,
+                                CategoricalWithStickBreaking, StackedNormalWisharts,
+                                StackedGaussiansWithNormalWisharts, StackedMatrixNormalWisharts,
+                                StackedLinearGaussiansWithMatrixNormalWisharts)
+from mimo.mixtures import BayesianMixtureOfGaussians, BayesianMixtureOfLinearGaussians
+from mimo.utils.data import one_hot
+
+from oracle.mimo_oracle import philox_uniforms   # only the counter-based uniforms (not in the reference)
+
+PHILOX_SEED, PHILOX_SWEEP = 1337, 3
+
+
+class FixedUniforms:
+    """Shim for the single npr.random((1,N)) call of sample_discrete_from_log (stats.py:14)."""
+
+    def __init__(self, u):
+        self.u = u
+
+    def __enter__(self):
+        self._orig = ref_stats.npr.random
+        ref_stats.npr.random = lambda size=None: np.reshape(self.u, size)
+        return self
+
+    def __exit__(self, *a):
+        ref_stats.npr.random = self._orig
+
+
+def make_data(N, D, n_clusters=4):
+    A = npr.randn(D, D) / np.sqrt(D)
+    shifts = 4.0 * npr.randn(n_clusters, D)
+    X = npr.randn(N, D) @ A + shifts[npr.randint(n_clusters, size=N)]
+    return np.ascontiguousarray(X)
+
+
+def make_gating(K, kind):
+    if kind == 'dirichlet':
+        prior = Dirichlet(dim=K, alphas=np.ones((K,)))
+        return CategoricalWithDirichlet(dim=K, prior=prior)
+    prior = TruncatedStickBreaking(dim=K, gammas=np.ones((K,)), deltas=5. * np.ones((K,)))
+    return CategoricalWithStickBreaking(dim=K, prior=prior)
+
+
+def gating_params(g, kind):
+    if kind == 'dirichlet':
+        return dict(alphas=np.array(g.alphas, dtype=float))
+    return dict(gammas=np.array(g.gammas, dtype=float), deltas=np.array(g.deltas, dtype=float))
+
+
+def put(out, prefix, d):
+    for k, v in d.items():
+        out[f"{prefix}_{k}"] = np.asarray(v)
+
+
+def nw_params(nw):
+    return dict(mus=nw.mus, kappas=nw.kappas, psis=nw.psis, nus=nw.nus)
+
+
+def mnw_params(p):
+    return dict(Ms=p.Ms, Ks=p.Ks, psis=p.psis, nus=p.nus)
+
+
+def gmm_case(name, N, D, K, kind, seed, vi_iters=20):
+    npr.seed(seed)
+    X = make_data(N, D)
+    gating = make_gating(K, kind)
+    prior = StackedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K,)),
+                                  psis=np.stack(K * [np.eye(D)]), nus=(D + 1.) * np.ones((K,)) + 1e-8)
+    comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior)
+    model = BayesianMixtureOfGaussians(gating=gating, components=comps)
+
+    out = dict(X=X, gating_kind=np.array(kind), K=np.array(K), D=np.array(D))
+    put(out, "prior", nw_params(model.components.prior))
+    put(out, "gprior", gating_params(model.gating.prior, kind))
+
+    # posterior from one M-step on seeded random responsibilities (gmm.py:265-267, 289-291)
+    resp0 = npr.rand(K, N)
+    resp0 /= np.sum(resp0, axis=0)
+    out["resp0"] = resp0
+    st0 = model.components.likelihood.weighted_statistics(X.copy(), resp0)          # A10
+    put(out, "stats0", dict(xk=st0[0], nk=st0[1], xxTk=st0[2]))
+    out["counts0"] = model.gating.likelihood.weighted_statistics(None, resp0)       # A12
+    model.meanfield_update_parameters(X.copy(), resp0)                              # A13 (+ rvs)
+    put(out, "post", nw_params(model.components.posterior))
+    put(out, "gpost", gating_params(model.gating.posterior, kind))
+    put(out, "lik", dict(mus=model.components.likelihood.mus, lmbdas=model.components.likelihood.lmbdas,
+                         probs=model.gating.likelihood.probs))
+
+    # Gibbs / EM form (A1, A2)
+    out["A1_loglik"] = model.components.likelihood.log_likelihood(X.copy())
+    out["A2_lcl"] = model.likelihood.log_complete_likelihood(X.copy())
+    out["A2_resp"] = model.likelihood.responsibilities(X.copy())
+    out["A2_ll"] = model.likelihood.log_likelihood(X.copy())
+
+    # VI form (A3, A4) and the expectations that feed it
+    es = model.components.posterior.expected_statistics()
+    put(out, "estats", dict(a=es[0], b=es[1], c=es[2], d=es[3]))
+    out["A3_eloglik"] = model.components.expected_log_likelihood(X.copy())
+    out["A4_elcl"] = model.expected_log_complete_likelihood(X.copy())
+    eresp = model.expected_responsibilities(X.copy())
+    out["A4_eresp"] = eresp
+    out["A4_ell"] = model.expected_log_likelihood(X.copy())
+
+    # statistics of the VI responsibilities (A10, A12)
+    st = model.components.likelihood.weighted_statistics(X.copy(), eresp)
+    put(out, "stats", dict(xk=st[0], nk=st[1], xxTk=st[2]))
+    out["counts"] = model.gating.likelihood.weighted_statistics(None, eresp)
+
+    # ELBO terms at the current posterior (A14)
+    out["vlb_obs"] = model.variational_lowerbound_obs(X.copy(), eresp)
+    out["vlb_labels"] = model.variational_lowerbound_labels(eresp)
+    out["vlb_gating"] = model.gating.variational_lowerbound()
+    out["vlb_comps"] = model.components.variational_lowerbound()
+    out["vlb_total"] = model.variational_lowerbound(X.copy(), eresp)
+
+    # label draw (A8) with captured uniforms: MT19937 uniforms and the engine's Philox uniforms
+    u_mt = npr.random(size=(1, N))
+    with FixedUniforms(u_mt):
+        _, labels_mt = model.resample_labels(X.copy())
+    u_ph = philox_uniforms(PHILOX_SEED, np.arange(N), PHILOX_SWEEP)
+    with FixedUniforms(u_ph):
+        _, labels_ph = model.resample_labels(X.copy())
+    out["u_mt"], out["labels_mt"], out["labels_philox"] = u_mt.ravel(), labels_mt, labels_ph
+    oh = one_hot(labels_mt, K)                                                       # A9
+    stl = model.components.likelihood.weighted_statistics(X.copy(), oh)
+    put(out, "lstats", dict(xk=stl[0], nk=stl[1], xxTk=stl[2]))
+    out["lcounts"] = model.gating.likelihood.statistics(labels_mt)
+
+    # conjugate update from the VI responsibilities (A13) on a copy
+    m2 = copy.deepcopy(model)
+    m2.meanfield_update_parameters(X.copy(), eresp)
+    put(out, "post2", nw_params(m2.components.posterior))
+    put(out, "gpost2", gating_params(m2.gating.posterior, kind))
+
+    # (7) ELBO trace of meanfield_coordinate_descent(randomize=False) from this posterior
+    m3 = copy.deepcopy(model)
+    vlb = m3.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=vi_iters, tol=0., progress_bar=False)
+    out["vi_vlb"] = np.array(vlb)
+    put(out, "vi_post", nw_params(m3.components.posterior))
+    put(out, "vi_gpost", gating_params(m3.gating.posterior, kind))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.size > 4096})
+
+
+def gibbs_trace_case(name, N, D, K, kind, seed, sweeps=5):
+    """(8) seeded Gibbs trace pinning the host-RNG call order of gmm.py:207-225."""
+    npr.seed(seed)
+    X = make_data(N, D)
+    gating = make_gating(K, kind)
+    prior = StackedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K,)),
+                                  psis=np.stack(K * [np.eye(D)]), nus=(D + 1.) * np.ones((K,)) + 1e-8)
+    comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior)
+    model = BayesianMixtureOfGaussians(gating=gating, components=comps)
+    out = dict(X=X, gating_kind=np.array(kind), K=np.array(K), D=np.array(D), seed2=np.array(seed + 1))
+    put(out, "prior", nw_params(model.components.prior))
+    put(out, "gprior", gating_params(model.gating.prior, kind))
+    put(out, "lik0", dict(mus=model.components.likelihood.mus, lmbdas=model.components.likelihood.lmbdas,
+                          probs=model.gating.likelihood.probs))
+    mA = copy.deepcopy(model)
+    # explicit loop (same body as gmm.py:220-223), recording every sweep
+    npr.seed(seed + 1)
+    labels = mA.gating.likelihood.rvs(len(X))                 # init_labels='prior' (gmm.py:213)
+    out["labels_init"] = labels
+    for s in range(sweeps):
+        mA.resample_components(X.copy(), labels)
+        mA.resample_gating(labels)
+        _, labels = mA.resample_labels(X.copy())
+        out[f"s{s}_labels"] = labels
+        out[f"s{s}_mus"] = mA.components.likelihood.mus
+        out[f"s{s}_lmbdas"] = mA.components.likelihood.lmbdas
+        out[f"s{s}_probs"] = np.array(mA.gating.likelihood.probs)
+        put(out, f"s{s}_post", nw_params(mA.components.posterior))
+    # the driver itself, same seed: final state must coincide with the explicit loop
+    mB = copy.deepcopy(model)
+    npr.seed(seed + 1)
+    mB.resample(X.copy(), init_labels='prior', maxiter=sweeps, progress_bar=False)
+    out["driver_mus"] = mB.components.likelihood.mus
+    out["driver_probs"] = np.array(mB.gating.likelihood.probs)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
+def ilr_case(name, N, dx, dy, K, kind, seed, vi_iters=20):
+    npr.seed(seed)
+    X = make_data(N, dx)
+    Atrue = npr.randn(4, dy, dx)
+    Y = np.einsum('ndl,nl->nd', Atrue[npr.randint(4, size=N)], X) + 0.3 * npr.randn(N, dy)
+    Y = np.ascontiguousarray(Y)
+    dc = dx + 1
+    gating = make_gating(K, kind)
+    bprior = StackedNormalWisharts(size=K, dim=dx, mus=np.zeros((K, dx)), kappas=1e-2 * np.ones((K,)),
+                                   psis=np.stack(K * [1e2 * np.eye(dx)]), nus=(dx + 1.) * np.ones((K,)) + 1e-16)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior)
+    mprior = StackedMatrixNormalWisharts(K, dc, dy, Ms=np.zeros((K, dy, dc)), Ks=np.stack(K * [1e-2 * np.eye(dc)]),
+                                         psis=np.stack(K * [np.eye(dy)]), nus=(dy + 1.) * np.ones((K,)) + 1e-16)
+    models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dc, dy, mprior, affine=True)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy,
+                                           gating=gating, basis=basis, models=models)
+    out = dict(X=X, Y=Y, gating_kind=np.array(kind), K=np.array(K))
+    put(out, "bprior", nw_params(ilr.basis.prior))
+    put(out, "mprior", mnw_params(ilr.models.prior))
+    put(out, "gprior", gating_params(ilr.gating.prior, kind))
+
+    resp0 = npr.rand(K, N)
+    resp0 /= np.sum(resp0, axis=0)
+    out["resp0"] = resp0
+    ms0 = ilr.models.likelihood.weighted_statistics(X.copy(), Y.copy(), resp0)      # A11
+    put(out, "mstats0", dict(yxTk=ms0[0], xxTk=ms0[1], yyTk=ms0[2], nk=ms0[3]))
+    ilr.meanfield_update_parameters(X.copy(), Y.copy(), resp0)
+    put(out, "bpost", nw_params(ilr.basis.posterior))
+    put(out, "mpost", mnw_params(ilr.models.posterior))
+    put(out, "gpost", gating_params(ilr.gating.posterior, kind))
+    put(out, "lik", dict(mus=ilr.basis.likelihood.mus, lmbdas=ilr.basis.likelihood.lmbdas,
+                         As=ilr.models.likelihood.As, lmbdas_y=ilr.models.likelihood.lmbdas,
+                         probs=ilr.gating.likelihood.probs))
+
+    out["A5_loglik"] = ilr.models.likelihood.log_likelihood(X.copy(), Y.copy())
+    out["A7_lcl"] = ilr.likelihood.log_complete_likelihood(X.copy(), Y.copy())
+    out["A7_resp"] = ilr.likelihood.responsibilities(X.copy(), Y.copy())
+    es = ilr.models.posterior.expected_statistics()
+    put(out, "mestats", dict(a=es[0], b=es[1], c=es[2], d=es[3]))
+    out["A6_eloglik"] = ilr.models.expected_log_likelihood(X.copy(), Y.copy())
+    out["A3_basis_eloglik"] = ilr.basis.expected_log_likelihood(X.copy())
+    out["A7_elcl"] = ilr.expected_log_complete_likelihood(X.copy(), Y.copy())
+    eresp = ilr.expected_responsibilities(X.copy(), Y.copy())
+    out["A7_eresp"] = eresp
+
+    bs = ilr.basis.likelihood.weighted_statistics(X.copy(), eresp)
+    put(out, "bstats", dict(xk=bs[0], nk=bs[1], xxTk=bs[2]))
+    ms = ilr.models.likelihood.weighted_statistics(X.copy(), Y.copy(), eresp)
+    put(out, "mstats", dict(yxTk=ms[0], xxTk=ms[1], yyTk=ms[2], nk=ms[3]))
+    out["counts"] = ilr.gating.likelihood.weighted_statistics(None, eresp)
+
+    out["vlb_data"] = ilr.variational_lowerbound_data(X.copy(), Y.copy(), eresp)
+    out["vlb_labels"] = ilr.variational_lowerbound_labels(eresp)
+    out["vlb_gating"] = ilr.gating.variational_lowerbound()
+    out["vlb_basis"] = ilr.basis.variational_lowerbound()
+    out["vlb_models"] = ilr.models.variational_lowerbound()
+    out["vlb_total"] = ilr.variational_lowerbound(X.copy(), Y.copy(), eresp)
+
+    u_mt = npr.random(size=(1, N))
+    with FixedUniforms(u_mt):
+        _, labels_mt = ilr.resample_labels(X.copy(), Y.copy())
+    u_ph = philox_uniforms(PHILOX_SEED, np.arange(N), PHILOX_SWEEP)
+    with FixedUniforms(u_ph):
+        _, labels_ph = ilr.resample_labels(X.copy(), Y.copy())
+    out["u_mt"], out["labels_mt"], out["labels_philox"] = u_mt.ravel(), labels_mt, labels_ph
+
+    m2 = copy.deepcopy(ilr)
+    m2.meanfield_update_parameters(X.copy(), Y.copy(), eresp)
+    put(out, "bpost2", nw_params(m2.basis.posterior))
+    put(out, "mpost2", mnw_params(m2.models.posterior))
+    put(out, "gpost2", gating_params(m2.gating.posterior, kind))
+
+    m3 = copy.deepcopy(ilr)
+    vlb = m3.meanfield_coordinate_descent(X.copy(), Y.copy(), randomize=False, maxiter=vi_iters, tol=0.,
+                                          progress_bar=False)
+    out["vi_vlb"] = np.array(vlb)
+    put(out, "vi_bpost", nw_params(m3.basis.posterior))
+    put(out, "vi_mpost", mnw_params(m3.models.posterior))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
+if __name__ == "__main__":
+    # fixture-size versions of BASELINE.json configs C1..C5 (true D; K capped for file size, one full-K case)
+    gmm_case("gmm_c1_d2_k4_dir", N=257, D=2, K=4, kind='dirichlet', seed=1337)
+    gmm_case("gmm_c2_d16_k16_dir", N=257, D=16, K=16, kind='dirichlet', seed=1338)
+    gmm_case("gmm_c2_d16_k64_dir", N=129, D=16, K=64, kind='dirichlet', seed=1339, vi_iters=5)
+    gmm_case("gmm_c3_d8_k32_stick", N=257, D=8, K=32, kind='stick', seed=1340)
+    gmm_case("gmm_c5_d32_k16_dir", N=129, D=32, K=16, kind='dirichlet', seed=1341, vi_iters=5)
+    gmm_case("gmm_tail_d5_k7_stick", N=1031, D=5, K=7, kind='stick', seed=1342, vi_iters=10)
+    ilr_case("ilr_c4_dx8_dy4_k16_stick", N=257, dx=8, dy=4, K=16, kind='stick', seed=1343)
+    ilr_case("ilr_dx1_dy1_k6_dir", N=300, dx=1, dy=1, K=6, kind='dirichlet', seed=1344)
+    gibbs_trace_case("gibbs_c1_trace", N=500, D=2, K=4, kind='dirichlet', seed=1345)
+    gibbs_trace_case("gibbs_stick_trace", N=400, D=3, K=6, kind='stick', seed=1346)

@@ -1,0 +1,173 @@
+"""Pins oracle/mimo_oracle.py (the CPU restatement) against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerance 1e-12 relative (same arithmetic, same order)."""
+import numpy as np
+import numpy.random as npr
+import pytest
+
+from conftest import (load_golden, rel_err, GMM_CASES, ILR_CASES, GIBBS_CASES, gating_of, nw_of, mnw_of)
+from oracle import mimo_oracle as O
+
+TOL = 1e-12
+
+
+@pytest.mark.parametrize("name", GMM_CASES)
+def test_gmm_tables_and_stats(name):
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    kind, gpost = gating_of(g, "gpost")
+    post = nw_of(g, "post")
+    # A10 / A12 / A13 from the random responsibilities
+    st0 = O.gauss_weighted_statistics(X, g["resp0"])
+    assert rel_err(st0[0], g["stats0_xk"]) < TOL and rel_err(st0[2], g["stats0_xxTk"]) < TOL
+    assert rel_err(st0[1], g["stats0_nk"]) < TOL
+    assert rel_err(O.categorical_weighted_statistics(g["resp0"]), g["counts0"]) < TOL
+    post_o = O.stacked_nw_update(nw_of(g, "prior"), st0)
+    for a, b in zip(post_o, post):
+        assert rel_err(a, b) < 1e-10
+    _, gprior = gating_of(g, "gprior")
+    gpost_o = O.gating_update(kind, gprior, g["counts0"])
+    for a, b in zip(np.atleast_2d(gpost_o), np.atleast_2d(gpost)):
+        assert rel_err(a, b) < TOL
+    # A1 / A2 (Gibbs / EM form)
+    mus, lmbdas, probs = g["lik_mus"], g["lik_lmbdas"], g["lik_probs"]
+    assert rel_err(O.gauss_log_likelihood(X, mus, lmbdas), g["A1_loglik"]) < TOL
+    lcl = O.gmm_log_complete_likelihood(X, mus, lmbdas, probs)
+    assert rel_err(lcl, g["A2_lcl"]) < TOL
+    assert rel_err(O.responsibilities(lcl), g["A2_resp"]) < 1e-11
+    # A3 / A4 (mean-field form)
+    es = [np.stack(v) for v in zip(*[O.nw_expected_statistics(*(p[k] for p in post)) for k in range(K)])]
+    for a, b in zip(es, (g["estats_a"], g["estats_b"], g["estats_c"], g["estats_d"])):
+        assert rel_err(a, b) < TOL
+    assert rel_err(O.gauss_nw_expected_log_likelihood(X, post, chunk=100), g["A3_eloglik"]) < TOL
+    elcl = O.gmm_expected_log_complete_likelihood(X, post, kind, gpost, chunk=64)
+    assert rel_err(elcl, g["A4_elcl"]) < TOL
+    eresp = O.responsibilities(elcl)
+    assert rel_err(eresp, g["A4_eresp"]) < 1e-11
+    # statistics of those responsibilities, ELBO pieces
+    st = O.gauss_weighted_statistics(X, g["A4_eresp"])
+    assert rel_err(st[0], g["stats_xk"]) < TOL and rel_err(st[2], g["stats_xxTk"]) < TOL
+    assert abs(np.sum(g["A4_eresp"] * g["A3_eloglik"]) - g["vlb_obs"]) < TOL * abs(g["vlb_obs"])
+    assert abs(O.vlb_labels(g["A4_eresp"], kind, gpost) - g["vlb_labels"]) < 1e-11 * abs(g["vlb_labels"])
+    assert abs(O.gating_vlb(kind, gpost, gprior) - g["vlb_gating"]) < 1e-10 * max(1, abs(g["vlb_gating"]))
+    prior = nw_of(g, "prior")
+    vc = np.array([O.nw_vlb(tuple(p[k] for p in post), tuple(p[k] for p in prior)) for k in range(K)])
+    assert rel_err(vc, g["vlb_comps"]) < 1e-10
+    # identity used by the fused kernel: obs + labels terms == sum_n logsumexp_k
+    from scipy.special import logsumexp
+    ident = np.sum(logsumexp(g["A4_elcl"], axis=0))
+    assert abs(ident - (g["vlb_obs"] + g["vlb_labels"])) < 1e-10 * abs(ident)
+
+
+@pytest.mark.parametrize("name", GMM_CASES)
+def test_gmm_labels_and_update(name):
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    kind, gpost = gating_of(g, "gpost")
+    lcl = O.gmm_log_complete_likelihood(X, g["lik_mus"], g["lik_lmbdas"], g["lik_probs"])
+    assert np.array_equal(O.sample_discrete_from_log(lcl, g["u_mt"]), g["labels_mt"])
+    u_ph = O.philox_uniforms(1337, np.arange(X.shape[0]), 3)
+    assert np.array_equal(O.sample_discrete_from_log(lcl, u_ph), g["labels_philox"])
+    oh = O.one_hot(g["labels_mt"], K)
+    stl = O.gauss_weighted_statistics(X, oh)
+    assert rel_err(stl[2], g["lstats_xxTk"]) < TOL and rel_err(stl[1], g["lstats_nk"]) < TOL
+    assert np.array_equal(O.categorical_statistics(g["labels_mt"], K), g["lcounts"])
+    post2 = O.stacked_nw_update(nw_of(g, "prior"), O.gauss_weighted_statistics(X, g["A4_eresp"]))
+    for a, b in zip(post2, nw_of(g, "post2")):
+        assert rel_err(a, b) < 1e-9
+
+
+@pytest.mark.parametrize("name", GMM_CASES)
+def test_gmm_vi_trace(name):
+    g = load_golden(name)
+    X = g["X"]
+    kind, gpost = gating_of(g, "gpost")
+    _, gprior = gating_of(g, "gprior")
+    prior = nw_of(g, "prior")
+    resp = g["A4_eresp"]
+    vlbs = []
+    for _ in range(len(g["vi_vlb"])):
+        post, gp, resp, v = O.gmm_vi_iteration(X, prior, gprior, kind, resp)
+        vlbs.append(v)
+    assert rel_err(np.array(vlbs), g["vi_vlb"]) < 1e-9
+    for a, b in zip(post, nw_of(g, "vi_post")):
+        assert rel_err(a, b) < 1e-7
+
+
+@pytest.mark.parametrize("name", ILR_CASES)
+def test_ilr_tables_stats_trace(name):
+    g = load_golden(name)
+    X, Y, K = g["X"], g["Y"], int(g["K"])
+    kind, gpost = gating_of(g, "gpost")
+    _, gprior = gating_of(g, "gprior")
+    bprior, mprior, bpost, mpost = nw_of(g, "bprior"), mnw_of(g, "mprior"), nw_of(g, "bpost"), mnw_of(g, "mpost")
+    ms0 = O.lingauss_weighted_statistics(X, Y, g["resp0"])
+    for a, b in zip(ms0, (g["mstats0_yxTk"], g["mstats0_xxTk"], g["mstats0_yyTk"], g["mstats0_nk"])):
+        assert rel_err(a, b) < TOL
+    for a, b in zip(O.stacked_mnw_update(mprior, ms0), mpost):
+        assert rel_err(a, b) < 1e-9
+    assert rel_err(O.lingauss_log_likelihood(X, Y, g["lik_As"], g["lik_lmbdas_y"]), g["A5_loglik"]) < TOL
+    lcl = O.ilr_log_complete_likelihood(X, Y, g["lik_mus"], g["lik_lmbdas"], g["lik_As"], g["lik_lmbdas_y"],
+                                        g["lik_probs"])
+    assert rel_err(lcl, g["A7_lcl"]) < TOL
+    es = [np.stack(v) for v in zip(*[O.mnw_expected_statistics(*(p[k] for p in mpost)) for k in range(K)])]
+    for a, b in zip(es, (g["mestats_a"], g["mestats_b"], g["mestats_c"], g["mestats_d"])):
+        assert rel_err(a, b) < 1e-11
+    assert rel_err(O.lingauss_mnw_expected_log_likelihood(X, Y, mpost, chunk=100), g["A6_eloglik"]) < 1e-11
+    elcl = O.ilr_expected_log_complete_likelihood(X, Y, bpost, mpost, kind, gpost)
+    assert rel_err(elcl, g["A7_elcl"]) < 1e-11
+    assert rel_err(O.responsibilities(elcl), g["A7_eresp"]) < 1e-10
+    ms = O.lingauss_weighted_statistics(X, Y, g["A7_eresp"])
+    for a, b in zip(ms, (g["mstats_yxTk"], g["mstats_xxTk"], g["mstats_yyTk"], g["mstats_nk"])):
+        assert rel_err(a, b) < TOL
+    vm = np.array([O.mnw_vlb(tuple(p[k] for p in mpost), tuple(p[k] for p in mprior)) for k in range(K)])
+    assert rel_err(vm, g["vlb_models"]) < 1e-9
+    assert np.array_equal(O.sample_discrete_from_log(lcl, g["u_mt"]), g["labels_mt"])
+    assert np.array_equal(O.sample_discrete_from_log(lcl, O.philox_uniforms(1337, np.arange(len(X)), 3)),
+                          g["labels_philox"])
+    resp, vlbs = g["A7_eresp"], []
+    for _ in range(len(g["vi_vlb"])):
+        bp, mp, gp, resp, v = O.ilr_vi_iteration(X, Y, bprior, mprior, gprior, kind, resp)
+        vlbs.append(v)
+    assert rel_err(np.array(vlbs), g["vi_vlb"]) < 1e-8
+    for a, b in zip(mp, mnw_of(g, "vi_mpost")):
+        assert rel_err(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("name", GIBBS_CASES)
+def test_gibbs_trace_rng_order(name):
+    """Seeded Gibbs trace: same host-RNG call order as gmm.py:207-225 => identical labels every sweep."""
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    kind, gprior = gating_of(g, "gprior")
+    prior = nw_of(g, "prior")
+    npr.seed(int(g["seed2"]))
+    labels = npr.choice(a=K, p=g["lik0_probs"], size=len(X))        # categorical.py:32
+    assert np.array_equal(labels, g["labels_init"])
+    s = 0
+    while f"s{s}_labels" in g:
+        post, gpost, mus, lmbdas, probs, labels = O.gmm_gibbs_sweep(X, prior, gprior, kind, labels, npr)
+        assert rel_err(mus, g[f"s{s}_mus"]) < 1e-9
+        assert rel_err(lmbdas, g[f"s{s}_lmbdas"]) < 1e-9
+        assert rel_err(probs, g[f"s{s}_probs"]) < 1e-12
+        assert np.array_equal(labels, g[f"s{s}_labels"])
+        s += 1
+    assert s == 5
+    assert rel_err(mus, g["driver_mus"]) < 1e-9
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors of Random123 (kat_vectors): counter/key all zero, all ones."""
+    def raw(c, k):
+        M = 0xFFFFFFFF
+        c = list(c); k = list(k)
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & M, (p0 >> 32) ^ c[3] ^ k[1], p0 & M]
+            k = [(k[0] + 0x9E3779B9) & M, (k[1] + 0xBB67AE85) & M]
+        return c
+    assert raw([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert raw([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    # the vectorised oracle agrees with the scalar rounds
+    c = raw([5, 0, 3, 0], [1337, 0])
+    u = ((c[0] >> 5) * 67108864.0 + (c[1] >> 6)) / 9007199254740992.0
+    assert O.philox_uniforms(1337, np.array([5]), 3)[0] == u
