@@ -128,6 +128,11 @@ int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, dou
  * last mimo_gibbs_labels left on the device. */
 int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, double* S);
 
+/* -sum_{k,n} t log t of a (K,N) table (entries <= 0 contribute 0, like nansum).
+ * Replaces: the entropy term of variational_lowerbound_labels for caller-supplied responsibilities
+ * (mimo/mixtures/gmm.py:353-355, ilr.py:310-312).  table == NULL uses the resident resp table. */
+int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int flags, double* out);
+
 /* ---- copy-outs of device-resident tables ----------------------------------------------- */
 int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
 int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);

@@ -444,6 +444,29 @@ int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, dou
   return run_fused(ctx, a, kSrcLabels, flags, S, nullptr);
 }
 
+int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int flags, double* out) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!out || count < 0) return fail(ctx, MIMO_E_INVALID, "mimo_table_entropy: bad arguments");
+  const double* src = table;
+  if (!table) {
+    if (!ctx->resp_valid) return fail(ctx, MIMO_E_STATE, "mimo_table_entropy: table is NULL and no resp table is resident");
+    src = ctx->resp;
+    count = (int64_t)ctx->resp_K * ctx->N;
+  } else if (!(flags & MIMO_F_DEVICE_IN)) {
+    if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, (size_t)(count > 0 ? count : 1)))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->win, table, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    src = ctx->win;
+  }
+  const int nblocks = 1024;
+  if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, (size_t)nblocks))) return rc;
+  if ((rc = ensure_dev(ctx, &ctx->reduced, &ctx->reduced_cap, 4))) return rc;
+  HIP_TRY(ctx, launch_table_entropy(src, count, ctx->partials, nblocks, ctx->reduced, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out, ctx->reduced, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIMO_OK;
+}
+
 static int copy_out(mimo_ctx* ctx, void* dst, const void* src, size_t bytes, bool valid, const char* what) {
   int rc = bind(ctx); if (rc) return rc;
   if (!dst) return fail(ctx, MIMO_E_INVALID, "%s: destination is NULL", what);

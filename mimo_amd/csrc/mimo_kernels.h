@@ -52,6 +52,9 @@ hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* 
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream);
 
+hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,
+                                double* out, hipStream_t stream);
+
 // host mirror of the in-kernel counter-based generator
 double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep);
 

@@ -380,6 +380,23 @@ __global__ void reduce_partials(const double* __restrict__ partials, int G, int6
   out[e] = (s0 + s1) + (s2 + s3);
 }
 
+// partial[b] = -sum t log t over this block's grid-stride share of a table; entries that are not
+// strictly positive contribute 0 (the reference uses nansum(resp * log(resp)), gmm.py:353-355).
+__global__ void table_entropy_partials(const double* __restrict__ t, int64_t count,
+                                       double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = t[i];
+    if (v > 0.0) s -= v * log(v);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // feature-space block [Kpad][F16] (+4 scalars) -> packed S[K][1 + D + D*D] and scalars[3]
 __global__ void unpack_stats(const double* __restrict__ red, const uint8_t* __restrict__ feat,
                              int K, int D, int F16, double* __restrict__ S,
@@ -487,6 +504,14 @@ hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* 
   hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((stride + bs - 1) / bs)), dim3(bs), 0, stream,
                      partials, G, stride, out);
   return hipGetLastError();
+}
+
+hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,
+                                double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(table_entropy_partials, dim3(nblocks), dim3(256), 0, stream, table, count, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_reduce(partials, nblocks, 1, out, stream);
 }
 
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,

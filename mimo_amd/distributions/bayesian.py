@@ -1,0 +1,221 @@
+"""Conjugate 'likelihood + prior + posterior' wrappers with the reference's method surface
+(mimo/distributions/bayesian.py:36-179, 182-323, 796-985):
+
+    resample / meanfield_update / meanfield_sgd / max_aposteriori / variational_lowerbound /
+    expected_log_likelihood, attributes .prior .posterior .likelihood
+
+Every update is  posterior.nat_param = prior.nat_param + stats  followed by a refresh of the
+point-estimate likelihood.  `stats` is either computed from (data, weights) through the HIP engine
+(reference-shaped calls) or handed over by the mixture drivers, which get the statistics of ALL
+blocks from one fused pass over the data.
+"""
+import copy
+
+import numpy as np
+
+from mimo_amd.utils.abstraction import Statistics as Stats
+from mimo_amd import engine as _engine
+from mimo_amd.distributions.gating import Categorical
+from mimo_amd.distributions.gaussian import StackedGaussiansWithPrecision
+from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision, joint_rows
+
+
+def stick_acc_counts(counts):
+    """counts of all later sticks, last entry 0 (bayesian.py:143,154; Blei & Jordan 2006)."""
+    return np.hstack((np.cumsum(counts[::-1])[-2::-1], 0))
+
+
+class _CategoricalWrapper:
+
+    def __init__(self, dim, prior, likelihood=None):
+        self.dim = dim
+        self.prior = prior
+        self.posterior = copy.deepcopy(prior)
+        if likelihood is not None:
+            self.likelihood = likelihood
+        else:
+            self.likelihood = Categorical(dim=self.dim, probs=self.prior.rvs())
+
+    def _counts(self, data, weights):
+        return self.likelihood.statistics(data) if weights is None\
+            else self.likelihood.weighted_statistics(data, weights)
+
+    def variational_lowerbound(self):
+        return self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
+
+    def expected_log_likelihood(self):
+        return self.posterior.expected_statistics()
+
+
+class CategoricalWithDirichlet(_CategoricalWrapper):
+    """reference: bayesian.py:36-99"""
+
+    def max_aposteriori(self, data, weights=None):
+        self.posterior.nat_param = self.prior.nat_param + self._counts(data, weights)
+        self.likelihood.params = self.posterior.mode()
+
+    def resample(self, data, counts=None):
+        counts = self.likelihood.statistics(data) if counts is None else counts
+        self.posterior.nat_param = self.prior.nat_param + counts
+        self.likelihood.params = np.clip(self.posterior.rvs(), np.spacing(1.), np.inf)
+
+    def meanfield_update(self, data, weights=None, sample=True):
+        self.posterior.nat_param = self.prior.nat_param + self._counts(data, weights)
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_sgd(self, data, weights, scale, step_size, sample=True):
+        stats = self._counts(data, weights)
+        self.posterior.nat_param = (1. - step_size) * self.posterior.nat_param\
+            + step_size * (self.prior.nat_param + 1. / scale * stats)
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def expected_log_gating(self):
+        """E[log pi_k] per component (gmm.py:248-249)."""
+        return self.posterior.expected_statistics()
+
+
+class CategoricalWithStickBreaking(_CategoricalWrapper):
+    """reference: bayesian.py:102-179"""
+
+    def _set(self, counts):
+        self.posterior.gammas = self.prior.gammas + counts
+        self.posterior.deltas = self.prior.deltas + stick_acc_counts(counts)
+
+    def max_aposteriori(self, data, weights=None):
+        self._set(self._counts(data, weights))
+        self.likelihood.params = self.posterior.mode()
+
+    def resample(self, data, counts=None):
+        self._set(self.likelihood.statistics(data) if counts is None else counts)
+        self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_update(self, data, weights=None, sample=True):
+        self._set(self._counts(data, weights))
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_sgd(self, data, weights, scale, step_size, sample=True):
+        counts = self._counts(data, weights)
+        acc = stick_acc_counts(counts)
+        self.posterior.gammas = (1. - step_size) * self.posterior.gammas\
+            + step_size * (self.prior.gammas + 1. / scale * counts)
+        self.posterior.deltas = (1. - step_size) * self.posterior.deltas\
+            + step_size * (self.prior.deltas + 1. / scale * acc)
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def expected_log_gating(self):
+        """E_log_stick_k + sum_{j<k} E_log_rest_j (gmm.py:250-252)."""
+        log_stick, log_rest = self.posterior.expected_statistics()
+        return log_stick + np.hstack((0, np.cumsum(log_rest)[:-1]))
+
+
+class _ConjugateBlock:
+    """Shared update logic: stats -> posterior natural parameters -> refreshed likelihood."""
+
+    def _apply(self, stats):
+        self.posterior.nat_param = self.prior.nat_param + stats
+
+    def _apply_sgd(self, stats, scale, step_size):
+        self.posterior.nat_param = (1. - step_size) * self.posterior.nat_param\
+            + step_size * (self.prior.nat_param + 1. / scale * stats)
+
+    def variational_lowerbound(self):
+        return self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
+
+    def log_marginal_likelihood(self):
+        return self.posterior.log_partition() - self.prior.log_partition()
+
+
+class StackedGaussiansWithNormalWisharts(_ConjugateBlock):
+    """reference: bayesian.py:182-265 + 268-323 (stacked)."""
+
+    def __init__(self, size, dim, prior, likelihood=None, engine=None):
+        self.size = size
+        self.dim = dim
+        self.prior = prior
+        self.posterior = copy.deepcopy(prior)
+        if likelihood is None:
+            mus, lmbdas = prior.rvs()
+            likelihood = StackedGaussiansWithPrecision(size=size, dim=dim, mus=mus, lmbdas=lmbdas, engine=engine)
+        self.likelihood = likelihood
+
+    def _stats(self, data, weights):
+        return self.likelihood.statistics(data) if weights is None\
+            else self.likelihood.weighted_statistics(data, weights)
+
+    def max_aposteriori(self, data, weights=None, stats=None):
+        self._apply(stats if stats is not None else self._stats(data, weights))
+        self.likelihood.params = self.posterior.mode()
+
+    def resample(self, data, labels=None, stats=None):
+        self._apply(stats if stats is not None else self._stats(data, labels))
+        self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_update(self, data, weights=None, stats=None, sample=True):
+        """bayesian.py:225-230.  `sample=False` skips the (numerically irrelevant for VI) refresh
+        likelihood.params = posterior.rvs() and with it the K Wishart draws it costs per iteration."""
+        self._apply(stats if stats is not None else self._stats(data, weights))
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_sgd(self, data, weights, scale, step_size, stats=None, sample=True):
+        self._apply_sgd(stats if stats is not None else self._stats(data, weights), scale, step_size)
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def canonical_expected(self):
+        return self.posterior.canonical_expected()
+
+    def expected_log_likelihood(self, x):
+        """(K, N) table <E_q[eta_k], t(x_n)> (bayesian.py:287-301), on the engine."""
+        eng = self.likelihood._bind(x)
+        eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+
+class StackedLinearGaussiansWithMatrixNormalWisharts(_ConjugateBlock):
+    """reference: bayesian.py:796-912 + 915-985 (stacked)."""
+
+    def __init__(self, size, column_dim, row_dim, prior, likelihood=None, affine=True, engine=None):
+        self.size = size
+        self.prior = prior
+        self.posterior = copy.deepcopy(prior)
+        if likelihood is None:
+            As, lmbdas = prior.rvs()
+            likelihood = StackedLinearGaussiansWithPrecision(size, column_dim, row_dim, As=As, lmbdas=lmbdas,
+                                                             affine=affine, engine=engine)
+        self.likelihood = likelihood
+
+    def _stats(self, x, y, weights):
+        return self.likelihood.statistics(x, y) if weights is None\
+            else self.likelihood.weighted_statistics(x, y, weights)
+
+    def max_aposteriori(self, x, y, weights=None, stats=None):
+        self._apply(stats if stats is not None else self._stats(x, y, weights))
+        self.likelihood.params = self.posterior.mode()
+
+    def resample(self, x, y, z=None, stats=None):
+        self._apply(stats if stats is not None else self._stats(x, y, z))
+        self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_update(self, x, y, weights=None, stats=None, sample=True):
+        self._apply(stats if stats is not None else self._stats(x, y, weights))
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def meanfield_sgd(self, x, y, weights, scale, step_size, stats=None, sample=True):
+        self._apply_sgd(stats if stats is not None else self._stats(x, y, weights), scale, step_size)
+        if sample:
+            self.likelihood.params = self.posterior.rvs()
+
+    def canonical_expected(self):
+        return self.posterior.canonical_expected(affine=self.likelihood.affine)
+
+    def expected_log_likelihood(self, x, y):
+        """(K, N) table of the expected log-density of y | x (bayesian.py:933-947), on the engine."""
+        eng = self.likelihood._bind(x, y)
+        eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)

@@ -1,0 +1,241 @@
+"""Conjugate priors / posteriors of the component blocks, batched over K (float64, host).
+
+StackedNormalWisharts        <-> mimo/distributions/composite.py:19-256
+StackedMatrixNormalWisharts  <-> mimo/distributions/composite.py:550-783 (+ matrix.py:10-175)
+
+These classes produce the per-component parameter block the kernels consume (expected statistics
+-> canonical (c, b, W)) and consume the sufficient-statistic block the kernels produce
+(nat_param = prior.nat_param + stats).  K small D x D problems per sweep: they stay on the host.
+"""
+import numpy as np
+import numpy.random as npr
+import scipy.linalg as sla
+
+from mimo_amd.utils.abstraction import Statistics as Stats
+from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs)
+
+
+def _outer(a, b):
+    return np.einsum('kd,kl->kdl', a, b)
+
+
+class StackedNormalWisharts:
+    """K independent Normal-Wishart distributions over (mu_k, Lambda_k):
+    Lambda ~ W(psi, nu), mu | Lambda ~ N(m, (kappa Lambda)^-1)."""
+
+    def __init__(self, size, dim, mus=None, kappas=None, psis=None, nus=None):
+        self.size = size
+        self.dim = dim
+        self.mus = None if mus is None else np.array(mus, dtype=float)
+        self.kappas = None if kappas is None else np.array(kappas, dtype=float)
+        self.psis = None if psis is None else np.array(psis, dtype=float)
+        self.nus = None if nus is None else np.array(nus, dtype=float)
+
+    @property
+    def params(self):
+        return self.mus, self.kappas, self.psis, self.nus
+
+    @params.setter
+    def params(self, values):
+        self.mus, self.kappas, self.psis, self.nus = (np.asarray(v, dtype=float) for v in values)
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    def std_to_nat(self, params):
+        """eta = [kappa m, kappa, psi^-1 + kappa m m', nu - D]  (composite.py:50-65)."""
+        mus, kappas, psis, nus = params
+        return Stats([kappas[:, None] * mus, kappas,
+                      np.linalg.inv(psis) + kappas[:, None, None] * _outer(mus, mus),
+                      nus - self.dim])
+
+    def nat_to_std(self, natparam):
+        """composite.py:67-72."""
+        a, b, c, d = natparam
+        mus = a / b[:, None]
+        psis = np.linalg.inv(c - b[:, None, None] * _outer(mus, mus))
+        return mus, b, psis, d + self.dim
+
+    def mean(self):
+        return self.mus, self.nus[:, None, None] * self.psis
+
+    def mode(self):
+        """composite.py:77-80: Lambda = (nu - D) psi."""
+        return self.mus, (self.nus - self.dim)[:, None, None] * self.psis
+
+    def rvs(self):
+        """Per component, in the reference's RNG order (composite.py:82-86, wishart.py:72-92,
+        gaussian.py:311-313): Wishart draw, then mu = m + normal(D) . chol_upper(kappa Lambda)^-T."""
+        mus, lmbdas = [], []
+        for k in range(self.size):
+            lmbda = wishart_rvs(self.psis[k], self.nus[k])
+            chol_inv = sla.inv(sla.cholesky(self.kappas[k] * lmbda, lower=False))
+            mus.append(self.mus[k] + npr.normal(size=self.dim).dot(chol_inv.T))
+            lmbdas.append(lmbda)
+        return np.stack(mus, axis=0), np.stack(lmbdas, axis=0)
+
+    @property
+    def base(self):
+        return np.power(2. * np.pi, - self.dim / 2.) * np.ones(self.size)
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        """composite.py:95-98."""
+        return - 0.5 * self.dim * np.log(self.kappas) + wishart_log_partition(self.psis, self.nus)
+
+    def expected_statistics(self):
+        """E[Lambda mu], E[-1/2 mu'Lambda mu], E[-1/2 Lambda], E[1/2 logdet Lambda] (composite.py:106-118)."""
+        nupsi = self.nus[:, None, None] * self.psis
+        E_lmbda_mu = np.einsum('kdl,kl->kd', nupsi, self.mus)
+        E_muT_lmbda_mu = - 0.5 * (self.dim / self.kappas + np.einsum('kd,kd->k', self.mus, E_lmbda_mu))
+        return E_lmbda_mu, E_muT_lmbda_mu, - 0.5 * nupsi, 0.5 * wishart_expected_logdet(self.psis, self.nus)
+
+    def canonical_expected(self):
+        """(c, b, W) of <E_q[eta_k], t(x)> + log_base  (bayesian.py:287-301): the VI E-step form."""
+        E1, E2, E3, E4 = self.expected_statistics()
+        return self.log_base() + E2 + E4, E1, - 2. * E3
+
+    @staticmethod
+    def _inner(nat, stats):
+        return (np.einsum('kd,kd->k', nat[0], stats[0]) + nat[1] * stats[1]
+                + np.einsum('kdl,kdl->k', nat[2], stats[2]) + nat[3] * stats[3])
+
+    def entropy(self):
+        return self.log_partition() - self.log_base() - self._inner(self.nat_param, self.expected_statistics())
+
+    def cross_entropy(self, other):
+        return other.log_partition() - other.log_base() - self._inner(other.nat_param, self.expected_statistics())
+
+    def log_likelihood(self, x):
+        """sum_k log NW(mu_k, Lambda_k) (composite.py:100-104, 244-246); x = (mus, lmbdas)."""
+        mus, lmbdas = x
+        D = self.dim
+        diff = mus - self.mus
+        kl = self.kappas[:, None, None] * lmbdas
+        gauss = - 0.5 * np.einsum('kd,kdl,kl->k', diff, kl, diff) + 0.5 * np.linalg.slogdet(kl)[1]\
+            - 0.5 * D * np.log(2. * np.pi)
+        wish = 0.5 * (self.nus - D - 1) * np.linalg.slogdet(lmbdas)[1]\
+            - 0.5 * np.trace(np.linalg.solve(self.psis, lmbdas), axis1=1, axis2=2)\
+            - wishart_log_partition(self.psis, self.nus)
+        return np.sum(gauss + wish)
+
+
+class StackedMatrixNormalWisharts:
+    """K independent Matrix-Normal-Wishart distributions over (A_k, Lambda_k):
+    Lambda ~ W(psi, nu), vec(A) | Lambda ~ N(vec(M), (K (x) Lambda)^-1)."""
+
+    def __init__(self, size, column_dim, row_dim, Ms=None, Ks=None, psis=None, nus=None):
+        self.size = size
+        self.column_dim = column_dim
+        self.row_dim = row_dim
+        self.Ms = None if Ms is None else np.array(Ms, dtype=float)
+        self.Ks = None if Ks is None else np.array(Ks, dtype=float)
+        self.psis = None if psis is None else np.array(psis, dtype=float)
+        self.nus = None if nus is None else np.array(nus, dtype=float)
+
+    @property
+    def params(self):
+        return self.Ms, self.Ks, self.psis, self.nus
+
+    @params.setter
+    def params(self, values):
+        self.Ms, self.Ks, self.psis, self.nus = (np.asarray(v, dtype=float) for v in values)
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    def std_to_nat(self, params):
+        """eta = [M K, K, psi^-1 + M K M', nu - d - 1 + l]  (composite.py:577-592)."""
+        Ms, Ks, psis, nus = params
+        MK = Ms @ Ks
+        return Stats([MK, Ks, np.linalg.inv(psis) + MK @ np.swapaxes(Ms, 1, 2),
+                      nus - self.row_dim - 1. + self.column_dim])
+
+    def nat_to_std(self, natparam):
+        """composite.py:594-599."""
+        a, b, c, d = natparam
+        Ms = a @ np.linalg.inv(b)
+        psis = np.linalg.inv(c - Ms @ b @ np.swapaxes(Ms, 1, 2))
+        return Ms, b, psis, d + self.row_dim + 1. - self.column_dim
+
+    def mean(self):
+        return self.Ms, self.nus[:, None, None] * self.psis
+
+    def mode(self):
+        return self.Ms, (self.nus - self.row_dim)[:, None, None] * self.psis
+
+    def rvs(self):
+        """Reference RNG order (composite.py:607-611, matrix.py:122-125): Wishart draw, then
+        vec_F(A) = vec_F(M) + normal(d l) . chol_upper(kron(K, Lambda))^-T."""
+        As, lmbdas = [], []
+        dy, dx = self.row_dim, self.column_dim
+        for k in range(self.size):
+            lmbda = wishart_rvs(self.psis[k], self.nus[k])
+            chol_inv = sla.inv(sla.cholesky(np.kron(self.Ks[k], lmbda), lower=False))
+            aux = npr.normal(size=dy * dx).dot(chol_inv.T)
+            As.append(self.Ms[k] + np.reshape(aux, (dy, dx), order='F'))
+            lmbdas.append(lmbda)
+        return np.stack(As, axis=0), np.stack(lmbdas, axis=0)
+
+    @property
+    def base(self):
+        return np.power(2. * np.pi, - self.row_dim * self.column_dim / 2.) * np.ones(self.size)
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        """composite.py:622-625."""
+        return - 0.5 * self.row_dim * np.linalg.slogdet(self.Ks)[1] + wishart_log_partition(self.psis, self.nus)
+
+    def expected_statistics(self):
+        """E[Lambda A], E[-1/2 A'Lambda A], E[-1/2 Lambda], E[1/2 logdet Lambda] (composite.py:635-647)."""
+        nupsi = self.nus[:, None, None] * self.psis
+        E_Lmbda_A = nupsi @ self.Ms
+        E_AT_Lmbda_A = - 0.5 * (self.row_dim * np.linalg.inv(self.Ks) + np.swapaxes(self.Ms, 1, 2) @ E_Lmbda_A)
+        return E_Lmbda_A, E_AT_Lmbda_A, - 0.5 * nupsi, 0.5 * wishart_expected_logdet(self.psis, self.nus)
+
+    def canonical_expected(self, affine=True):
+        """(c, b, W) over z = [x, y] of the expected log-density of y | x (bayesian.py:933-947):
+        <E[Lambda A], y x~'> + <E[-1/2 A'Lambda A], x~ x~'> + <E[-1/2 Lambda], y y'> + E[1/2 logdet] + log_base
+        with x~ = [x, 1] when affine."""
+        E1, E2, E3, E4 = self.expected_statistics()
+        dy, dc = self.row_dim, self.column_dim
+        dx = dc - 1 if affine else dc
+        Kc = self.size
+        W = np.zeros((Kc, dx + dy, dx + dy))
+        b = np.zeros((Kc, dx + dy))
+        c = np.power(2. * np.pi, - dy / 2.) * np.ones(Kc)
+        c = np.log(c) + E4
+        W[:, :dx, :dx] = - 2. * E2[:, :dx, :dx]
+        W[:, dx:, dx:] = - 2. * E3
+        W[:, dx:, :dx] = - E1[:, :, :dx]            # the cross term <E1, y x'> = -1/2 z'Wz with
+        W[:, :dx, dx:] = - np.swapaxes(E1[:, :, :dx], 1, 2)   # W_yx = -E1_x (and its transpose)
+        if affine:
+            b[:, :dx] = 2. * E2[:, :dx, dx]         # x~ x~' off-diagonal (x, 1) appears twice
+            b[:, dx:] = E1[:, :, dx]
+            c = c + E2[:, dx, dx]
+        return c, b, W
+
+    @staticmethod
+    def _inner(nat, stats):
+        return (np.einsum('kdl,kdl->k', nat[0], stats[0]) + np.einsum('kdl,kdl->k', nat[1], stats[1])
+                + np.einsum('kdl,kdl->k', nat[2], stats[2]) + nat[3] * stats[3])
+
+    def entropy(self):
+        return self.log_partition() - self.log_base() - self._inner(self.nat_param, self.expected_statistics())
+
+    def cross_entropy(self, other):
+        return other.log_partition() - other.log_base() - self._inner(other.nat_param, self.expected_statistics())

@@ -1,0 +1,217 @@
+"""Gating distributions: Categorical likelihood, Dirichlet and truncated stick-breaking priors.
+
+Same class / method names and semantics as the reference's mimo/distributions/categorical.py and
+mimo/distributions/dirichlet.py; everything here is O(K) host math (float64 NumPy / SciPy).  The
+only O(N) quantity the gating needs — the per-component counts sum_n r_kn / bincount(labels) — is
+one column of the sufficient-statistic block the HIP engine returns.
+"""
+import warnings
+
+import numpy as np
+import numpy.random as npr
+from scipy.special import digamma, gammaln, betaln
+
+
+class Categorical:
+    """reference: mimo/distributions/categorical.py:5-68"""
+
+    def __init__(self, dim, probs=None):
+        self.dim = dim
+        self.probs = probs
+        if probs is None:
+            self.probs = 1. / self.dim * np.ones((self.dim,))
+
+    @property
+    def params(self):
+        return self.probs
+
+    @params.setter
+    def params(self, values):
+        self.probs = values
+
+    @property
+    def nb_params(self):
+        return len(self.probs) - 1
+
+    def mode(self):
+        return np.argmax(self.probs)
+
+    def rvs(self, size=1):
+        return npr.choice(a=self.dim, p=self.probs, size=size)          # categorical.py:32
+
+    def statistics(self, data):
+        """categorical.py:35-39 (counts of integer labels)."""
+        if isinstance(data, np.ndarray):
+            return np.bincount(data, minlength=self.dim)
+        return sum(list(map(self.statistics, data)))
+
+    def weighted_statistics(self, data, weights):
+        """categorical.py:41-46 — sum_n r_kn.  `weights` may already be the (K,) count vector the
+        engine produced (the drivers' path); a (K,N) table is reduced as in the reference."""
+        if isinstance(weights, np.ndarray):
+            if weights.ndim == 1:
+                return weights
+            return np.sum(np.atleast_2d(weights), axis=1)
+        data = data if data else [None] * len(weights)
+        return sum(list(map(self.weighted_statistics, data, weights)))
+
+    def log_likelihood(self, x):
+        """categorical.py:51-59"""
+        log_lik = np.zeros_like(x, dtype=np.double)
+        err = np.seterr(invalid='ignore', divide='ignore')
+        bads = np.isnan(x)
+        log_lik[~bads] = np.log(self.probs)[list(x[~bads])]
+        np.seterr(**err)
+        return log_lik
+
+    def max_likelihood(self, data, weights=None):
+        counts = self.statistics(data) if weights is None else self.weighted_statistics(data, weights)
+        self.probs = counts / counts.sum()
+
+
+class Dirichlet:
+    """reference: mimo/distributions/dirichlet.py:8-97"""
+
+    def __init__(self, dim=None, alphas=None):
+        self.dim = dim
+        self.alphas = alphas
+
+    @property
+    def params(self):
+        return self.alphas
+
+    @params.setter
+    def params(self, values):
+        self.alphas = values
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    @staticmethod
+    def std_to_nat(params):
+        return params - 1.
+
+    @staticmethod
+    def nat_to_std(natparam):
+        return natparam + 1.
+
+    def mean(self):
+        return self.alphas / np.sum(self.alphas)
+
+    def mode(self):
+        assert np.all(self.alphas > 1.), "Make sure alphas > 1."
+        return (self.alphas - 1.) / (np.sum(self.alphas) - self.dim)
+
+    def rvs(self, size=1):
+        return npr.dirichlet(self.alphas)
+
+    @property
+    def base(self):
+        return 1.
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        return np.sum(gammaln(self.alphas)) - gammaln(np.sum(self.alphas))
+
+    def log_likelihood(self, x):
+        return - self.log_partition() + self.log_base() + np.sum((self.alphas - 1.) * np.log(x))
+
+    def expected_statistics(self):
+        return digamma(self.alphas) - digamma(np.sum(self.alphas))
+
+    def entropy(self):
+        return self.log_partition() - self.log_base() - self.nat_param.dot(self.expected_statistics())
+
+    def cross_entropy(self, dist):
+        return dist.log_partition() - dist.log_base() - dist.nat_param.dot(self.expected_statistics())
+
+
+class TruncatedStickBreaking:
+    """reference: mimo/distributions/dirichlet.py:100-214 (Ishwaran & James 2001; Blei & Jordan 2006)"""
+
+    def __init__(self, dim=None, gammas=None, deltas=None):
+        self.dim = dim
+        self.gammas = gammas
+        self.deltas = deltas
+
+    @property
+    def params(self):
+        return self.gammas, self.deltas
+
+    @params.setter
+    def params(self, values):
+        self.gammas, self.deltas = values
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    @staticmethod
+    def std_to_nat(params):
+        return params[0] - 1., params[1] - 1.
+
+    @staticmethod
+    def nat_to_std(natparam):
+        return natparam[0] + 1., natparam[1] + 1.
+
+    @staticmethod
+    def _probs(betas_head):
+        betas = np.hstack((betas_head, 1.))
+        probs = np.zeros((betas.shape[0],))
+        probs[0] = betas[0]
+        probs[1:] = betas[1:] * np.cumprod(1.0 - betas[:-1])
+        return probs
+
+    def mean(self):
+        return self._probs(self.gammas[:-1] / (self.gammas[:-1] + self.deltas[:-1]))
+
+    def mode(self):
+        g, d = self.gammas[:-1], self.deltas[:-1]
+        betas = np.full(g.shape, np.nan)
+        both = (g > 1.) & (d > 1.)
+        betas[both] = (g[both] - 1.) / (g[both] + d[both] - 2.)
+        betas[(g == 1.) & (d == 1.)] = 1.
+        betas[(g < 1.) & (d < 1.)] = 1.
+        betas[(g <= 1.) & (d > 1.)] = 0.
+        betas[(g > 1.) & (d <= 1.)] = 1.
+        if np.isnan(betas).any():
+            warnings.warn("Mode of Dirichlet process not defined")
+            raise ValueError
+        return self._probs(betas)
+
+    def rvs(self, size=1, truncate=True):
+        return self._probs(npr.beta(self.gammas[:-1], self.deltas[:-1]))      # dirichlet.py:177-186
+
+    @property
+    def base(self):
+        return 1.
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        return np.sum(betaln(self.gammas, self.deltas))
+
+    def expected_statistics(self):
+        E_log_stick = digamma(self.gammas) - digamma(self.gammas + self.deltas)
+        E_log_rest = digamma(self.deltas) - digamma(self.gammas + self.deltas)
+        return E_log_stick, E_log_rest
+
+    def entropy(self):
+        nat, stats = self.nat_param, self.expected_statistics()
+        return self.log_partition() - self.log_base() - (nat[0].dot(stats[0]) + nat[1].dot(stats[1]))
+
+    def cross_entropy(self, dist):
+        nat, stats = dist.nat_param, self.expected_statistics()
+        return dist.log_partition() - dist.log_base() - (nat[0].dot(stats[0]) + nat[1].dot(stats[1]))

@@ -1,0 +1,193 @@
+"""Stacked linear-Gaussian experts  y | x ~ N(A_k [x,1], Lambda_k^-1).
+
+API mirror of StackedLinearGaussiansWithPrecision (mimo/distributions/lingauss.py:187-367).  On the
+engine the joint row z = [x, y] is the datum, so both the log-density and every block of the
+sufficient statistics (y x~', x~ x~', y y', n with x~ = [x, 1]; lingauss.py:306-322) come out of
+the same quadratic-form kernel: with G = [-A_x, I] (so y - A_x x = G z) and offset a0,
+
+    l = -1/2 (G z - a0)' Lambda (G z - a0) + sum log diag chol Lambda - d_y/2 log 2pi
+      = c + b.z - 1/2 z' W z ,   W = G' Lambda G,  b = G' Lambda a0,  c = -1/2 a0' Lambda a0 + ...
+"""
+import numpy as np
+import numpy.random as npr
+import scipy.linalg as sla
+
+from mimo_amd.utils.abstraction import Statistics as Stats
+from mimo_amd import engine as _engine
+from mimo_amd.distributions.gaussian import symmetrize, upper_chol
+
+
+def residual_quadratic(As, lmbdas, affine, input_dim):
+    """(c0, b, W) over z = [x, y] of  -1/2 (y - A x~)' Lambda (y - A x~)  for stacks As (K,dy,dc),
+    lmbdas (K,dy,dy): c0 = -1/2 a0'Lambda a0, b = G'Lambda a0, W = G'Lambda G."""
+    K, dy = lmbdas.shape[0], lmbdas.shape[1]
+    dx = input_dim
+    Ax = As[:, :, :dx]
+    a0 = As[:, :, -1] if affine else np.zeros((K, dy))
+    G = np.concatenate([-Ax, np.broadcast_to(np.eye(dy), (K, dy, dy))], axis=2)      # (K, dy, dx+dy)
+    LG = lmbdas @ G
+    W = np.swapaxes(G, 1, 2) @ LG
+    b = np.einsum('kdz,kd->kz', LG, a0)
+    c0 = - 0.5 * np.einsum('kd,kdl,kl->k', a0, lmbdas, a0)
+    return c0, b, W
+
+
+def split_joint_stats(S, dx, affine):
+    """Blocks of the engine's packed statistics over z = [x, y]:
+    returns (xk, xxTk) for the input density and (yxTk, x~x~Tk, yyTk) for the experts."""
+    sx_x, sx_y = S.sx[:, :dx], S.sx[:, dx:]
+    sxx_xx, sxx_yx, sxx_yy = S.sxx[:, :dx, :dx], S.sxx[:, dx:, :dx], S.sxx[:, dx:, dx:]
+    if affine:
+        yxT = np.concatenate([sxx_yx, sx_y[:, :, None]], axis=2)
+        top = np.concatenate([sxx_xx, sx_x[:, :, None]], axis=2)
+        bot = np.concatenate([sx_x[:, None, :], S.n[:, None, None]], axis=2)
+        xxT = np.concatenate([top, bot], axis=1)
+    else:
+        yxT, xxT = sxx_yx, sxx_xx
+    return (sx_x, sxx_xx), (yxT, xxT, sxx_yy)
+
+
+class StackedLinearGaussiansWithPrecision:
+
+    def __init__(self, size, column_dim, row_dim, As=None, lmbdas=None, affine=True, engine=None):
+        self.size = size
+        self.column_dim = column_dim
+        self.row_dim = row_dim
+        self.affine = affine
+        self.As = None if As is None else np.array(As, dtype=float)
+        self.lmbdas = None if lmbdas is None else np.array(lmbdas, dtype=float)
+        self._engine = engine
+
+    @property
+    def engine(self):
+        return self._engine if self._engine is not None else _engine.default_engine()
+
+    @engine.setter
+    def engine(self, value):
+        self._engine = value
+
+    @property
+    def params(self):
+        return self.As, self.lmbdas
+
+    @params.setter
+    def params(self, values):
+        self.As, self.lmbdas = (np.asarray(v, dtype=float) for v in values)
+
+    @property
+    def input_dim(self):
+        return self.column_dim - 1 if self.affine else self.column_dim
+
+    @property
+    def output_dim(self):
+        return self.row_dim
+
+    @property
+    def lmbdas_chol(self):
+        return upper_chol(self.lmbdas)
+
+    @property
+    def lmbdas_chol_inv(self):
+        return np.stack([sla.inv(c) for c in self.lmbdas_chol])
+
+    @property
+    def sigmas(self):
+        ci = self.lmbdas_chol_inv
+        return ci @ np.swapaxes(ci, -1, -2)
+
+    def predict(self, x):
+        """lingauss.py:251-257 — (K, ..., d_y) means; host einsum, prediction-time helper."""
+        if self.affine:
+            A, b = self.As[:, :, :-1], self.As[:, :, -1]
+            return np.einsum('kdl,...l->k...d', A, x, optimize=True) + b[:, None, :]
+        return np.einsum('kdl,...l->k...d', self.As, x, optimize=True)
+
+    def mean(self, x):
+        return self.predict(x)
+
+    def mode(self, x):
+        return self.predict(x)
+
+    def rvs(self, x):
+        ci = self.lmbdas_chol_inv
+        mu = self.predict(x)
+        out = []
+        for k in range(self.size):
+            size = self.output_dim if x.ndim == 1 else (x.shape[0], self.output_dim)
+            out.append(mu[k] + npr.normal(size=size).dot(ci[k].T))
+        return np.array(out)
+
+    @property
+    def base(self):
+        return np.power(2. * np.pi, - self.output_dim / 2.) * np.ones(self.size)
+
+    def log_base(self):
+        return np.log(self.base)
+
+    # ---- canonical form over z = [x, y] -------------------------------------------------------
+    def canonical(self):
+        """Point-estimate form (lingauss.py:330-345 with log_partition(x) :166-169 folded in)."""
+        c0, b, W = residual_quadratic(self.As, self.lmbdas, self.affine, self.input_dim)
+        logdet_half = np.sum(np.log(np.diagonal(self.lmbdas_chol, axis1=1, axis2=2)), axis=1)
+        return c0 + logdet_half + self.log_base(), b, W
+
+    def _bind(self, x, y):
+        x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
+        y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
+        if np.isnan(x).any() or np.isnan(y).any():
+            raise ValueError("NaN rows are not supported by the HIP engine")
+        return _engine.bind(self.engine, joint_rows(x, y))
+
+    def log_likelihood(self, x, y):
+        if not (isinstance(x, np.ndarray) and isinstance(y, np.ndarray)):
+            return list(map(self.log_likelihood, x, y))
+        eng = self._bind(x, y)
+        eng.estep(*self.canonical(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def weighted_statistics(self, x, y, weights):
+        """Stats([sum r y x~', sum r x~ x~', sum r y y', n]) (lingauss.py:306-322)."""
+        if not (isinstance(x, np.ndarray) and isinstance(y, np.ndarray)):
+            stats = list(map(self.weighted_statistics, x, y, weights))
+            out = stats[0]
+            for s in stats[1:]:
+                out = out + s
+            return out
+        eng = self._bind(x, y)
+        S = eng.weighted_stats(np.asarray(weights, dtype=float))
+        _, (yxT, xxT, yyT) = split_joint_stats(S, self.input_dim, self.affine)
+        return Stats([yxT, xxT, yyT, S.n])
+
+    def statistics(self, x, y, fold=True):
+        if not fold:
+            raise NotImplementedError("statistics(fold=False) materialises (K,N,.,.) tables; use "
+                                      "expected_log_likelihood / the fused E-step instead")
+        eng = self._bind(x, y)
+        S = eng.weighted_stats(np.ones((1, eng.N)))
+        _, (yxT, xxT, yyT) = split_joint_stats(S, self.input_dim, self.affine)
+        rep = lambda a: np.repeat(a, self.size, axis=0)
+        return Stats([rep(yxT), rep(xxT), rep(yyT), rep(S.n)])
+
+    def max_likelihood(self, x, y, weights=None, stats=None):
+        """lingauss.py:350-367."""
+        yxTk, xxTk, yyTk, nk = stats if stats is not None else self.weighted_statistics(x, y, weights)
+        As = np.swapaxes(np.linalg.solve(xxTk, np.swapaxes(yxTk, 1, 2)), 1, 2)
+        sigmas = (yyTk - As @ np.swapaxes(yxTk, 1, 2)) / nk[:, None, None]
+        sigmas = symmetrize(sigmas) + 1e-16 * np.eye(self.output_dim)
+        assert np.all(np.linalg.eigvalsh(sigmas) > 0.)
+        self.As, self.lmbdas = As, np.linalg.inv(sigmas)
+
+
+_joint_cache = {}
+
+
+def joint_rows(x, y):
+    """z = [x, y] as one C-contiguous (N, dx+dy) array; the same (x, y) pair maps to the same z
+    object so that the engine's identity-based binding recognises it across calls."""
+    key = (x.__array_interface__['data'][0], y.__array_interface__['data'][0], x.shape, y.shape)
+    hit = _joint_cache.get('last')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    z = np.ascontiguousarray(np.hstack((x, y)))
+    _joint_cache['last'] = (key, z, x, y)
+    return z

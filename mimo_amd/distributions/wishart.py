@@ -1,0 +1,115 @@
+"""Wishart distribution (host-side, O(D^3)) and batched helpers shared by the Normal-Wishart and
+Matrix-Normal-Wishart blocks.  Reference: mimo/distributions/wishart.py:11-153."""
+import numpy as np
+import numpy.random as npr
+from scipy.special import multigammaln, digamma
+
+from mimo_amd.utils.abstraction import Statistics as Stats
+
+
+def sum_log_diag_chol(mats):
+    """sum_i log diag(chol(A))_i for a stack (..., D, D) of SPD matrices (= 1/2 logdet A)."""
+    chol = np.linalg.cholesky(mats)
+    return np.sum(np.log(np.diagonal(chol, axis1=-2, axis2=-1)), axis=-1)
+
+
+def wishart_log_partition(psis, nus):
+    """wishart.py:129-132, vectorised over a stack: nu D/2 log 2 + ln Gamma_D(nu/2) + nu sum log diag chol psi."""
+    D = psis.shape[-1]
+    return 0.5 * nus * D * np.log(2) + multigammaln(nus / 2., D) + nus * sum_log_diag_chol(psis)
+
+
+def wishart_expected_logdet(psis, nus):
+    """wishart.py:139-143: E[logdet X] = sum_i psi((nu - i)/2) + D log 2 + 2 sum log diag chol psi."""
+    D = psis.shape[-1]
+    i = np.arange(D)
+    return np.sum(digamma((np.asarray(nus)[..., None] - i) / 2.), axis=-1) + D * np.log(2.)\
+        + 2. * sum_log_diag_chol(psis)
+
+
+def wishart_rvs(psi, nu):
+    """Bartlett decomposition with the reference's RNG call order (wishart.py:72-92):
+    normal(n_tril) for the strict lower triangle, then D separate chisquare(nu - i) draws."""
+    D = psi.shape[0]
+    n_tril = D * (D - 1) // 2
+    covariances = npr.normal(size=n_tril).reshape((n_tril,))
+    variances = np.array([npr.chisquare(nu - i, size=1)[0] ** 0.5 for i in range(D)])
+    A = np.zeros((D, D))
+    A[np.tril_indices(D, k=-1)] = covariances
+    A[np.diag_indices(D)] = variances
+    T = np.linalg.cholesky(psi) @ A
+    return T @ T.T
+
+
+class Wishart:
+
+    def __init__(self, dim, psi=None, nu=None):
+        self.dim = dim
+        self.psi = psi
+        self.nu = nu
+
+    @property
+    def params(self):
+        return self.psi, self.nu
+
+    @params.setter
+    def params(self, values):
+        self.psi, self.nu = values
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    @staticmethod
+    def std_to_nat(params):
+        a = - 0.5 * np.linalg.inv(params[0])
+        return Stats([a, 0.5 * (params[1] - a.shape[0] - 1)])
+
+    @staticmethod
+    def nat_to_std(natparam):
+        psi = - 0.5 * np.linalg.inv(natparam[0])
+        return psi, 2. * natparam[1] + psi.shape[0] + 1
+
+    @property
+    def psi_chol(self):
+        return np.linalg.cholesky(self.psi)
+
+    def mean(self):
+        return self.nu * self.psi
+
+    def mode(self):
+        assert self.nu >= (self.dim + 1)
+        return (self.nu - self.dim - 1) * self.psi
+
+    def rvs(self, size=1):
+        return wishart_rvs(self.psi, self.nu)
+
+    @property
+    def base(self):
+        return 1.
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        return wishart_log_partition(self.psi, self.nu)
+
+    def log_likelihood(self, x):
+        log_lik = 0.5 * (self.nu - self.dim - 1) * np.linalg.slogdet(x)[1]\
+            - 0.5 * np.trace(np.linalg.solve(self.psi, x))
+        return - self.log_partition() + self.log_base() + log_lik
+
+    def expected_statistics(self):
+        return self.nu * self.psi, wishart_expected_logdet(self.psi, self.nu)
+
+    def entropy(self):
+        nat, stats = self.nat_param, self.expected_statistics()
+        return self.log_partition() - self.log_base() - (np.tensordot(nat[0], stats[0]) + nat[1] * stats[1])
+
+    def cross_entropy(self, dist):
+        nat, stats = dist.nat_param, self.expected_statistics()
+        return dist.log_partition() - dist.log_base() - (np.tensordot(nat[0], stats[0]) + nat[1] * stats[1])

@@ -190,6 +190,16 @@ class HipEngine:
         self._check(self._lib.mimo_label_stats(self._ctx, p, K, 0, _ptr(S)))
         return SuffStats.from_packed(S, K, self.D)
 
+    def table_entropy(self, table=None):
+        """-sum t log t of a (K,N) host table (None: the resident responsibilities)."""
+        out = C.c_double()
+        if table is None:
+            self._check(self._lib.mimo_table_entropy(self._ctx, None, 0, 0, C.byref(out)))
+        else:
+            table = _f64(table)
+            self._check(self._lib.mimo_table_entropy(self._ctx, _ptr(table), table.size, 0, C.byref(out)))
+        return out.value
+
     # -- copy-outs ------------------------------------------------------------------------
     def get_resp(self, K=None):
         out = np.empty((int(K if K is not None else self._K), self.N))
@@ -216,3 +226,47 @@ def philox_uniforms(seed, rows, sweep):
     """Host mirror of the in-kernel Philox4x32-10 stream (one uniform per global row index)."""
     lib = _lib.load()
     return np.array([lib.mimo_philox_uniform(int(seed), int(r), int(sweep)) for r in rows])
+
+
+# ---------------------------------------------------------------------------------------------
+# data binding used by the reference-shaped array methods (log_likelihood(x), weighted_statistics
+# (x, w), ...): the array last bound stays resident, so passing the SAME array again costs nothing.
+# ---------------------------------------------------------------------------------------------
+def _bind_key(Z):
+    return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str)
+
+
+def bind(engine, Z):
+    """Make `Z` ((N,Dz) float64 host array) the engine's resident data set, uploading it only if it
+    is not the array bound last (identity = address + shape; in-place edits need engine.unbind())."""
+    Z = np.asarray(Z)
+    if Z.ndim == 1:
+        Z = Z.reshape(-1, 1)
+    key = _bind_key(Z)
+    if getattr(engine, "_bound_key", None) != key:
+        engine.upload(Z)
+        engine._bound_key = key
+        engine._bound_ref = Z        # keeps the address from being recycled
+    return engine
+
+
+def unbind(engine):
+    engine._bound_key = None
+    engine._bound_ref = None
+
+
+_default_engine = None
+
+
+def default_engine():
+    """Process-wide engine on device LOCAL_RANK (one process per GPU); raises without HIP."""
+    global _default_engine
+    if _default_engine is None:
+        import os
+        _default_engine = HipEngine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_engine
+
+
+def set_default_engine(engine):
+    global _default_engine
+    _default_engine = engine

@@ -1,0 +1,376 @@
+"""(Bayesian) mixtures of Gaussians — drivers of EM, MAP, Gibbs sampling, mean-field VI and SVI.
+
+Same class / method surface as the reference's mimo/mixtures/gmm.py, re-built around ONE fused
+pass over the device-resident data per sweep (HipEngine.estep / HipEngine.gibbs_labels):
+
+    reference VI iteration (gmm.py:275-285)           this module
+    --------------------------------------------      ------------------------------------------
+    weighted_statistics(obs, resp)   O(NKD^2)  \
+    expected_responsibilities(obs)   O(NKD^2)   }     engine.estep(c, b, W) -> S, sum_n lse_n
+    variational_lowerbound_obs(...)  O(NKD^2)  /      (responsibilities never leave the GPU)
+    conjugate update + ELBO prior terms  O(KD^3)      unchanged (host, float64 NumPy)
+
+The data/label ELBO terms come from the identity (verified on the reference)
+    sum resp * E[log p(x|k)] + sum resp * E[log pi] - sum resp log resp = sum_n logsumexp_k l[k,n].
+Host RNG (Wishart / Dirichlet / Beta draws, optional label uniforms) stays numpy.random in the
+reference's call order, so seeded runs are comparable.
+"""
+import numpy as np
+import numpy.random as npr
+from tqdm import tqdm
+
+from mimo_amd import engine as _engine
+from mimo_amd.utils.abstraction import Statistics as Stats
+from mimo_amd.utils.data import batches
+from mimo_amd.distributions.bayesian import CategoricalWithDirichlet, CategoricalWithStickBreaking  # noqa: F401
+
+
+def _component_stats(S):
+    """engine block -> Stats([sum r x, n, sum r xx', n]) (gaussian.py:502)."""
+    return Stats([S.sx, S.n, S.sxx, S.n])
+
+
+def canonical_inner(c, b, W, S):
+    """sum_kn r_kn l_kn = <Theta, S(r)>  for l = c + b.x - 1/2 x'Wx  and S the statistics of r."""
+    return float(np.sum(c * S.n) + np.sum(b * S.sx) - 0.5 * np.sum(W * S.sxx))
+
+
+class MixtureOfGaussians:
+    """reference: mimo/mixtures/gmm.py:16-145 (plotting omitted)."""
+
+    def __init__(self, gating, components, engine=None):
+        assert components.size == gating.dim
+        self.gating = gating
+        self.components = components
+        self._engine = engine
+
+    @property
+    def engine(self):
+        return self._engine if self._engine is not None else self.components.engine
+
+    @property
+    def size(self):
+        return self.gating.dim
+
+    @property
+    def dim(self):
+        return self.components.dim
+
+    def used_labels(self, obs):
+        labels = np.argmax(self.responsibilities(obs), axis=0)
+        return np.where(np.bincount(labels, minlength=self.size) > 0)[0]
+
+    def rvs(self, size=1):
+        """gmm.py:50-60 (same RNG order: labels, per-component draws, permutation)."""
+        labels = self.gating.rvs(size)
+        counts = np.bincount(labels, minlength=self.size)
+        obs = np.zeros((size, self.dim))
+        ci = self.components.lmbdas_chol_inv
+        for idx, count in enumerate(counts):
+            shape = self.dim if count == 1 else (count, self.dim)
+            obs[labels == idx, ...] = self.components.mus[idx] + npr.normal(size=shape).dot(ci[idx].T)
+        perm = npr.permutation(size)
+        return obs[perm], labels[perm]
+
+    # ---- canonical form ---------------------------------------------------------------------
+    def canonical(self):
+        c, b, W = self.components.canonical()
+        with np.errstate(divide='ignore'):
+            return c + np.log(self.gating.probs), b, W
+
+    def _bind(self, obs):
+        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+
+    # ---- reference-shaped table methods --------------------------------------------------------
+    def log_complete_likelihood(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def log_likelihood(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical(), stats=False, keep_lse=True)
+        return eng.get_lse()
+
+    def responsibilities(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical(), stats=False, keep_resp=True)
+        return eng.get_resp(self.size)
+
+    # ---- EM ------------------------------------------------------------------------------------
+    def max_likelihood(self, obs, randomize=True, weights=None, maxiter=250, progress_bar=True, process_id=0):
+        """gmm.py:77-103.  Each iteration is one fused pass: the E-step under the new parameters
+        also yields the statistics of the next M-step and sum_n log p(x_n)."""
+        eng = self._bind(obs)
+        if weights is not None:
+            return self._max_likelihood_weighted(eng, randomize, weights, maxiter, progress_bar, process_id)
+        if randomize:
+            resp = npr.rand(self.size, eng.N)
+            resp /= np.sum(resp, axis=0)
+            S = eng.weighted_stats(resp)
+        else:
+            S, _ = eng.estep(*self.canonical())
+        log_lik = []
+        with tqdm(total=maxiter, desc=f'EM #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for _ in range(maxiter):
+                self.components.max_likelihood(None, stats=_component_stats(S))
+                self.gating.max_likelihood(None, S.n)
+                S, sc = eng.estep(*self.canonical())
+                log_lik.append(sc[0])
+                pbar.update(1)
+        return log_lik
+
+    def _max_likelihood_weighted(self, eng, randomize, weights, maxiter, progress_bar, process_id):
+        """per-datum weights (gmm.py:93): resp * weights needs the table; kept for API parity."""
+        if randomize:
+            resp = npr.rand(self.size, eng.N)
+            resp /= np.sum(resp, axis=0)
+        else:
+            eng.estep(*self.canonical(), stats=False, keep_resp=True)
+            resp = eng.get_resp(self.size)
+        log_lik = []
+        with tqdm(total=maxiter, desc=f'EM #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for _ in range(maxiter):
+                S = eng.weighted_stats(resp * weights)
+                self.components.max_likelihood(None, stats=_component_stats(S))
+                self.gating.max_likelihood(None, S.n)
+                _, sc = eng.estep(*self.canonical(), stats=False, keep_resp=True)
+                resp = eng.get_resp(self.size)
+                log_lik.append(sc[0])
+                pbar.update(1)
+        return log_lik
+
+
+class BayesianMixtureOfGaussians:
+    """reference: mimo/mixtures/gmm.py:147-371 (plotting omitted)."""
+
+    def __init__(self, gating, components, engine=None):
+        self.gating = gating
+        self.components = components
+        self.likelihood = MixtureOfGaussians(gating=self.gating.likelihood,
+                                             components=self.components.likelihood, engine=engine)
+        self._engine = engine
+        self._batch_engine = None
+        self.labels_ = None
+
+    @property
+    def engine(self):
+        return self._engine if self._engine is not None else self.components.likelihood.engine
+
+    @property
+    def size(self):
+        return self.likelihood.size
+
+    @property
+    def dim(self):
+        return self.likelihood.dim
+
+    def _bind(self, obs):
+        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+
+    def used_labels(self, obs):
+        labels = np.argmax(self.expected_responsibilities(obs), axis=0)
+        return np.where(np.bincount(labels, minlength=self.size) > 0)[0]
+
+    # ---- canonical forms ---------------------------------------------------------------------
+    def canonical_expected(self):
+        """VI form: <E_q[eta_k], t(x)> + E[log pi_k]  (gmm.py:244-254)."""
+        c, b, W = self.components.canonical_expected()
+        return c + self.gating.expected_log_gating(), b, W
+
+    # ---- MAP-EM --------------------------------------------------------------------------------
+    def max_aposteriori(self, obs, randomize=True, maxiter=250, progress_bar=True, process_id=0):
+        """gmm.py:176-204."""
+        eng = self._bind(obs)
+        if randomize:
+            resp = npr.rand(self.size, eng.N)
+            resp /= np.sum(resp, axis=0)
+            S = eng.weighted_stats(resp)
+        else:
+            S, _ = eng.estep(*self.likelihood.canonical())
+        log_prob = []
+        with tqdm(total=maxiter, desc=f'MAP #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for _ in range(maxiter):
+                self.components.max_aposteriori(None, stats=_component_stats(S))
+                self.gating.max_aposteriori(None, S.n)
+                S, sc = eng.estep(*self.likelihood.canonical())
+                log_prior = self.gating.prior.log_likelihood(self.gating.likelihood.params)\
+                    + np.sum(self.components.prior.log_likelihood(self.components.likelihood.params))
+                log_prob.append(sc[0] + log_prior)
+                pbar.update(1)
+        return log_prob
+
+    # ---- Gibbs sampling ------------------------------------------------------------------------
+    def resample(self, obs, init_labels='prior', maxiter=1, progress_bar=True, process_id=0,
+                 label_rng='host', seed=0):
+        """gmm.py:207-225 — sweep order components -> gating -> labels.
+
+        label_rng='host'   : the uniforms are numpy.random.random((1, N)) exactly as in
+                             mimo/utils/stats.py:14 (seeded runs reproduce the reference's labels).
+        label_rng='philox' : per-datum counter-based Philox4x32-10 inside the kernel, keyed by
+                             `seed`, counter (global row, sweep) — no PCIe traffic per sweep.
+        The label kernel also returns the statistics of the labels it drew, which are exactly what
+        the next sweep's resample_components / resample_gating need: one pass per sweep."""
+        eng = self._bind(obs)
+        N = eng.N
+        if init_labels == 'random':
+            labels = npr.choice(self.size, size=(N))
+        elif init_labels == 'prior':
+            labels = self.gating.likelihood.rvs(N)
+        elif init_labels == 'posterior':
+            labels = self._draw_labels(eng, label_rng, seed, 0, stats=False)[0]
+        else:
+            raise ValueError(init_labels)
+        S = eng.label_stats(labels, self.size)
+
+        with tqdm(total=maxiter, desc=f'Init #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for it in range(maxiter):
+                self.components.resample(None, stats=_component_stats(S))
+                self.gating.resample(None, counts=S.n)
+                last = it == maxiter - 1
+                labels, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last,
+                                              return_labels=last)
+                pbar.update(1)
+        self.labels_ = labels
+
+    resample_model = resample      # pybasicbayes-era name used by BASELINE.json's north star
+
+    def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
+        c, b, W = self.likelihood.canonical()
+        if label_rng == 'host':
+            u = npr.random(size=(1, eng.N))
+            return eng.gibbs_labels(c, b, W, u=u, stats=stats, return_labels=return_labels)
+        if label_rng == 'philox':
+            return eng.gibbs_labels(c, b, W, seed=seed, sweep=sweep, stats=stats, return_labels=return_labels)
+        raise ValueError(label_rng)
+
+    def resample_labels(self, obs):
+        """gmm.py:227-230 -> (log_prob (K,N), labels int32); reference-shaped (copies the table)."""
+        eng = self._bind(obs)
+        c, b, W = self.likelihood.canonical()
+        labels, _ = eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=False, keep_logp=True)
+        return eng.get_logp(self.size), labels
+
+    def resample_gating(self, labels):
+        self.gating.resample(np.asarray(labels).astype(int))
+
+    def resample_components(self, obs, labels):
+        """gmm.py:235-237 without the dense one_hot table."""
+        eng = self._bind(obs)
+        self.components.resample(None, stats=_component_stats(eng.label_stats(labels, self.size)))
+
+    # ---- mean field ----------------------------------------------------------------------------
+    def expected_log_complete_likelihood(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def expected_log_likelihood(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical_expected(), stats=False, keep_lse=True)
+        return eng.get_lse()
+
+    def expected_responsibilities(self, obs):
+        eng = self._bind(obs)
+        eng.estep(*self.canonical_expected(), stats=False, keep_resp=True)
+        return eng.get_resp(self.size)
+
+    def meanfield_coordinate_descent(self, obs, randomize=True, maxiter=250, tol=1e-8,
+                                     progress_bar=True, process_id=0, sample_likelihood=True):
+        """gmm.py:261-287.  Returns the ELBO list.  `sample_likelihood=False` drops the reference's
+        per-iteration likelihood.params = posterior.rvs() (host RNG only; no effect on the ELBO)."""
+        eng = self._bind(obs)
+        if randomize:
+            resp = npr.rand(self.size, eng.N)
+            resp /= np.sum(resp, axis=0)
+            S = eng.weighted_stats(resp)
+        else:
+            S, _ = eng.estep(*self.canonical_expected())
+        vlb = []
+        with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for _ in range(maxiter):
+                self._update_from_stats(S, sample_likelihood)
+                S, sc = eng.estep(*self.canonical_expected())
+                vlb.append(self._vlb_prior_terms() + sc[0])
+                if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
+                    return vlb
+                pbar.update(1)
+        return vlb
+
+    def _update_from_stats(self, S, sample=True):
+        self.components.meanfield_update(None, stats=_component_stats(S), sample=sample)
+        self.gating.meanfield_update(None, S.n, sample=sample)
+
+    def _vlb_prior_terms(self):
+        return self.gating.variational_lowerbound() + np.sum(self.components.variational_lowerbound())
+
+    def meanfield_update_parameters(self, obs, resp):
+        eng = self._bind(obs)
+        self._update_from_stats(eng.weighted_stats(resp))
+
+    def meanfield_update_gating(self, resp):
+        self.gating.meanfield_update(None, np.asarray(resp))
+
+    def meanfield_update_components(self, obs, resp):
+        eng = self._bind(obs)
+        self.components.meanfield_update(None, stats=_component_stats(eng.weighted_stats(resp)))
+
+    # ---- SVI -----------------------------------------------------------------------------------
+    def meanfield_stochastic_descent(self, obs, randomize=True, maxiter=500, step_size=1e-2, batch_size=128,
+                                     progress_bar=True, procces_id=0, sample_likelihood=True):
+        """gmm.py:300-326: one minibatch natural-gradient step + one full-data E-step / ELBO per
+        outer iteration (batches() yields a single batch — SURVEY.md Appendix B #6)."""
+        obs = np.asarray(obs, dtype=float).reshape(-1, self.dim)
+        eng = self._bind(obs)
+        if self._batch_engine is None:
+            self._batch_engine = type(eng)(eng.device) if hasattr(eng, "device") else eng.spawn()
+        beng = self._batch_engine
+        vlb = []
+        scale = batch_size / float(len(obs))
+        with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
+                  disable=not progress_bar) as pbar:
+            for i in range(maxiter):
+                for batch in batches(batch_size, len(obs)):
+                    beng.upload(obs[batch, :])
+                    if i == 0 and randomize is True:
+                        resp = npr.rand(self.size, len(batch))
+                        resp /= np.sum(resp, axis=0)
+                        Sb = beng.weighted_stats(resp)
+                    else:
+                        Sb, _ = beng.estep(*self.canonical_expected())
+                    self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb),
+                                                  sample=sample_likelihood)
+                    self.gating.meanfield_sgd(None, Sb.n, scale, step_size, sample=sample_likelihood)
+                _, sc = eng.estep(*self.canonical_expected(), stats=False)
+                vlb.append(self._vlb_prior_terms() + sc[0])
+                pbar.update(1)
+        return vlb
+
+    def meanfield_sgd_parameters(self, obs, resp, scale, step_size):
+        eng = _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+        S = eng.weighted_stats(resp)
+        self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(S))
+        self.gating.meanfield_sgd(None, S.n, scale, step_size)
+
+    # ---- ELBO with explicit responsibilities (reference-shaped) ----------------------------------
+    def variational_lowerbound_obs(self, obs, resp):
+        """gmm.py:338-339: sum resp * E[log p(x|k)] = <Theta_components, S(resp)> (no second table)."""
+        eng = self._bind(obs)
+        return canonical_inner(*self.components.canonical_expected(), eng.weighted_stats(resp))
+
+    def variational_lowerbound_labels(self, resp):
+        """gmm.py:341-356."""
+        resp = np.asarray(resp, dtype=float)
+        nk = np.sum(resp, axis=1)
+        vlb = float(np.sum(nk * self.gating.expected_log_gating()))
+        return vlb + self.engine.table_entropy(resp)
+
+    def variational_lowerbound(self, obs, resp):
+        """gmm.py:358-364."""
+        return self._vlb_prior_terms() + self.variational_lowerbound_obs(obs, resp)\
+            + self.variational_lowerbound_labels(resp)

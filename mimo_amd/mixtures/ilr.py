@@ -1,0 +1,347 @@
+"""(Bayesian) mixtures of linear-Gaussian experts ("infinite local regression").
+
+Same method surface as the reference's mimo/mixtures/ilr.py (inference part, :21-323).  The joint
+row z = [x, y] is the datum on the engine: the input density over x (`basis`), the expert density of
+y | x (`models`) and the gating add up to ONE quadratic form in z per component, and one fused pass
+returns the statistics of all three conjugate blocks (they are blocks of sum_n r z~ z~').
+"""
+import numpy as np
+import numpy.random as npr
+from tqdm import tqdm
+
+from mimo_amd import engine as _engine
+from mimo_amd.utils.abstraction import Statistics as Stats
+from mimo_amd.utils.data import batches
+from mimo_amd.distributions.lingauss import split_joint_stats, joint_rows
+from mimo_amd.mixtures.gmm import canonical_inner
+
+
+class Standardizer:
+    """Column standardisation with sklearn.preprocessing.StandardScaler semantics (population std,
+    zero-variance columns left unscaled) — what ilr.py:108-109,124-127 uses."""
+
+    def fit(self, a):
+        a = np.asarray(a, dtype=float)
+        self.mean_ = a.mean(axis=0)
+        self.scale_ = a.std(axis=0)
+        self.scale_[self.scale_ == 0.] = 1.
+        return self
+
+    def transform(self, a):
+        return (np.asarray(a, dtype=float) - self.mean_) / self.scale_
+
+    def inverse_transform(self, a):
+        return np.asarray(a, dtype=float) * self.scale_ + self.mean_
+
+
+def embed_joint(basis_cbw, models_cbw, gating_log, dx):
+    """Sum of the three per-component terms as one (c, b, W) over z = [x, y]."""
+    c1, b1, W1 = basis_cbw
+    c2, b2, W2 = models_cbw
+    W = W2.copy()
+    b = b2.copy()
+    W[:, :dx, :dx] += W1
+    b[:, :dx] += b1
+    return c1 + c2 + gating_log, b, W
+
+
+def embed_basis(basis_cbw, dz):
+    """The input-density term alone, zero-padded to z-space (for the per-block ELBO pieces)."""
+    c1, b1, W1 = basis_cbw
+    K, dx = b1.shape
+    W = np.zeros((K, dz, dz))
+    b = np.zeros((K, dz))
+    W[:, :dx, :dx] = W1
+    b[:, :dx] = b1
+    return c1, b, W
+
+
+class MixtureOfLinearGaussians:
+    """reference: mimo/mixtures/ilr.py:21-84"""
+
+    def __init__(self, size, input_dim, output_dim, gating, basis, models, engine=None):
+        self.size = size
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.gating = gating
+        self.basis = basis
+        self.models = models
+        self._engine = engine
+
+    @property
+    def engine(self):
+        return self._engine if self._engine is not None else self.models.engine
+
+    def canonical(self):
+        with np.errstate(divide='ignore'):
+            return embed_joint(self.basis.canonical(), self.models.canonical(),
+                               np.log(self.gating.probs), self.input_dim)
+
+    def _bind(self, x, y):
+        x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
+        y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
+        return _engine.bind(self.engine, joint_rows(x, y))
+
+    def log_complete_likelihood(self, x, y):
+        eng = self._bind(x, y)
+        eng.estep(*self.canonical(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def log_likelihood(self, x, y):
+        eng = self._bind(x, y)
+        eng.estep(*self.canonical(), stats=False, keep_lse=True)
+        return eng.get_lse()
+
+    def responsibilities(self, x, y):
+        eng = self._bind(x, y)
+        eng.estep(*self.canonical(), stats=False, keep_resp=True)
+        return eng.get_resp(self.size)
+
+    def rvs(self, size=1):
+        z = self.gating.rvs(size)
+        counts = np.bincount(z, minlength=self.size)
+        x = np.empty((size, self.input_dim))
+        y = np.empty((size, self.output_dim))
+        bci, mci = self.basis.lmbdas_chol_inv, self.models.lmbdas_chol_inv
+        for idx, count in enumerate(counts):
+            shape = self.input_dim if count == 1 else (count, self.input_dim)
+            xk = np.reshape(self.basis.mus[idx] + npr.normal(size=shape).dot(bci[idx].T), (-1, self.input_dim))
+            mu = self.models.predict(xk)[idx]
+            x[z == idx, ...] = xk
+            y[z == idx, ...] = mu + npr.normal(size=(xk.shape[0], self.output_dim)).dot(mci[idx].T)
+        perm = npr.permutation(size)
+        return x[perm], y[perm], z[perm]
+
+
+class BayesianMixtureOfLinearGaussians:
+    """reference: mimo/mixtures/ilr.py:87-323 (prediction :325-430 is outside the hot path)."""
+
+    def __init__(self, size, input_dim, output_dim, gating, basis, models, scale=False, engine=None):
+        self.size = size
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.gating = gating
+        self.basis = basis
+        self.models = models
+        self.likelihood = MixtureOfLinearGaussians(size, input_dim, output_dim, gating=self.gating.likelihood,
+                                                   basis=self.basis.likelihood, models=self.models.likelihood,
+                                                   engine=engine)
+        self.scale = scale
+        self.input_transform = Standardizer()
+        self.output_transform = Standardizer()
+        self._engine = engine
+        self._batch_engine = None
+        self.labels_ = None
+
+    @property
+    def engine(self):
+        return self._engine if self._engine is not None else self.models.likelihood.engine
+
+    @property
+    def affine(self):
+        return self.models.likelihood.affine
+
+    def init_transform(self, x, y):
+        self.scale = True
+        self.input_transform.fit(x)
+        self.output_transform.fit(y)
+
+    def _scaled(self, x, y):
+        x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
+        y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
+        if self.scale:
+            key = (x.__array_interface__['data'][0], y.__array_interface__['data'][0], x.shape)
+            hit = getattr(self, "_scaled_cache", None)
+            if hit is None or hit[0] != key:
+                hit = (key, np.ascontiguousarray(self.input_transform.transform(x)),
+                       np.ascontiguousarray(self.output_transform.transform(y)), x, y)
+                self._scaled_cache = hit
+            return hit[1], hit[2]
+        return x, y
+
+    def _bind(self, xx, yy):
+        return _engine.bind(self.engine, joint_rows(xx, yy))
+
+    def used_labels(self, x, y):
+        labels = np.argmax(self.expected_responsibilities(*self._scaled(x, y)), axis=0)
+        return np.where(np.bincount(labels, minlength=self.size) > 0)[0]
+
+    # ---- statistics blocks -----------------------------------------------------------------------
+    def _block_stats(self, S):
+        (xk, xxTk), (yxT, xxT, yyT) = split_joint_stats(S, self.input_dim, self.affine)
+        return Stats([xk, S.n, xxTk, S.n]), Stats([yxT, xxT, yyT, S.n])
+
+    # ---- canonical forms --------------------------------------------------------------------------
+    def canonical_expected(self):
+        """ilr.py:178-189: basis + models + gating, mean-field form."""
+        return embed_joint(self.basis.canonical_expected(), self.models.canonical_expected(),
+                           self.gating.expected_log_gating(), self.input_dim)
+
+    # ---- Gibbs sampling --------------------------------------------------------------------------
+    def resample(self, x, y, init_labels='prior', maxiter=1, progress_bar=True, process_id=0,
+                 label_rng='host', seed=0):
+        """ilr.py:134-159 — sweep order basis -> models -> gating -> labels."""
+        xx, yy = self._scaled(x, y)
+        eng = self._bind(xx, yy)
+        N = eng.N
+        if init_labels == 'random':
+            z = npr.choice(self.size, size=(N))
+        elif init_labels == 'posterior':
+            z = self._draw_labels(eng, label_rng, seed, 0, stats=False)[0]
+        elif init_labels == 'prior':
+            z = self.gating.likelihood.rvs(N)
+        else:
+            raise ValueError(init_labels)
+        S = eng.label_stats(z, self.size)
+        with tqdm(total=maxiter, desc=f'Init #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for it in range(maxiter):
+                bstats, mstats = self._block_stats(S)
+                self.basis.resample(None, stats=bstats)
+                self.models.resample(None, None, stats=mstats)
+                self.gating.resample(None, counts=S.n)
+                last = it == maxiter - 1
+                z, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last, return_labels=last)
+                pbar.update(1)
+        self.labels_ = z
+
+    resample_model = resample
+
+    def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
+        c, b, W = self.likelihood.canonical()
+        if label_rng == 'host':
+            return eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=stats,
+                                    return_labels=return_labels)
+        if label_rng == 'philox':
+            return eng.gibbs_labels(c, b, W, seed=seed, sweep=sweep, stats=stats, return_labels=return_labels)
+        raise ValueError(label_rng)
+
+    def resample_labels(self, x, y):
+        eng = self._bind(*self._as2d(x, y))
+        c, b, W = self.likelihood.canonical()
+        labels, _ = eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=False, keep_logp=True)
+        return eng.get_logp(self.size), labels
+
+    def _as2d(self, x, y):
+        return (np.asarray(x, dtype=float).reshape(-1, self.input_dim),
+                np.asarray(y, dtype=float).reshape(-1, self.output_dim))
+
+    def resample_gating(self, z):
+        self.gating.resample(np.asarray(z).astype(int))
+
+    def resample_basis(self, x, z):
+        """ilr.py:169-171 without the dense one_hot table."""
+        S = self.basis.likelihood._bind(x).label_stats(z, self.size)
+        self.basis.resample(None, stats=Stats([S.sx, S.n, S.sxx, S.n]))
+
+    def resample_models(self, x, y, z):
+        """ilr.py:173-175 without the dense one_hot table."""
+        S = self._bind(*self._as2d(x, y)).label_stats(z, self.size)
+        self.models.resample(None, None, stats=self._block_stats(S)[1])
+
+    # ---- mean field --------------------------------------------------------------------------------
+    def expected_log_complete_likelihood(self, x, y):
+        eng = self._bind(*self._as2d(x, y))
+        eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def expected_responsibilities(self, x, y):
+        eng = self._bind(*self._as2d(x, y))
+        eng.estep(*self.canonical_expected(), stats=False, keep_resp=True)
+        return eng.get_resp(self.size)
+
+    def meanfield_coordinate_descent(self, x, y, randomize=True, maxiter=250, tol=1e-8,
+                                     progress_bar=True, process_id=0, sample_likelihood=True):
+        """ilr.py:196-228."""
+        xx, yy = self._scaled(x, y)
+        eng = self._bind(xx, yy)
+        if randomize:
+            resp = npr.rand(self.size, eng.N)
+            resp /= np.sum(resp, axis=0)
+            S = eng.weighted_stats(resp)
+        else:
+            S, _ = eng.estep(*self.canonical_expected())
+        vlb = []
+        with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,
+                  disable=not progress_bar) as pbar:
+            for _ in range(maxiter):
+                self._update_from_stats(S, sample_likelihood)
+                S, sc = eng.estep(*self.canonical_expected())
+                vlb.append(self._vlb_prior_terms() + sc[0])
+                if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
+                    return vlb
+                pbar.update(1)
+        return vlb
+
+    def _update_from_stats(self, S, sample=True):
+        bstats, mstats = self._block_stats(S)
+        self.basis.meanfield_update(None, stats=bstats, sample=sample)
+        self.models.meanfield_update(None, None, stats=mstats, sample=sample)
+        self.gating.meanfield_update(None, S.n, sample=sample)
+
+    def _vlb_prior_terms(self):
+        return self.gating.variational_lowerbound() + np.sum(self.basis.variational_lowerbound())\
+            + np.sum(self.models.variational_lowerbound())
+
+    def meanfield_update_parameters(self, x, y, resp):
+        eng = self._bind(*self._as2d(x, y))
+        self._update_from_stats(eng.weighted_stats(resp))
+
+    def meanfield_update_gating(self, resp):
+        self.gating.meanfield_update(None, np.asarray(resp))
+
+    def meanfield_update_basis(self, x, resp):
+        self.basis.meanfield_update(x, resp)
+
+    def meanfield_update_models(self, x, y, resp):
+        self.models.meanfield_update(x, y, resp)
+
+    # ---- SVI ---------------------------------------------------------------------------------------
+    def meanfield_stochastic_descent(self, x, y, randomize=True, maxiter=500, step_size=1e-3, batch_size=128,
+                                     progress_bar=True, procces_id=0, sample_likelihood=True):
+        """ilr.py:245-277."""
+        xx, yy = self._scaled(x, y)
+        eng = self._bind(xx, yy)
+        zz = joint_rows(xx, yy)
+        if self._batch_engine is None:
+            self._batch_engine = type(eng)(eng.device) if hasattr(eng, "device") else eng.spawn()
+        beng = self._batch_engine
+        vlb = []
+        scale = batch_size / float(len(xx))
+        with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
+                  disable=not progress_bar) as pbar:
+            for i in range(maxiter):
+                for batch in batches(batch_size, len(xx)):
+                    beng.upload(zz[batch, :])
+                    if i == 0 and randomize is True:
+                        resp = npr.rand(self.size, len(batch))
+                        resp /= np.sum(resp, axis=0)
+                        Sb = beng.weighted_stats(resp)
+                    else:
+                        Sb, _ = beng.estep(*self.canonical_expected())
+                    bstats, mstats = self._block_stats(Sb)
+                    self.basis.meanfield_sgd(None, None, scale, step_size, stats=bstats, sample=sample_likelihood)
+                    self.models.meanfield_sgd(None, None, None, scale, step_size, stats=mstats,
+                                              sample=sample_likelihood)
+                    self.gating.meanfield_sgd(None, Sb.n, scale, step_size, sample=sample_likelihood)
+                _, sc = eng.estep(*self.canonical_expected(), stats=False)
+                vlb.append(self._vlb_prior_terms() + sc[0])
+                pbar.update(1)
+        return vlb
+
+    # ---- ELBO with explicit responsibilities (reference-shaped) -------------------------------------
+    def variational_lowerbound_data(self, x, y, resp):
+        """ilr.py:293-297: sum resp * (basis + models expected log-densities) = <Theta, S(resp)>."""
+        eng = self._bind(*self._as2d(x, y))
+        S = eng.weighted_stats(resp)
+        cbw = embed_joint(self.basis.canonical_expected(), self.models.canonical_expected(), 0., self.input_dim)
+        return canonical_inner(*cbw, S)
+
+    def variational_lowerbound_labels(self, resp):
+        resp = np.asarray(resp, dtype=float)
+        nk = np.sum(resp, axis=1)
+        return float(np.sum(nk * self.gating.expected_log_gating())) + self.engine.table_entropy(resp)
+
+    def variational_lowerbound(self, x, y, resp):
+        return self._vlb_prior_terms() + self.variational_lowerbound_data(x, y, resp)\
+            + self.variational_lowerbound_labels(resp)

@@ -1,0 +1,206 @@
+"""Shared parity checks of the host API (mimo_amd.distributions / mimo_amd.mixtures) against the golden
+vectors of the reference.  Run on CPU with the oracle-backed test double (tests/test_host_models.py)
+and on the GPU with the real HipEngine through the C ABI (tests/test_gpu_parity.py)."""
+import numpy as np
+import numpy.random as npr
+
+from conftest import load_golden, rel_err, gating_of, nw_of, mnw_of
+from mimo_amd.distributions import (Dirichlet, TruncatedStickBreaking, CategoricalWithDirichlet,
+                                    CategoricalWithStickBreaking, StackedNormalWisharts,
+                                    StackedGaussiansWithNormalWisharts, StackedMatrixNormalWisharts,
+                                    StackedLinearGaussiansWithMatrixNormalWisharts)
+from mimo_amd.mixtures import BayesianMixtureOfGaussians, BayesianMixtureOfLinearGaussians
+
+
+def make_gating(g, K):
+    kind, gprior = gating_of(g, "gprior")
+    if kind == "dirichlet":
+        return kind, CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=gprior.copy()))
+    prior = TruncatedStickBreaking(dim=K, gammas=gprior[0].copy(), deltas=gprior[1].copy())
+    return kind, CategoricalWithStickBreaking(dim=K, prior=prior)
+
+
+def set_gating_posterior(gating, kind, params):
+    if kind == "dirichlet":
+        gating.posterior.alphas = params.copy()
+    else:
+        gating.posterior.gammas, gating.posterior.deltas = params[0].copy(), params[1].copy()
+
+
+def gating_posterior(gating, kind):
+    return gating.posterior.alphas if kind == "dirichlet" else (gating.posterior.gammas, gating.posterior.deltas)
+
+
+def build_gmm(g, engine):
+    K, D = int(g["K"]), int(g["D"])
+    kind, gating = make_gating(g, K)
+    prior = StackedNormalWisharts(size=K, dim=D, **{k: g["prior_" + k] for k in ("mus", "kappas", "psis", "nus")})
+    comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior, engine=engine)
+    return kind, BayesianMixtureOfGaussians(gating=gating, components=comps, engine=engine)
+
+
+def load_gmm_state(model, g, kind, prefix="post", gprefix="gpost"):
+    model.components.posterior.params = nw_of(g, prefix)
+    set_gating_posterior(model.gating, kind, gating_of(g, gprefix)[1])
+    if "lik_mus" in g:
+        model.components.likelihood.params = (g["lik_mus"], g["lik_lmbdas"])
+        model.gating.likelihood.params = g["lik_probs"].copy()
+
+
+def check_gmm_case(name, engine, tol=1e-9):
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    kind, model = build_gmm(g, engine)
+    load_gmm_state(model, g, kind)
+
+    # Gibbs / EM form (A1, A2)
+    assert rel_err(model.components.likelihood.log_likelihood(X), g["A1_loglik"]) < tol
+    assert rel_err(model.likelihood.log_complete_likelihood(X), g["A2_lcl"]) < tol
+    assert rel_err(model.likelihood.responsibilities(X), g["A2_resp"]) < tol
+    assert rel_err(model.likelihood.log_likelihood(X), g["A2_ll"]) < tol
+    # mean-field form (A3, A4)
+    assert rel_err(model.components.expected_log_likelihood(X), g["A3_eloglik"]) < tol
+    assert rel_err(model.expected_log_complete_likelihood(X), g["A4_elcl"]) < tol
+    assert rel_err(model.expected_responsibilities(X), g["A4_eresp"]) < tol
+    assert rel_err(model.expected_log_likelihood(X), g["A4_ell"]) < tol
+    # statistics (A10, A12) for reference responsibilities and for random weights
+    st = model.components.likelihood.weighted_statistics(X, g["A4_eresp"])
+    assert rel_err(st[0], g["stats_xk"]) < tol and rel_err(st[1], g["stats_nk"]) < tol
+    assert rel_err(st[2], g["stats_xxTk"]) < tol and rel_err(st[3], g["counts"]) < tol
+    st0 = model.components.likelihood.weighted_statistics(X, g["resp0"])
+    assert rel_err(st0[2], g["stats0_xxTk"]) < tol and rel_err(st0[0], g["stats0_xk"]) < tol
+    # label draw (A8): reference uniforms and the engine's own counter-based stream — bit exact
+    eng = model._bind(X)
+    c, b, W = model.likelihood.canonical()
+    labels, S = eng.gibbs_labels(c, b, W, u=g["u_mt"])
+    assert labels.dtype == np.int32 and np.array_equal(labels, g["labels_mt"])
+    assert rel_err(S.sxx, g["lstats_xxTk"]) < tol and np.array_equal(S.n, g["lcounts"])
+    labels_p, _ = eng.gibbs_labels(c, b, W, seed=1337, sweep=3, stats=False)
+    assert np.array_equal(labels_p, g["labels_philox"])
+    S2 = eng.label_stats(g["labels_mt"], K)
+    assert rel_err(S2.sxx, g["lstats_xxTk"]) < tol and rel_err(S2.sx, g["lstats_xk"]) < tol
+    # ELBO pieces (A14)
+    assert abs(model.variational_lowerbound_obs(X, g["A4_eresp"]) - g["vlb_obs"]) < tol * abs(g["vlb_obs"])
+    assert abs(model.variational_lowerbound_labels(g["A4_eresp"]) - g["vlb_labels"]) < tol * abs(g["vlb_labels"])
+    assert abs(model.gating.variational_lowerbound() - g["vlb_gating"]) < tol * max(1., abs(g["vlb_gating"]))
+    assert rel_err(model.components.variational_lowerbound(), g["vlb_comps"]) < tol
+    assert abs(model.variational_lowerbound(X, g["A4_eresp"]) - g["vlb_total"]) < tol * abs(g["vlb_total"])
+    # the fused pass returns the same ELBO data terms and statistics in one go
+    Sf, sc = eng.estep(*model.canonical_expected())
+    assert abs(sc[0] - (g["vlb_obs"] + g["vlb_labels"])) < tol * abs(sc[0])
+    assert rel_err(Sf.sxx, g["stats_xxTk"]) < tol and rel_err(Sf.n, g["counts"]) < tol
+    # conjugate update (A13)
+    model.meanfield_update_parameters(X, g["A4_eresp"])
+    for a, bb in zip(model.components.posterior.params, nw_of(g, "post2")):
+        assert rel_err(a, bb) < 1e-8
+    for a, bb in zip(np.atleast_2d(gating_posterior(model.gating, kind)), np.atleast_2d(gating_of(g, "gpost2")[1])):
+        assert rel_err(a, bb) < tol
+
+
+def check_gmm_vi_trace(name, engine, tol=1e-8):
+    g = load_golden(name)
+    kind, model = build_gmm(g, engine)
+    load_gmm_state(model, g, kind)
+    vlb = model.meanfield_coordinate_descent(g["X"], randomize=False, maxiter=len(g["vi_vlb"]), tol=0.,
+                                             progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    for a, b in zip(model.components.posterior.params, nw_of(g, "vi_post")):
+        assert rel_err(a, b) < 1e-6
+    assert np.all(np.diff(vlb) >= -1e-8 * abs(vlb[-1]))        # ELBO monotone (examples/gmm/toy/vi_toy.py:60)
+
+
+def check_gibbs_trace(name, engine):
+    """Seeded Gibbs run through the public driver reproduces the reference's labels and parameters."""
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    kind, model = build_gmm(g, engine)
+    model.components.likelihood.params = (g["lik0_mus"], g["lik0_lmbdas"])
+    model.gating.likelihood.params = g["lik0_probs"].copy()
+    # explicit sweeps through the reference-shaped methods
+    npr.seed(int(g["seed2"]))
+    labels = model.gating.likelihood.rvs(len(X))
+    assert np.array_equal(labels, g["labels_init"])
+    for s in range(5):
+        model.resample_components(X, labels)
+        model.resample_gating(labels)
+        _, labels = model.resample_labels(X)
+        assert np.array_equal(labels, g[f"s{s}_labels"]), f"sweep {s}"
+        assert rel_err(model.components.likelihood.mus, g[f"s{s}_mus"]) < 1e-8
+        assert rel_err(model.gating.likelihood.probs, g[f"s{s}_probs"]) < 1e-10
+    # the fused driver, same seed
+    kind, model = build_gmm(g, engine)
+    model.components.likelihood.params = (g["lik0_mus"], g["lik0_lmbdas"])
+    model.gating.likelihood.params = g["lik0_probs"].copy()
+    npr.seed(int(g["seed2"]))
+    model.resample(X, init_labels='prior', maxiter=5, progress_bar=False, label_rng='host')
+    assert np.array_equal(model.labels_, g["s4_labels"])
+    assert rel_err(model.components.likelihood.mus, g["driver_mus"]) < 1e-8
+    assert rel_err(model.gating.likelihood.probs, g["driver_probs"]) < 1e-10
+
+
+def build_ilr(g, engine):
+    K = int(g["K"])
+    dx, dy = g["X"].shape[1], g["Y"].shape[1]
+    kind, gating = make_gating(g, K)
+    bprior = StackedNormalWisharts(size=K, dim=dx, **{k: g["bprior_" + k] for k in ("mus", "kappas", "psis", "nus")})
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior, engine=engine)
+    mprior = StackedMatrixNormalWisharts(K, dx + 1, dy, **{k: g["mprior_" + k] for k in ("Ms", "Ks", "psis", "nus")})
+    models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dx + 1, dy, mprior, affine=True, engine=engine)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis,
+                                           models=models, engine=engine)
+    return kind, ilr
+
+
+def load_ilr_state(ilr, g, kind):
+    ilr.basis.posterior.params = nw_of(g, "bpost")
+    ilr.models.posterior.params = mnw_of(g, "mpost")
+    set_gating_posterior(ilr.gating, kind, gating_of(g, "gpost")[1])
+    ilr.basis.likelihood.params = (g["lik_mus"], g["lik_lmbdas"])
+    ilr.models.likelihood.params = (g["lik_As"], g["lik_lmbdas_y"])
+    ilr.gating.likelihood.params = g["lik_probs"].copy()
+
+
+def check_ilr_case(name, engine, tol=1e-9):
+    g = load_golden(name)
+    X, Y, K = g["X"], g["Y"], int(g["K"])
+    kind, ilr = build_ilr(g, engine)
+    load_ilr_state(ilr, g, kind)
+    assert rel_err(ilr.models.likelihood.log_likelihood(X, Y), g["A5_loglik"]) < tol
+    assert rel_err(ilr.likelihood.log_complete_likelihood(X, Y), g["A7_lcl"]) < tol
+    assert rel_err(ilr.likelihood.responsibilities(X, Y), g["A7_resp"]) < tol
+    assert rel_err(ilr.models.expected_log_likelihood(X, Y), g["A6_eloglik"]) < tol
+    assert rel_err(ilr.basis.expected_log_likelihood(X), g["A3_basis_eloglik"]) < tol
+    assert rel_err(ilr.expected_log_complete_likelihood(X, Y), g["A7_elcl"]) < tol
+    assert rel_err(ilr.expected_responsibilities(X, Y), g["A7_eresp"]) < tol
+    ms = ilr.models.likelihood.weighted_statistics(X, Y, g["A7_eresp"])
+    for a, b in zip(ms, (g["mstats_yxTk"], g["mstats_xxTk"], g["mstats_yyTk"], g["mstats_nk"])):
+        assert rel_err(a, b) < tol
+    bs = ilr.basis.likelihood.weighted_statistics(X, g["A7_eresp"])
+    assert rel_err(bs[2], g["bstats_xxTk"]) < tol and rel_err(bs[0], g["bstats_xk"]) < tol
+    eng = ilr._bind(X, Y)
+    c, b, W = ilr.likelihood.canonical()
+    labels, _ = eng.gibbs_labels(c, b, W, u=g["u_mt"], stats=False)
+    assert np.array_equal(labels, g["labels_mt"])
+    labels_p, _ = eng.gibbs_labels(c, b, W, seed=1337, sweep=3, stats=False)
+    assert np.array_equal(labels_p, g["labels_philox"])
+    assert abs(ilr.variational_lowerbound_data(X, Y, g["A7_eresp"]) - g["vlb_data"]) < tol * abs(g["vlb_data"])
+    assert abs(ilr.variational_lowerbound_labels(g["A7_eresp"]) - g["vlb_labels"]) < tol * abs(g["vlb_labels"])
+    assert rel_err(ilr.basis.variational_lowerbound(), g["vlb_basis"]) < tol
+    assert rel_err(ilr.models.variational_lowerbound(), g["vlb_models"]) < 1e-8
+    assert abs(ilr.variational_lowerbound(X, Y, g["A7_eresp"]) - g["vlb_total"]) < 1e-8 * abs(g["vlb_total"])
+    ilr.meanfield_update_parameters(X, Y, g["A7_eresp"])
+    for a, bb in zip(ilr.models.posterior.params, mnw_of(g, "mpost2")):
+        assert rel_err(a, bb) < 1e-7
+    for a, bb in zip(ilr.basis.posterior.params, nw_of(g, "bpost2")):
+        assert rel_err(a, bb) < 1e-7
+
+
+def check_ilr_vi_trace(name, engine, tol=1e-7):
+    g = load_golden(name)
+    kind, ilr = build_ilr(g, engine)
+    load_ilr_state(ilr, g, kind)
+    vlb = ilr.meanfield_coordinate_descent(g["X"], g["Y"], randomize=False, maxiter=len(g["vi_vlb"]), tol=0.,
+                                           progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    for a, b in zip(ilr.models.posterior.params, mnw_of(g, "vi_mpost")):
+        assert rel_err(a, b) < 1e-5

@@ -1,0 +1,91 @@
+"""TEST DOUBLE of mimo_amd.engine.HipEngine backed by the CPU oracle (oracle/mimo_oracle.py).
+
+Lives under tests/ and is injected through the `engine=` arguments of the host classes so that the
+host-side logic (canonical forms, conjugate updates, drivers, sharded all-reduce) can be tested
+without a GPU.  It is never importable from the product package.
+"""
+import numpy as np
+from scipy.special import logsumexp
+
+from oracle import mimo_oracle as O
+from mimo_amd.engine import SuffStats
+
+
+class OracleEngine:
+    device = 0
+
+    def __init__(self, device=0):
+        self.N = self.D = 0
+        self.Z = None
+        self.row0 = 0
+        self._K = None
+        self._resp = self._logp = self._lse = self._labels = None
+
+    def spawn(self):
+        return OracleEngine()
+
+    def upload(self, Z):
+        self.Z = np.ascontiguousarray(Z, dtype=float)
+        self.N, self.D = self.Z.shape
+
+    def set_row_offset(self, row0):
+        self.row0 = int(row0)
+
+    def set_stream(self, s):
+        pass
+
+    def _stats(self, R):
+        n, sx, sxx = O.packed_stats(self.Z, R)
+        return SuffStats(n, sx, sxx)
+
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False):
+        L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))
+        lse = logsumexp(L, axis=0) if self.N else np.zeros(0)
+        R = np.exp(L - lse)
+        self._K = L.shape[0]
+        if keep_resp:
+            self._resp = R
+        if keep_logp:
+            self._logp = L
+        if keep_lse:
+            self._lse = lse
+        srl = float(np.sum(R * L))
+        sc = np.array([float(np.sum(lse)), srl, float(np.sum(lse)) - srl])
+        return (self._stats(R) if stats else None), sc
+
+    def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
+        L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))
+        if u is None:
+            u = O.philox_uniforms(seed, self.row0 + np.arange(self.N), sweep)
+        labels = O.sample_discrete_from_log(L, np.asarray(u).reshape(-1))
+        self._labels, self._K = labels, L.shape[0]
+        if keep_logp:
+            self._logp = L
+        S = self._stats(O.one_hot(labels, L.shape[0])) if stats else None
+        return (labels if return_labels else None), S
+
+    def weighted_stats(self, resp=None, K=None):
+        return self._stats(self._resp if resp is None else np.asarray(resp, float))
+
+    def label_stats(self, labels, K):
+        labels = self._labels if labels is None else np.asarray(labels).astype(int)
+        if labels.size and (labels.min() < 0 or labels.max() >= K):
+            raise ValueError("labels out of range")
+        return self._stats(O.one_hot(labels, K))
+
+    def table_entropy(self, table=None):
+        t = self._resp if table is None else np.asarray(table, float)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return float(-np.nansum(t * np.log(t)))
+
+    def get_resp(self, K=None):
+        return self._resp
+
+    def get_logp(self, K=None):
+        return self._logp
+
+    def get_lse(self):
+        return self._lse
+
+    def get_labels(self):
+        return self._labels

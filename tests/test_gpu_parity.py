@@ -1,0 +1,120 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libmimo_hip.so), against the
+reference's golden vectors and against the CPU oracle on seeded inputs.  Tolerances: labels and
+counts bit-exact; float tables / statistics / ELBO 1e-9 relative (north star: 1e-6)."""
+import numpy as np
+import pytest
+
+from conftest import GMM_CASES, ILR_CASES, GIBBS_CASES, rel_err, load_golden
+import model_checks as mc
+
+pytestmark = pytest.mark.gpu
+
+GPU_GMM = [c for c in GMM_CASES if "d32" not in c]     # Dz=32 is beyond the fused kernels this round
+
+
+@pytest.mark.parametrize("name", GPU_GMM)
+def test_gmm_tables_stats_elbo(name, engine):
+    mc.check_gmm_case(name, engine)
+
+
+@pytest.mark.parametrize("name", GPU_GMM)
+def test_gmm_vi_trace(name, engine):
+    mc.check_gmm_vi_trace(name, engine)
+
+
+@pytest.mark.parametrize("name", GIBBS_CASES)
+def test_gibbs_trace(name, engine):
+    mc.check_gibbs_trace(name, engine)
+
+
+@pytest.mark.parametrize("name", ILR_CASES)
+def test_ilr_tables_stats_elbo(name, engine):
+    mc.check_ilr_case(name, engine)
+
+
+@pytest.mark.parametrize("name", ILR_CASES)
+def test_ilr_vi_trace(name, engine):
+    mc.check_ilr_vi_trace(name, engine)
+
+
+def test_unsupported_shapes_fail_loudly(engine):
+    from mimo_amd import _lib
+    with pytest.raises(_lib.MimoHipError):
+        engine.upload(np.zeros((10, 40)))
+    engine.upload(np.zeros((10, 4)))
+    with pytest.raises(_lib.MimoHipError):
+        engine.estep(np.zeros(300), np.zeros((300, 4)), np.tile(np.eye(4), (300, 1, 1)))
+    with pytest.raises(ValueError):
+        engine.label_stats(np.array([0, 5] * 5), 3)
+
+
+def _random_problem(rng, N, D, K):
+    Z = rng.standard_normal((N, D)) * 2.0 + rng.standard_normal(D)
+    A = rng.standard_normal((K, D, D))
+    W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+    mu = rng.standard_normal((K, D)) * 2
+    b = np.einsum('kde,ke->kd', W, mu)
+    c = -0.5 * np.einsum('kd,kd->k', mu, b) + rng.standard_normal(K) * 0.1
+    return Z, c, b, W
+
+
+@pytest.mark.parametrize("N,D,K", [(0, 3, 2), (1, 1, 1), (31, 16, 16), (32, 2, 4), (33, 5, 70), (4099, 8, 256),
+                                    (4099, 12, 64), (20011, 16, 64), (1000, 9, 200), (777, 13, 17)])
+def test_engine_vs_oracle_seeded(engine, N, D, K):
+    """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(1000 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0) if N else np.zeros(0)
+    R = np.exp(L - lse)
+    S, sc = engine.estep(c, b, W, keep_resp=True, keep_logp=True, keep_lse=True)
+    n, sx, sxx = O.packed_stats(Z, R)
+    assert rel_err(engine.get_logp(), L) < 1e-12 and rel_err(engine.get_lse(), lse) < 1e-12
+    assert rel_err(engine.get_resp(), R) < 1e-11
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    if N:
+        assert abs(sc[0] - lse.sum()) < 1e-12 * abs(lse.sum())
+        assert abs(sc[2] + np.nansum(R * np.log(np.where(R > 0, R, 1)))) < 1e-9 * max(1.0, abs(sc[2]))
+        assert abs(engine.table_entropy() - sc[2]) < 1e-9 * max(1.0, abs(sc[2]))
+    Wt = rng.random((K, N))
+    S2 = engine.weighted_stats(Wt)
+    n2, sx2, sxx2 = O.packed_stats(Z, Wt)
+    assert rel_err(S2.n, n2) < 1e-11 and rel_err(S2.sxx, sxx2) < 1e-11
+    u = rng.random(N)
+    lab, S3 = engine.gibbs_labels(c, b, W, u=u)
+    ref = O.sample_discrete_from_log(L, u) if N else np.zeros(0, np.int32)
+    assert np.array_equal(lab, ref)
+    assert np.array_equal(S3.n, np.bincount(ref, minlength=K))
+    lab_p, _ = engine.gibbs_labels(c, b, W, seed=99, sweep=7, stats=False)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(99, np.arange(N), 7)) if N else ref
+    assert np.array_equal(lab_p, ref_p)
+    assert np.array_equal(engine.get_labels(), ref_p)
+
+
+def test_full_size_properties(engine):
+    """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
+    (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the
+    statistics of the two halves add up to the statistics of the whole; (iii) run-to-run bit
+    reproducibility; (iv) Philox labels of a row block do not depend on where the block starts."""
+    N, D, K = 10_000_000, 16, 64
+    rng = np.random.default_rng(7)
+    Z, c, b, W = _random_problem(rng, 4096, D, K)
+    Z = np.ascontiguousarray(np.tile(Z, (N // 4096 + 1, 1))[:N] + 1e-3 * np.arange(N)[:, None] / N)
+    engine.upload(Z)
+    S, sc = engine.estep(c, b, W)
+    assert abs(S.n.sum() - N) < 1e-9 * N
+    S_again, sc_again = engine.estep(c, b, W)
+    assert np.array_equal(S.sxx, S_again.sxx) and sc[0] == sc_again[0]
+    lab_full, Sg = engine.gibbs_labels(c, b, W, seed=5, sweep=1)
+    assert Sg.n.sum() == N and np.array_equal(Sg.n, np.bincount(lab_full, minlength=K))
+    half = N // 2
+    engine.upload(Z[:half]); Sa, sca = engine.estep(c, b, W)
+    engine.upload(Z[half:]); engine.set_row_offset(half); Sb, scb = engine.estep(c, b, W)
+    lab_b, _ = engine.gibbs_labels(c, b, W, seed=5, sweep=1, stats=False)
+    engine.set_row_offset(0)
+    assert rel_err(Sa.sxx + Sb.sxx, S.sxx) < 1e-12 and rel_err(Sa.n + Sb.n, S.n) < 1e-12
+    assert abs((sca[0] + scb[0]) - sc[0]) < 1e-12 * abs(sc[0])
+    assert np.array_equal(lab_b, lab_full[half:])
