@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py — E-step datapoint-component evaluations per second (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (default c2 = BASELINE.json configs[1]): mean-field VB of a full-covariance GMM, N = 1e7 rows
+PER GPU (weak scaling), D = 16, K = 64, synthetic float64 data already resident in HBM.  One timed
+"step" is one complete VI iteration: the fused HIP pass over the data (log-densities -> softmax ->
+sufficient statistics -> ELBO terms; the (K,N) responsibilities never leave the GPU), the RCCL
+all-reduce of the statistic block when N > 1, the host conjugate update of all K posteriors and the
+ELBO.  value = (rows on all ranks x K) / max-over-ranks step time.
+
+The JSON line also carries
+  roofline     : the fused kernel against the float64 matrix-core peak (HIP events around every launch
+                 on the launch stream, averaged over the timed steps; algorithmic flops of SURVEY.md §8(d))
+  cpu_baseline : the NumPy restatement of the reference algorithm (oracle/, verified equal to the
+                 reference on golden vectors) timed on this box's host cores on a bounded row sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, vendor; tools/f64_rates measures 78.0
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+CONFIGS = {
+    # name: (description, N per GPU, D (Dz), K, mode)
+    "c2": ("C2: mean-field VB GMM, N=1e7 per GPU, D=16, K=64, full covariance", 10_000_000, 16, 64, "vi"),
+    "c3": ("C3: DP-GMM truncated stick-breaking Kmax=256, N=1e7 per GPU, D=8, Gibbs (Philox labels)",
+           10_000_000, 8, 256, "gibbs"),
+    "c4": ("C4: mixture of linear-Gaussian experts, N=5e6 per GPU, x in R^8 -> y in R^4, K=64, mean-field VB",
+           5_000_000, 12, 64, "ilr"),
+}
+
+
+def algorithmic_flops_per_eval(D, mode):
+    """F_E = D(D+1) + 3D + 8 (E-step), F_S = (D+1)(D+2) + 1 (statistics, per
+    (datum, component) for VI; once per datum for Gibbs)."""
+    FE = D * (D + 1) + 3 * D + 8
+    FS = (D + 1) * (D + 2) + 1
+    return FE, FS
+
+
+def make_data(N, D, K, seed, device, ilr=False):
+    """Synthetic mixture data generated on the GPU: K_true = min(K, 32) centres
+    ~ N(0, 6^2 I), per-centre covariance A A'/D + 0.1 I, rows assigned uniformly."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    Kt = min(K, 32)
+    hg = np.random.Generator(np.random.Philox(1337))          # identical centres on every rank
+    dx = 8 if ilr else D
+    centres = torch.tensor(hg.normal(0.0, 6.0, size=(Kt, dx)), device=device)
+    A = hg.normal(size=(Kt, dx, dx))
+    cov = A @ A.transpose(0, 2, 1) / dx + 0.1 * np.eye(dx)
+    L = torch.tensor(np.linalg.cholesky(cov), device=device)
+    z = torch.randint(Kt, (N,), generator=g, device=device)
+    X = torch.empty((N, D), dtype=torch.float64, device=device)
+    chunk = 1_000_000
+    if ilr:
+        Ak = torch.tensor(hg.normal(size=(Kt, 4, dx)) / np.sqrt(dx), device=device)
+        ck = torch.tensor(hg.normal(size=(Kt, 4)), device=device)
+    for s in range(0, N, chunk):
+        zz = z[s:s + chunk]
+        eps = torch.randn((zz.numel(), dx), dtype=torch.float64, generator=g, device=device)
+        x = centres[zz] + torch.einsum('nde,ne->nd', L[zz], eps)
+        X[s:s + chunk, :dx] = x
+        if ilr:
+            y = torch.einsum('nde,ne->nd', Ak[zz], x) + ck[zz] \
+                + 0.3 * torch.randn((zz.numel(), 4), dtype=torch.float64, generator=g, device=device)
+            X[s:s + chunk, dx:] = y
+    return X
+
+
+def build_model(cfg, engine):
+    from mimo_amd.distributions import (Dirichlet, TruncatedStickBreaking, CategoricalWithDirichlet,
+                                        CategoricalWithStickBreaking, StackedNormalWisharts,
+                                        StackedGaussiansWithNormalWisharts, StackedMatrixNormalWisharts,
+                                        StackedLinearGaussiansWithMatrixNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfGaussians, BayesianMixtureOfLinearGaussians
+    _, _, D, K, mode = cfg
+    np.random.seed(1337)      # identical host state on every rank
+    if mode == "gibbs":
+        gating = CategoricalWithStickBreaking(K, TruncatedStickBreaking(K, np.ones(K), 5. * np.ones(K)))
+    else:
+        gating = CategoricalWithDirichlet(K, Dirichlet(K, np.ones(K)))
+    if mode == "ilr":
+        dx, dy = 8, 4
+        bprior = StackedNormalWisharts(K, dx, np.zeros((K, dx)), 1e-2 * np.ones(K),
+                                       np.stack(K * [1e2 * np.eye(dx)]), (dx + 1.) * np.ones(K) + 1e-16)
+        basis = StackedGaussiansWithNormalWisharts(K, dx, bprior, engine=engine)
+        mprior = StackedMatrixNormalWisharts(K, dx + 1, dy, np.zeros((K, dy, dx + 1)),
+                                             np.stack(K * [1e-2 * np.eye(dx + 1)]),
+                                             np.stack(K * [np.eye(dy)]), (dy + 1.) * np.ones(K) + 1e-16)
+        models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dx + 1, dy, mprior, engine=engine)
+        return BayesianMixtureOfLinearGaussians(K, dx, dy, gating, basis, models, engine=engine)
+    prior = StackedNormalWisharts(K, D, np.zeros((K, D)), 1e-2 * np.ones(K), np.stack(K * [np.eye(D)]),
+                                  (D + 1.) * np.ones(K) + 1e-8)
+    comps = StackedGaussiansWithNormalWisharts(K, D, prior, engine=engine)
+    return BayesianMixtureOfGaussians(gating, comps, engine=engine)
+
+
+def cpu_baseline(cfg, X_host):
+    """The reference algorithm's VI sweep (E-step table in 1024-row chunks as the reference's
+    (K,N,D,D) replication forces, softmax, weighted statistics) timed on the host cores."""
+    from oracle import mimo_oracle as O
+    _, _, D, K, mode = cfg
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((K, D, D))
+    post = (rng.standard_normal((K, D)) * 3, np.full(K, 100.0), np.linalg.inv(A @ A.transpose(0, 2, 1) / D + np.eye(D)) / 50.,
+            np.full(K, 60.0))
+    gpost = np.full(K, 50.0)
+
+    def sweep(x):
+        ll = O.gmm_expected_log_complete_likelihood(x, post, 'dirichlet', gpost, chunk=1024)
+        r = O.responsibilities(ll)
+        return O.gauss_weighted_statistics(x, r)
+    t0 = time.time(); sweep(X_host[:1024]); dt = time.time() - t0
+    rows = int(min(len(X_host), max(2048, 1024 * round(12.0 / max(dt, 1e-3)))))
+    t0 = time.time(); sweep(X_host[:rows]); dt = time.time() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = blas[0]["num_threads"]
+    except Exception:
+        pass
+    return {"value": rows * K / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {rows} rows of the same synthetic data, one VI sweep of the NumPy restatement of the "
+                      f"reference (E-step in 1024-row chunks + softmax + weighted_statistics), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0, help="override rows per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    from mimo_amd.engine import HipEngine
+    from mimo_amd.sharded import ShardedEngine
+
+    cfg = CONFIGS[args.config]
+    desc, N, D, K, mode = cfg
+    if args.rows:
+        N = args.rows
+    X = make_data(N, D, K, seed=1337 + rank, device=device, ilr=(mode == "ilr"))
+    torch.cuda.synchronize()
+
+    hip = HipEngine(local_rank)
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.upload(X)                                  # borrows the device tensor (no copy)
+    engine = ShardedEngine(hip, row_offset=rank * N) if world > 1 else hip
+    if world > 1:
+        hip.set_row_offset(rank * N)
+    model = build_model(cfg, engine)
+
+    # initial posterior: one M-step from seeded random hard labels
+    labels0 = np.random.default_rng(4242 + rank).integers(0, K, size=N).astype(np.int32)
+    S = engine.label_stats(labels0, K)
+
+    def step(S, it):
+        if mode == "gibbs":
+            bs = S
+            model.components.resample(None, stats=_comp_stats(bs))
+            model.gating.resample(None, counts=bs.n)
+            _, S2 = engine.gibbs_labels(*model.likelihood.canonical(), seed=2024, sweep=it, stats=True,
+                                        return_labels=False)
+            return S2, None
+        model._update_from_stats(S, sample=False)
+        S2, sc = engine.estep(*model.canonical_expected())
+        return S2, model._vlb_prior_terms() + sc[0]
+
+    from mimo_amd.mixtures.gmm import _component_stats as _comp_stats
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    vlb = []
+    for it in range(args.warmup):
+        S, v = step(S, it)
+    hip.profile(True)
+    hip.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        S, v = step(S, args.warmup + it)
+        vlb.append(v)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = hip.profile_read(reset=True)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * N * K / (elapsed / args.steps)
+        FE, FS = algorithmic_flops_per_eval(D, mode)
+        flops_per_launch = N * K * FE + (N * K * FS if mode != "gibbs" else N * FS)
+        k_ms = kernel_ms / max(launches, 1)
+        achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
+        hbm_bytes = 8.0 * N * D + (4.0 * N if mode == "gibbs" else 0.0)
+        out = {
+            "metric": "E-step datapoint-component evals/sec",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": N, "Dz": D, "K": K,
+                       "step": "fused HIP pass (log-densities, softmax/label draw, sufficient statistics, ELBO terms)"
+                               + (", RCCL all-reduce of the statistic block" if world > 1 else "")
+                               + ", host conjugate update of all K posteriors",
+                       "resp_materialised_in_hbm": False, "parallelism": f"rows sharded over {world} GPU(s)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "mimo::fused_kernel", "kernel_ms": k_ms, "launches": launches,
+                         "flops_per_eval": {"estep": FE, "stats": FS},
+                         "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
+                                 "achieved_GBs": hbm_bytes / (k_ms * 1e-3) / 1e9,
+                                 "frac_of_8TBs": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "kernel_evals_per_s": N * K / (k_ms * 1e-3),
+        }
+        if vlb and vlb[0] is not None:
+            out["elbo_first_last"] = [float(vlb[0]), float(vlb[-1])]
+        if world == 1 and not args.no_cpu_baseline and mode == "vi":
+            out["cpu_baseline"] = cpu_baseline(cfg, X[:200_000].cpu().numpy())
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
