@@ -22,7 +22,9 @@
  *     i.e. K × (1 + Dz + Dz²) doubles  (mimo/distributions/gaussian.py:491-502,
  *     mimo/distributions/lingauss.py:306-322: yxT/xxT/yyT/n_k are blocks of this for z=[x,y]).
  *   - scalars[3] = { sum_n logsumexp_k l[k,n] , sum_n sum_k r_kn l[k,n] , −sum_n sum_k r_kn log r_kn }
- *     (mimo/mixtures/gmm.py:338-356).
+ *     (mimo/mixtures/gmm.py:338-356).  scalars[0] alone gives the data + label ELBO terms; the split
+ *     into scalars[1], scalars[2] costs extra float64 work per (datum, component) and is only
+ *     computed with MIMO_F_ENTROPY_SPLIT or any MIMO_F_KEEP_* flag (otherwise both are NaN).
  *   - every function returns 0 on success or a negative MIMO_E_* code; the message is
  *     available from mimo_last_error().  No C++ exception crosses this boundary.
  *   - pointers are HOST pointers unless MIMO_F_DEVICE_OUT is set in `flags`, in which case the
@@ -57,6 +59,7 @@ typedef struct mimo_ctx mimo_ctx;
 #define MIMO_F_NO_STATS       0x08  /* skip the sufficient-statistics accumulation                 */
 #define MIMO_F_DEVICE_OUT     0x10  /* S / scalars are device pointers; asynchronous               */
 #define MIMO_F_DEVICE_IN      0x20  /* `resp` / `labels` / `u` inputs are device pointers          */
+#define MIMO_F_ENTROPY_SPLIT  0x40  /* also produce scalars[1], scalars[2] (see above)             */
 
 /* ---- lifetime -------------------------------------------------------------------------- */
 

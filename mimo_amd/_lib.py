@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
 # error codes / flags (mirror include/mimo_hip.h)
 OK = 0
 E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
-F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN = 1, 2, 4, 8, 0x10, 0x20
+F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN, F_ENTROPY_SPLIT = 1, 2, 4, 8, 0x10, 0x20, 0x40
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

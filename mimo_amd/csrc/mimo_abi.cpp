@@ -62,6 +62,18 @@ struct mimo_ctx {
 };
 
 static std::string g_err;
+#ifdef MIMO_STAMPS
+static unsigned long long* g_stamps = nullptr;
+static int g_stamps_grid = 0;
+extern "C" int mimo_debug_stamps(double* out8) {   // mean cycles per wave of each phase, last launch
+  std::vector<unsigned long long> h((size_t)g_stamps_grid * 32);
+  if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  for (size_t w = 0; w < h.size() / 8; ++w) for (int i = 0; i < 8; ++i) out8[i] += (double)h[w * 8 + i];
+  for (int i = 0; i < 8; ++i) out8[i] /= (double)(h.size() / 8);
+  return 0;
+}
+#endif
 
 static int fail(mimo_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -146,7 +158,8 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
 // (c, b, W) -> Theta[k][f] -> MFMA A-operand image [K16][F16/4][64] on the device.
 //   f = (D,D): c_k ; (a,D): b_k[a] ; (a,a): -W_aa/2 ; (a,b), a<b: -(W_ab + W_ba)/2
 static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, F16 = ctx->F16, K16 = (K + 15) / 16, NS = F16 / 4;
+  const int D = ctx->D, F16 = ctx->F16, NS = F16 / 4;
+  const int K16 = ((K + 15) / 16 <= 4) ? 4 : 16;   // every wave streams 1 (K<=64) or 4 row blocks; unused ones are zero
   const size_t count = (size_t)K16 * NS * 64;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
@@ -200,6 +213,14 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   if ((rc = ensure_dev(ctx, &ctx->reduced, &ctx->reduced_cap, pstride))) return rc;
   a.partials = ctx->partials;
 
+#ifdef MIMO_STAMPS
+  {
+    static unsigned long long* stamps_d = nullptr;
+    if (!stamps_d) (void)hipMalloc(reinterpret_cast<void**>(&stamps_d), 8192 * 4 * 8 * sizeof(unsigned long long));
+    a.stamps = stamps_d;
+    g_stamps = stamps_d; g_stamps_grid = grid;
+  }
+#endif
   bool unsupported = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
@@ -359,6 +380,7 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   KernelArgs a;
   fill_args(ctx, K, &a);
   a.do_stats = no_stats ? 0 : 1;
+  a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;

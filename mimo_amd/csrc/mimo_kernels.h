@@ -13,6 +13,9 @@ constexpr int kMaxD = 16;       // largest Dz the fused kernels cover (F = 153 f
 
 // Where the per-tile weight table R (rows x K) comes from.
 enum Source : int { kSrcEstep = 0, kSrcWeights = 1, kSrcLabels = 2 };
+// Compile-time specialisations of the fused kernel: the two hot modes carry no optional-output or
+// other-mode code (register pressure decides occupancy here); kGeneric keeps every runtime flag.
+enum Mode : int { kFastVI = 0, kFastGibbs = 1, kGeneric = 2, kModeWeights = 3, kModeLabels = 4 };
 
 struct KernelArgs {
   const double* Z;        // (N, D) row-major observations
@@ -34,7 +37,9 @@ struct KernelArgs {
   int64_t row0;
   int gibbs;              // 0: softmax responsibilities, 1: categorical draw (one-hot weights)
   int do_stats;
+  int split;              // also accumulate sum_k r l (entropy split of the ELBO scalars)
   int64_t ntiles;
+  unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
 };
 
 // feature count helpers (z~ = [z,1]; features = upper-triangular pairs of z~)

@@ -115,11 +115,13 @@ class HipEngine:
             raise ValueError(f"parameter shapes {c.shape}, {b.shape}, {W.shape} do not match K={K}, Dz={self.D}")
         return c, b, W, K
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False):
-        """Fused E-step.  Returns (SuffStats | None, scalars[3])."""
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
+        """Fused E-step.  Returns (SuffStats | None, scalars[3]); scalars[1:] are NaN unless
+        entropy_split (or a keep_* flag) is set."""
         c, b, W, K = self._params(c, b, W)
         flags = ((_lib.F_KEEP_RESP if keep_resp else 0) | (_lib.F_KEEP_LOGP if keep_logp else 0)
-                 | (_lib.F_KEEP_LSE if keep_lse else 0) | (0 if stats else _lib.F_NO_STATS))
+                 | (_lib.F_KEEP_LSE if keep_lse else 0) | (0 if stats else _lib.F_NO_STATS)
+                 | (_lib.F_ENTROPY_SPLIT if entropy_split else 0))
         S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
         sc = np.empty(3)
         self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, flags,

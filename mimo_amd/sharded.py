@@ -85,8 +85,8 @@ class ShardedEngine:
             self._host = torch.empty(n, dtype=torch.float64).pin_memory()
         return self._buf, n - 4
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False):
-        if self._device_path and stats and not (keep_resp or keep_logp or keep_lse):
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
+        if self._device_path and stats and not (keep_resp or keep_logp or keep_lse or entropy_split):
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)
             self.inner.estep_device(c, b, W, buf.data_ptr(), buf.data_ptr() + 8 * slen)
@@ -94,7 +94,8 @@ class ShardedEngine:
             self._host.copy_(buf, non_blocking=False)
             out = self._host.numpy()
             return SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
-        S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse)
+        S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
+                                 entropy_split=entropy_split)
         if not stats:
             t = self._allreduce_scalars(sc)
             return None, t

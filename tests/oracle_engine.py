@@ -38,7 +38,7 @@ class OracleEngine:
         n, sx, sxx = O.packed_stats(self.Z, R)
         return SuffStats(n, sx, sxx)
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False):
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
         L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))
         lse = logsumexp(L, axis=0) if self.N else np.zeros(0)
         R = np.exp(L - lse)
