@@ -193,8 +193,14 @@ def main():
                                         return_labels=False)
             return S2, None
         model._update_from_stats(S, sample=False)
-        S2, sc = engine.estep(*model.canonical_expected())
-        return S2, model._vlb_prior_terms() + sc[0]
+        if hasattr(engine, "estep_async"):       # same overlap as meanfield_coordinate_descent
+            engine.estep_async(*model.canonical_expected())
+            prior_terms = model._vlb_prior_terms()
+            S2, sc = engine.estep_wait()
+        else:
+            S2, sc = engine.estep(*model.canonical_expected())
+            prior_terms = model._vlb_prior_terms()
+        return S2, prior_terms + sc[0]
 
     from mimo_amd.mixtures.gmm import _component_stats as _comp_stats
 

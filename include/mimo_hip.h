@@ -60,6 +60,7 @@ typedef struct mimo_ctx mimo_ctx;
 #define MIMO_F_DEVICE_OUT     0x10  /* S / scalars are device pointers; asynchronous               */
 #define MIMO_F_DEVICE_IN      0x20  /* `resp` / `labels` / `u` inputs are device pointers          */
 #define MIMO_F_ENTROPY_SPLIT  0x40  /* also produce scalars[1], scalars[2] (see above)             */
+#define MIMO_F_ASYNC          0x80  /* enqueue only; fetch the host results with mimo_wait()       */
 
 /* ---- lifetime -------------------------------------------------------------------------- */
 
@@ -103,6 +104,11 @@ int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0);
  * c (K), b (K,Dz), W (K,Dz,Dz).  S: K×(1+Dz+Dz²) or NULL with MIMO_F_NO_STATS; scalars: 3 or NULL. */
 int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                int flags, double* S, double* scalars);
+
+/* Completes a call issued with MIMO_F_ASYNC: waits for the context's stream and copies the packed
+ * statistics / scalars of that call to the host pointers (either may be NULL).  Lets the host overlap
+ * its own O(K D^3) work (the ELBO's prior terms, gmm.py:360-361) with the pass over the data. */
+int mimo_wait(mimo_ctx* ctx, double* S, double* scalars);
 
 /* Fused Gibbs label step: log-densities, categorical draw per datum by inverse CDF, and the
  * sufficient statistics of the labels just drawn (what the next sweep's resample_components /

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
 # error codes / flags (mirror include/mimo_hip.h)
 OK = 0
 E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
-F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN, F_ENTROPY_SPLIT = 1, 2, 4, 8, 0x10, 0x20, 0x40
+F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN, F_ENTROPY_SPLIT, F_ASYNC = 1, 2, 4, 8, 0x10, 0x20, 0x40, 0x80
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -29,6 +29,7 @@ SIGNATURES = {
     "mimo_attach": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mimo_set_row_offset": (C.c_int, [_vp, C.c_int64]),
     "mimo_estep": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "mimo_wait": (C.c_int, [_vp, _vp, _vp]),
     "mimo_gibbs_labels": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _vp,
                                     C.c_int, _vp, _vp]),
     "mimo_weighted_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),

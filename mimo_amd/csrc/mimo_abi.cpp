@@ -53,6 +53,11 @@ struct mimo_ctx {
   double* win = nullptr;   size_t win_cap = 0;    // staged host weights
   int32_t* lin = nullptr;  size_t lin_cap = 0;    // staged host labels
 
+  // pending asynchronous call (MIMO_F_ASYNC)
+  bool pending_async = false;
+  size_t pending_slen = 0;
+  bool pending_stats = false;
+
   // profiling of the fused kernel
   bool prof = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -136,6 +141,7 @@ static int prepare_features(mimo_ctx* ctx, int D) {
 }
 
 static int check_shapes(mimo_ctx* ctx, int K) {
+  if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
   if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "no data uploaded or attached");
   if (K < 1) return fail(ctx, MIMO_E_INVALID, "K must be >= 1 (got %d)", K);
   if (K > 256) return fail(ctx, MIMO_E_UNSUPPORTED, "K = %d > 256 is not covered by the fused kernels", K);
@@ -240,9 +246,10 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     ctx->pending.emplace_back(e0, e1);
   }
-  const bool want_stats = a.do_stats && S;
+  const bool async = (flags & MIMO_F_ASYNC) != 0;
+  const bool want_stats = a.do_stats && (S || async);
   const bool device_out = (flags & MIMO_F_DEVICE_OUT) != 0;
-  if (!want_stats && !scalars) return MIMO_OK;
+  if (!want_stats && !scalars && !async) return MIMO_OK;
 
   HIP_TRY(ctx, launch_reduce(ctx->partials, grid, (int64_t)pstride, ctx->reduced, ctx->stream));
   const size_t slen = (size_t)K * (1 + D + (size_t)D * D);
@@ -255,6 +262,10 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, a.F16, want_stats ? ctx->S_d : nullptr,
                              ctx->S_d + slen, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (flags & MIMO_F_ASYNC) {
+    ctx->pending_async = true; ctx->pending_slen = slen; ctx->pending_stats = want_stats;
+    return MIMO_OK;
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (want_stats) memcpy(S, ctx->S_h, slen * sizeof(double));
   if (scalars) memcpy(scalars, ctx->S_h + slen, 3 * sizeof(double));
@@ -376,7 +387,8 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!c || !b || !W) return fail(ctx, MIMO_E_INVALID, "mimo_estep: c, b, W must be non-NULL");
   const bool no_stats = (flags & MIMO_F_NO_STATS) != 0;
-  if (!no_stats && !S) return fail(ctx, MIMO_E_INVALID, "mimo_estep: S is NULL without MIMO_F_NO_STATS");
+  if (!no_stats && !S && !(flags & MIMO_F_ASYNC))
+    return fail(ctx, MIMO_E_INVALID, "mimo_estep: S is NULL without MIMO_F_NO_STATS / MIMO_F_ASYNC");
   KernelArgs a;
   fill_args(ctx, K, &a);
   a.do_stats = no_stats ? 0 : 1;
@@ -385,6 +397,19 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   return run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
+}
+
+int mimo_wait(mimo_ctx* ctx, double* S, double* scalars) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!ctx->pending_async) return fail(ctx, MIMO_E_STATE, "mimo_wait: no asynchronous call is pending");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pending_async = false;
+  if (S) {
+    if (!ctx->pending_stats) return fail(ctx, MIMO_E_STATE, "mimo_wait: the pending call produced no statistics");
+    memcpy(S, ctx->S_h, ctx->pending_slen * sizeof(double));
+  }
+  if (scalars) memcpy(scalars, ctx->S_h + ctx->pending_slen, 3 * sizeof(double));
+  return MIMO_OK;
 }
 
 int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,

@@ -12,7 +12,8 @@ import numpy.random as npr
 import scipy.linalg as sla
 
 from mimo_amd.utils.abstraction import Statistics as Stats
-from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs)
+from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs,
+                                            sum_log_diag_chol)
 
 
 def _outer(a, b):
@@ -30,6 +31,7 @@ class StackedNormalWisharts:
         self.kappas = None if kappas is None else np.array(kappas, dtype=float)
         self.psis = None if psis is None else np.array(psis, dtype=float)
         self.nus = None if nus is None else np.array(nus, dtype=float)
+        self._memo = {}
 
     @property
     def params(self):
@@ -39,13 +41,27 @@ class StackedNormalWisharts:
     def params(self, values):
         self.mus, self.kappas, self.psis, self.nus = (np.asarray(v, dtype=float) for v in values)
 
+    def _cached(self, name, fn):
+        """Derived quantities (natural parameters, expectations, log-partition) are recomputed only
+        when a parameter ARRAY is replaced; in-place edits of a parameter array are not tracked."""
+        key = tuple(id(p) for p in self.params)
+        memo = self.__dict__.setdefault('_memo', {})
+        if memo.get('key') != key:
+            memo.clear()
+            memo['key'] = key
+            memo['refs'] = self.params        # keep the arrays alive so ids cannot be recycled
+        if name not in memo:
+            memo[name] = fn()
+        return memo[name]
+
     @property
     def nat_param(self):
-        return self.std_to_nat(self.params)
+        return self._cached('nat', lambda: self.std_to_nat(self.params))
 
     @nat_param.setter
     def nat_param(self, natparam):
         self.params = self.nat_to_std(natparam)
+        self._cached('nat', lambda: Stats(natparam))   # the exact natural parameters just assigned
 
     def std_to_nat(self, params):
         """eta = [kappa m, kappa, psi^-1 + kappa m m', nu - D]  (composite.py:50-65)."""
@@ -86,16 +102,24 @@ class StackedNormalWisharts:
     def log_base(self):
         return np.log(self.base)
 
+    def _half_logdet_psi(self):
+        return self._cached('hld', lambda: sum_log_diag_chol(self.psis))
+
     def log_partition(self):
         """composite.py:95-98."""
-        return - 0.5 * self.dim * np.log(self.kappas) + wishart_log_partition(self.psis, self.nus)
+        return self._cached('logZ', lambda: - 0.5 * self.dim * np.log(self.kappas)
+                            + wishart_log_partition(self.psis, self.nus, self._half_logdet_psi()))
 
     def expected_statistics(self):
         """E[Lambda mu], E[-1/2 mu'Lambda mu], E[-1/2 Lambda], E[1/2 logdet Lambda] (composite.py:106-118)."""
+        return self._cached('estats', self._expected_statistics)
+
+    def _expected_statistics(self):
         nupsi = self.nus[:, None, None] * self.psis
         E_lmbda_mu = np.einsum('kdl,kl->kd', nupsi, self.mus)
         E_muT_lmbda_mu = - 0.5 * (self.dim / self.kappas + np.einsum('kd,kd->k', self.mus, E_lmbda_mu))
-        return E_lmbda_mu, E_muT_lmbda_mu, - 0.5 * nupsi, 0.5 * wishart_expected_logdet(self.psis, self.nus)
+        return (E_lmbda_mu, E_muT_lmbda_mu, - 0.5 * nupsi,
+                0.5 * wishart_expected_logdet(self.psis, self.nus, self._half_logdet_psi()))
 
     def canonical_expected(self):
         """(c, b, W) of <E_q[eta_k], t(x)> + log_base  (bayesian.py:287-301): the VI E-step form."""
@@ -139,6 +163,7 @@ class StackedMatrixNormalWisharts:
         self.Ks = None if Ks is None else np.array(Ks, dtype=float)
         self.psis = None if psis is None else np.array(psis, dtype=float)
         self.nus = None if nus is None else np.array(nus, dtype=float)
+        self._memo = {}
 
     @property
     def params(self):
@@ -148,13 +173,16 @@ class StackedMatrixNormalWisharts:
     def params(self, values):
         self.Ms, self.Ks, self.psis, self.nus = (np.asarray(v, dtype=float) for v in values)
 
+    _cached = StackedNormalWisharts._cached
+
     @property
     def nat_param(self):
-        return self.std_to_nat(self.params)
+        return self._cached('nat', lambda: self.std_to_nat(self.params))
 
     @nat_param.setter
     def nat_param(self, natparam):
         self.params = self.nat_to_std(natparam)
+        self._cached('nat', lambda: Stats(natparam))
 
     def std_to_nat(self, params):
         """eta = [M K, K, psi^-1 + M K M', nu - d - 1 + l]  (composite.py:577-592)."""
@@ -196,16 +224,24 @@ class StackedMatrixNormalWisharts:
     def log_base(self):
         return np.log(self.base)
 
+    def _half_logdet_psi(self):
+        return self._cached('hld', lambda: sum_log_diag_chol(self.psis))
+
     def log_partition(self):
         """composite.py:622-625."""
-        return - 0.5 * self.row_dim * np.linalg.slogdet(self.Ks)[1] + wishart_log_partition(self.psis, self.nus)
+        return self._cached('logZ', lambda: - 0.5 * self.row_dim * np.linalg.slogdet(self.Ks)[1]
+                            + wishart_log_partition(self.psis, self.nus, self._half_logdet_psi()))
 
     def expected_statistics(self):
         """E[Lambda A], E[-1/2 A'Lambda A], E[-1/2 Lambda], E[1/2 logdet Lambda] (composite.py:635-647)."""
+        return self._cached('estats', self._expected_statistics)
+
+    def _expected_statistics(self):
         nupsi = self.nus[:, None, None] * self.psis
         E_Lmbda_A = nupsi @ self.Ms
         E_AT_Lmbda_A = - 0.5 * (self.row_dim * np.linalg.inv(self.Ks) + np.swapaxes(self.Ms, 1, 2) @ E_Lmbda_A)
-        return E_Lmbda_A, E_AT_Lmbda_A, - 0.5 * nupsi, 0.5 * wishart_expected_logdet(self.psis, self.nus)
+        return (E_Lmbda_A, E_AT_Lmbda_A, - 0.5 * nupsi,
+                0.5 * wishart_expected_logdet(self.psis, self.nus, self._half_logdet_psi()))
 
     def canonical_expected(self, affine=True):
         """(c, b, W) over z = [x, y] of the expected log-density of y | x (bayesian.py:933-947):

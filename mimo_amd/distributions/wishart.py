@@ -13,18 +13,20 @@ def sum_log_diag_chol(mats):
     return np.sum(np.log(np.diagonal(chol, axis1=-2, axis2=-1)), axis=-1)
 
 
-def wishart_log_partition(psis, nus):
-    """wishart.py:129-132, vectorised over a stack: nu D/2 log 2 + ln Gamma_D(nu/2) + nu sum log diag chol psi."""
+def wishart_log_partition(psis, nus, half_logdet=None):
+    """wishart.py:129-132, vectorised over a stack: nu D/2 log 2 + ln Gamma_D(nu/2) + nu sum log diag chol psi.
+    `half_logdet` = sum log diag chol psi if the caller already has it."""
     D = psis.shape[-1]
-    return 0.5 * nus * D * np.log(2) + multigammaln(nus / 2., D) + nus * sum_log_diag_chol(psis)
+    hld = sum_log_diag_chol(psis) if half_logdet is None else half_logdet
+    return 0.5 * nus * D * np.log(2) + multigammaln(nus / 2., D) + nus * hld
 
 
-def wishart_expected_logdet(psis, nus):
+def wishart_expected_logdet(psis, nus, half_logdet=None):
     """wishart.py:139-143: E[logdet X] = sum_i psi((nu - i)/2) + D log 2 + 2 sum log diag chol psi."""
     D = psis.shape[-1]
     i = np.arange(D)
-    return np.sum(digamma((np.asarray(nus)[..., None] - i) / 2.), axis=-1) + D * np.log(2.)\
-        + 2. * sum_log_diag_chol(psis)
+    hld = sum_log_diag_chol(psis) if half_logdet is None else half_logdet
+    return np.sum(digamma((np.asarray(nus)[..., None] - i) / 2.), axis=-1) + D * np.log(2.) + 2. * hld
 
 
 def wishart_rvs(psi, nu):

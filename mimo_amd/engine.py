@@ -129,6 +129,21 @@ class HipEngine:
         self._K = K
         return (SuffStats.from_packed(S, K, self.D) if stats else None), sc
 
+    def estep_async(self, c, b, W):
+        """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
+        The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs."""
+        c, b, W, K = self._params(c, b, W)
+        self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
+        self._K = K
+        self._async_K = K
+
+    def estep_wait(self):
+        K = self._async_K
+        S = np.empty((K, 1 + self.D + self.D * self.D))
+        sc = np.empty(3)
+        self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
+        return SuffStats.from_packed(S, K, self.D), sc
+
     def estep_device(self, c, b, W, S_dev_ptr, scalars_dev_ptr):
         """Asynchronous fused E-step writing packed S / scalars to device pointers."""
         c, b, W, K = self._params(c, b, W)

@@ -266,8 +266,14 @@ class BayesianMixtureOfLinearGaussians:
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
                 self._update_from_stats(S, sample_likelihood)
-                S, sc = eng.estep(*self.canonical_expected())
-                vlb.append(self._vlb_prior_terms() + sc[0])
+                if hasattr(eng, "estep_async"):      # ELBO prior terms computed while the data pass runs
+                    eng.estep_async(*self.canonical_expected())
+                    prior_terms = self._vlb_prior_terms()
+                    S, sc = eng.estep_wait()
+                else:
+                    S, sc = eng.estep(*self.canonical_expected())
+                    prior_terms = self._vlb_prior_terms()
+                vlb.append(prior_terms + sc[0])
                 if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
                     return vlb
                 pbar.update(1)
