@@ -184,10 +184,12 @@ def main():
     labels0 = np.random.default_rng(4242 + rank).integers(0, K, size=N).astype(np.int32)
     S = engine.label_stats(labels0, K)
 
+    param_rng = np.random.Generator(np.random.Philox(99))     # identical on every rank
+
     def step(S, it):
         if mode == "gibbs":
             bs = S
-            model.components.resample(None, stats=_comp_stats(bs))
+            model.components.resample(None, stats=_comp_stats(bs), rng=param_rng)
             model.gating.resample(None, counts=bs.n)
             _, S2 = engine.gibbs_labels(*model.likelihood.canonical(), seed=2024, sweep=it, stats=True,
                                         return_labels=False)

@@ -153,7 +153,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->Z = ctx->Z; a->N = ctx->N; a->D = ctx->D; a->K = K; a->K16 = (K + 15) / 16;
   a->F16 = ctx->F16;
   a->ZS = (ctx->D + 2) | 1;
-  a->RS = ctx->F16 + 2;
+  a->RS = ctx->F16 + 1;   // odd stride: conflict-free under the ds_read2_b64 / ds_write2_b64 banking the compiler emits
   a->LS = a->K16 * 16 + 2;
   a->feat = ctx->feat_d;
   a->row0 = ctx->row0;

@@ -150,9 +150,9 @@ class StackedGaussiansWithNormalWisharts(_ConjugateBlock):
         self._apply(stats if stats is not None else self._stats(data, weights))
         self.likelihood.params = self.posterior.mode()
 
-    def resample(self, data, labels=None, stats=None):
+    def resample(self, data, labels=None, stats=None, rng=None):
         self._apply(stats if stats is not None else self._stats(data, labels))
-        self.likelihood.params = self.posterior.rvs()
+        self.likelihood.params = self.posterior.rvs(rng) if rng is not None else self.posterior.rvs()
 
     def meanfield_update(self, data, weights=None, stats=None, sample=True):
         """bayesian.py:225-230.  `sample=False` skips the (numerically irrelevant for VI) refresh
@@ -197,9 +197,9 @@ class StackedLinearGaussiansWithMatrixNormalWisharts(_ConjugateBlock):
         self._apply(stats if stats is not None else self._stats(x, y, weights))
         self.likelihood.params = self.posterior.mode()
 
-    def resample(self, x, y, z=None, stats=None):
+    def resample(self, x, y, z=None, stats=None, rng=None):
         self._apply(stats if stats is not None else self._stats(x, y, z))
-        self.likelihood.params = self.posterior.rvs()
+        self.likelihood.params = self.posterior.rvs(rng) if rng is not None else self.posterior.rvs()
 
     def meanfield_update(self, x, y, weights=None, stats=None, sample=True):
         self._apply(stats if stats is not None else self._stats(x, y, weights))

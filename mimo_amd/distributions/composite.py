@@ -13,7 +13,7 @@ import scipy.linalg as sla
 
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs,
-                                            sum_log_diag_chol)
+                                            wishart_rvs_batched, sum_log_diag_chol)
 
 
 def _outer(a, b):
@@ -84,9 +84,16 @@ class StackedNormalWisharts:
         """composite.py:77-80: Lambda = (nu - D) psi."""
         return self.mus, (self.nus - self.dim)[:, None, None] * self.psis
 
-    def rvs(self):
+    def rvs(self, rng=None):
         """Per component, in the reference's RNG order (composite.py:82-86, wishart.py:72-92,
-        gaussian.py:311-313): Wishart draw, then mu = m + normal(D) . chol_upper(kappa Lambda)^-T."""
+        gaussian.py:311-313): Wishart draw, then mu = m + normal(D) . chol_upper(kappa Lambda)^-T.
+        With `rng` (a numpy Generator) all K draws are batched (same law, different stream)."""
+        if rng is not None:
+            lmbdas = wishart_rvs_batched(self.psis, self.nus, rng)
+            # mu = m + L^-T eps with kappa Lambda = L L'  =>  cov = (kappa Lambda)^-1
+            L = np.linalg.cholesky(self.kappas[:, None, None] * lmbdas)
+            eps = rng.standard_normal((self.size, self.dim, 1))
+            return self.mus + np.linalg.solve(np.swapaxes(L, 1, 2), eps)[..., 0], lmbdas
         mus, lmbdas = [], []
         for k in range(self.size):
             lmbda = wishart_rvs(self.psis[k], self.nus[k])
@@ -204,9 +211,17 @@ class StackedMatrixNormalWisharts:
     def mode(self):
         return self.Ms, (self.nus - self.row_dim)[:, None, None] * self.psis
 
-    def rvs(self):
+    def rvs(self, rng=None):
         """Reference RNG order (composite.py:607-611, matrix.py:122-125): Wishart draw, then
-        vec_F(A) = vec_F(M) + normal(d l) . chol_upper(kron(K, Lambda))^-T."""
+        vec_F(A) = vec_F(M) + normal(d l) . chol_upper(kron(K, Lambda))^-T.
+        With `rng` all K draws are batched: A = M + Ll^-T E Lk^-1 with Lambda = Ll Ll', K = Lk Lk'."""
+        if rng is not None:
+            lmbdas = wishart_rvs_batched(self.psis, self.nus, rng)
+            Ll, Lk = np.linalg.cholesky(lmbdas), np.linalg.cholesky(self.Ks)
+            E = rng.standard_normal((self.size, self.row_dim, self.column_dim))
+            X = np.linalg.solve(np.swapaxes(Ll, 1, 2), E)                       # Ll^-T E
+            X = np.swapaxes(np.linalg.solve(Lk, np.swapaxes(X, 1, 2)), 1, 2)    # ... Lk^-1
+            return self.Ms + X, lmbdas
         As, lmbdas = [], []
         dy, dx = self.row_dim, self.column_dim
         for k in range(self.size):

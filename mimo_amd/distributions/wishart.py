@@ -43,6 +43,17 @@ def wishart_rvs(psi, nu):
     return T @ T.T
 
 
+def wishart_rvs_batched(psis, nus, rng):
+    """K Wishart draws in one shot (Bartlett), from a numpy Generator.  Same distribution as
+    wishart_rvs but NOT the reference's numpy.random call order — used by the fast Gibbs path."""
+    K, D = psis.shape[0], psis.shape[-1]
+    A = np.tril(rng.standard_normal((K, D, D)), k=-1)
+    dof = np.asarray(nus)[:, None] - np.arange(D)[None, :]
+    A[:, np.arange(D), np.arange(D)] = np.sqrt(rng.chisquare(dof))
+    T = np.linalg.cholesky(psis) @ A
+    return T @ np.swapaxes(T, 1, 2)
+
+
 class Wishart:
 
     def __init__(self, dim, psi=None, nu=None):

@@ -205,13 +205,15 @@ class BayesianMixtureOfGaussians:
 
     # ---- Gibbs sampling ------------------------------------------------------------------------
     def resample(self, obs, init_labels='prior', maxiter=1, progress_bar=True, process_id=0,
-                 label_rng='host', seed=0):
+                 label_rng='host', seed=0, param_rng=None):
         """gmm.py:207-225 — sweep order components -> gating -> labels.
 
         label_rng='host'   : the uniforms are numpy.random.random((1, N)) exactly as in
                              mimo/utils/stats.py:14 (seeded runs reproduce the reference's labels).
         label_rng='philox' : per-datum counter-based Philox4x32-10 inside the kernel, keyed by
                              `seed`, counter (global row, sweep) — no PCIe traffic per sweep.
+        param_rng          : None keeps the reference's per-component numpy.random call order for the
+                             Wishart / Gaussian draws; a numpy Generator batches the K draws.
         The label kernel also returns the statistics of the labels it drew, which are exactly what
         the next sweep's resample_components / resample_gating need: one pass per sweep."""
         eng = self._bind(obs)
@@ -229,7 +231,7 @@ class BayesianMixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'Init #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for it in range(maxiter):
-                self.components.resample(None, stats=_component_stats(S))
+                self.components.resample(None, stats=_component_stats(S), rng=param_rng)
                 self.gating.resample(None, counts=S.n)
                 last = it == maxiter - 1
                 labels, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last,

@@ -179,7 +179,7 @@ class BayesianMixtureOfLinearGaussians:
 
     # ---- Gibbs sampling --------------------------------------------------------------------------
     def resample(self, x, y, init_labels='prior', maxiter=1, progress_bar=True, process_id=0,
-                 label_rng='host', seed=0):
+                 label_rng='host', seed=0, param_rng=None):
         """ilr.py:134-159 — sweep order basis -> models -> gating -> labels."""
         xx, yy = self._scaled(x, y)
         eng = self._bind(xx, yy)
@@ -197,8 +197,8 @@ class BayesianMixtureOfLinearGaussians:
                   disable=not progress_bar) as pbar:
             for it in range(maxiter):
                 bstats, mstats = self._block_stats(S)
-                self.basis.resample(None, stats=bstats)
-                self.models.resample(None, None, stats=mstats)
+                self.basis.resample(None, stats=bstats, rng=param_rng)
+                self.models.resample(None, None, stats=mstats, rng=param_rng)
                 self.gating.resample(None, counts=S.n)
                 last = it == maxiter - 1
                 z, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last, return_labels=last)

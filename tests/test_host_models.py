@@ -30,3 +30,28 @@ def test_ilr_tables_stats_elbo(name):
 @pytest.mark.parametrize("name", ILR_CASES)
 def test_ilr_vi_trace(name):
     mc.check_ilr_vi_trace(name, OracleEngine())
+
+
+def test_batched_samplers_match_the_reference_law():
+    """The batched (Generator) Normal-Wishart / Matrix-Normal-Wishart samplers of the fast Gibbs path
+    have the same first two moments as the reference-order samplers."""
+    import numpy as np
+    import numpy.random as npr
+    from mimo_amd.distributions import StackedNormalWisharts, StackedMatrixNormalWisharts
+    rng = np.random.default_rng(3)
+    K, D = 4000, 3
+    A = rng.standard_normal((D, D)); psi = A @ A.T / D + np.eye(D)
+    nw = StackedNormalWisharts(K, D, np.tile([1., -2., .5], (K, 1)), 2.5 * np.ones(K), np.tile(psi, (K, 1, 1)), 7.5 * np.ones(K))
+    mus_f, lm_f = nw.rvs(rng)
+    npr.seed(5); mus_r, lm_r = nw.rvs()
+    assert np.allclose(lm_f.mean(0), 7.5 * psi, rtol=0.05, atol=0.4) and np.allclose(lm_r.mean(0), lm_f.mean(0), rtol=0.05, atol=0.6)
+    assert np.allclose(mus_f.mean(0), [1., -2., .5], atol=0.03)
+    assert np.allclose(np.cov(mus_f.T), np.cov(mus_r.T), rtol=0.25, atol=0.01)
+    dy, dc = 2, 3
+    Kc = np.array([[2., .3, 0.], [.3, 1., .2], [0., .2, 3.]])
+    mnw = StackedMatrixNormalWisharts(K, dc, dy, np.zeros((K, dy, dc)), np.tile(Kc, (K, 1, 1)),
+                                      np.tile(np.eye(dy), (K, 1, 1)), 6. * np.ones(K))
+    A_f, _ = mnw.rvs(rng)
+    npr.seed(6); A_r, _ = mnw.rvs()
+    cf = np.cov(A_f.reshape(K, -1).T); cr = np.cov(A_r.reshape(K, -1).T)
+    assert np.allclose(cf, cr, rtol=0.3, atol=0.02)
