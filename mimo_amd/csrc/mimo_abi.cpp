@@ -154,6 +154,9 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->F16 = ctx->F16;
   a->ZS = (ctx->D + 2) | 1;
   a->RS = ctx->F16 + 1;   // odd stride: conflict-free under the ds_read2_b64 / ds_write2_b64 banking the compiler emits
+  a->F16_total = ctx->F16;
+  a->cb0 = 0;
+  a->write_scalars = 1;
   a->LS = a->K16 * 16 + 2;
   a->feat = ctx->feat_d;
   a->row0 = ctx->row0;
@@ -227,21 +230,53 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
     g_stamps = stamps_d; g_stamps_grid = grid;
   }
 #endif
-  bool unsupported = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
-  if (unsupported) {
-    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    return fail(ctx, MIMO_E_UNSUPPORTED,
-                "no fused kernel for K=%d, Dz=%d (covered: Dz<=%d with K<=64, or Dz<=9 with K<=256 "
-                "for the E-step; K<=256 for weighted/label statistics)", K, D, kMaxD);
+  const int ncb_total = a.F16 / 16;
+  if (fused_covers(a.K16, ncb_total, src)) {
+    bool unsupported = false;
+    hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
+    if (unsupported) {
+      if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+      return fail(ctx, MIMO_E_UNSUPPORTED, "no fused kernel for K=%d, Dz=%d", K, D);
+    }
+    HIP_TRY(ctx, he);
+  } else {
+    // two-stage path: chunked E-step writes responsibilities / labels, then the statistics kernel
+    // runs once per group of <= kMaxNCB feature column blocks, all into the same partial block.
+    KernelArgs st = a;
+    int stats_src = src;
+    if (src == kSrcEstep) {
+      KernelArgs e = a;
+      e.RS = 16 * kChunkNCB + 1;
+      if (!e.gibbs && e.do_stats && !e.resp) {       // statistics need the table: keep it internally
+        const size_t kn = (size_t)K * (size_t)(ctx->N > 0 ? ctx->N : 1);
+        if ((rc = ensure_dev(ctx, &ctx->resp, &ctx->resp_cap, kn))) return rc;
+        e.resp = ctx->resp; ctx->resp_K = K; ctx->resp_valid = true;
+      }
+      if (chunked_lds_bytes(e) > 160 * 1024)
+        return fail(ctx, MIMO_E_UNSUPPORTED, "K=%d, Dz=%d needs more LDS than one CU has", K, D);
+      HIP_TRY(ctx, launch_estep_chunked(e, grid, ctx->stream));
+      st.resp = e.resp; st.labels = e.labels; st.write_scalars = 0;
+      stats_src = e.gibbs ? kSrcLabels : kSrcWeights;
+    }
+    if (a.do_stats) {
+      for (int cb0 = 0; cb0 < ncb_total; cb0 += kMaxNCB) {
+        KernelArgs g = st;
+        const int ncb = ncb_total - cb0 < kMaxNCB ? ncb_total - cb0 : kMaxNCB;
+        g.cb0 = cb0; g.F16 = 16 * ncb; g.RS = g.F16 + 1; g.F16_total = a.F16;
+        g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
+        if (cb0 > 0) g.write_scalars = 0;
+        bool unsupported = false;
+        HIP_TRY(ctx, launch_fused(g, stats_src, grid, ctx->stream, &unsupported));
+        if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no statistics kernel for K=%d, Dz=%d", K, D);
+      }
+    }
   }
-  HIP_TRY(ctx, he);
   if (ctx->prof) {
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     ctx->pending.emplace_back(e0, e1);

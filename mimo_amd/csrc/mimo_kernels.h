@@ -9,7 +9,9 @@ namespace mimo {
 constexpr int kWG = 256;        // threads per workgroup (4 wavefronts of 64)
 constexpr int kTile = 32;       // data rows per tile
 constexpr int kMaxNCB = 10;     // 16-wide feature column blocks one launch accumulates
-constexpr int kMaxD = 16;       // largest Dz the fused kernels cover (F = 153 features)
+constexpr int kMaxFusedD = 16;  // largest Dz the single-pass fused kernels cover (F = 153 features)
+constexpr int kMaxD = 32;       // largest Dz overall (two-stage path: chunked E-step + statistics per column group)
+constexpr int kChunkNCB = 8;    // feature column blocks per chunk of the chunked E-step (128 features)
 
 // Where the per-tile weight table R (rows x K) comes from.
 enum Source : int { kSrcEstep = 0, kSrcWeights = 1, kSrcLabels = 2 };
@@ -39,6 +41,9 @@ struct KernelArgs {
   int do_stats;
   int split;              // also accumulate sum_k r l (entropy split of the ELBO scalars)
   int64_t ntiles;
+  int cb0;                // statistics modes: first 16-wide feature column block of this launch
+  int F16_total;          // padded feature count of the whole problem (partials row stride)
+  int write_scalars;      // write the 4 scalar slots of the partial block (0: another launch owns them)
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
 };
 
@@ -53,6 +58,10 @@ size_t fused_lds_bytes(const KernelArgs& a);
 int fused_grid(const KernelArgs& a, int num_cu);
 // returns hipSuccess or an error; sets *unsupported when (K, D, src) has no kernel
 hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
+// chunked E-step for shapes outside the fused kernels (Dz > 16, or K > 64 with Dz > 9): no statistics
+size_t chunked_lds_bytes(const KernelArgs& a);
+hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream);
+bool fused_covers(int K16, int ncb, int src);
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream);

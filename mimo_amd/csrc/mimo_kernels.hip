@@ -111,6 +111,114 @@ __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-datum normalisation over k of one 32-row tile held in LDS as Lt[row][component]:
+// 8 lanes per datum, 2*K16 consecutive components per lane, fully unrolled.  Softmax -> r written
+// back in place, or inverse-CDF categorical draw -> one-hot written back (+ label to HBM).
+// ------------------------------------------------------------------------------------------
+template <int RBW, int MODE>
+__device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __restrict__ Lt, const int LS,
+                                               const double* __restrict__ etab, const int K, const int K16,
+                                               const int64_t N, const int64_t n0, const int wave, const int lane,
+                                               const bool gibbs, double* const out_logp, double* const out_resp,
+                                               double* const out_lse, double& sc_lse, double& sc_rl) {
+        constexpr int CPM = 8 * RBW;  // most components a lane can own (Kpad <= 64 * RBW)
+        const int pt = 8 * wave + (lane & 7), part = lane >> 3;
+        const int CPP = 2 * K16, k0 = part * CPP;
+        const int64_t n = n0 + pt;
+        const bool valid = n < N;
+        double* row = Lt + pt * LS + k0;
+
+        // x[] holds l, then exp(l - max), then the weight written back — one register array
+        double x[CPM];
+#pragma unroll
+        for (int c = 0; c < CPM; ++c) x[c] = (c < CPP && k0 + c < K) ? row[c] : -INFINITY;
+        if (out_logp && valid) {
+#pragma unroll
+          for (int c = 0; c < CPM; ++c)
+            if (c < CPP && k0 + c < K) out_logp[(int64_t)(k0 + c) * N + n] = x[c];
+        }
+        double m = x[0];
+#pragma unroll
+        for (int c = 1; c < CPM; ++c) m = fmax(m, x[c]);
+        m = fmax(m, __shfl_xor(m, 8));
+        m = fmax(m, __shfl_xor(m, 16));
+        m = fmax(m, __shfl_xor(m, 32));
+
+        double ssum = 0.0, sel = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPM; ++c) {
+          const double lc = x[c];
+          x[c] = exp_nonpos(lc - m, etab);              // inactive slots: l = -inf -> 0
+          ssum += x[c];
+          if constexpr (MODE == kGeneric) sel = fma(x[c], (c < CPP && k0 + c < K) ? lc : 0.0, sel);
+          if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 chains in flight bound the temporaries
+        }
+        ssum += __shfl_xor(ssum, 8);
+        ssum += __shfl_xor(ssum, 16);
+        ssum += __shfl_xor(ssum, 32);
+        if constexpr (MODE == kGeneric) {   // sum_k r l only feeds the entropy split of the ELBO (scalars[1..2])
+          sel += __shfl_xor(sel, 8);
+          sel += __shfl_xor(sel, 16);
+          sel += __shfl_xor(sel, 32);
+        }
+        const double lse = m + log(ssum);
+        const double inv = 1.0 / ssum;
+
+        if (part == 0 && valid) {
+          sc_lse += lse;
+          sc_rl += sel * inv;
+          if (out_lse) out_lse[n] = lse;
+        }
+
+        if (!gibbs) {
+          const double scale = valid ? inv : 0.0;
+#pragma unroll
+          for (int c = 0; c < CPM; ++c) {
+            x[c] *= scale;
+            if (c < CPP) row[c] = x[c];
+          }
+          if (out_resp && valid) {
+#pragma unroll
+            for (int c = 0; c < CPM; ++c)
+              if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c];
+          }
+        } else {
+          // inverse-CDF draw (mimo/utils/stats.py:10-17): p_k = exp(l_k - lse) (= e_k / sum e),
+          // cum = cumsum_k p, label = #{k : u * cum[K-1] > cum[k]}.
+          double cum = 0.0;
+#pragma unroll
+          for (int c = 0; c < CPM; ++c) {
+            cum = fma(x[c], inv, cum);
+            x[c] = cum;  // local inclusive cumulative sum
+          }
+          double incl = cum;  // inclusive scan over the 8 parts of this datum
+          {
+            double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
+            v = __shfl_up(incl, 16);        if (part >= 2) incl += v;
+            v = __shfl_up(incl, 32);        if (part >= 4) incl += v;
+          }
+          double excl = __shfl_up(incl, 8);
+          if (part == 0) excl = 0.0;
+          const double ctot = __shfl(excl + cum, 56 + (lane & 7));  // == last cumulative value
+          const double uu = a.u ? (valid ? a.u[n] : 0.0)
+                                : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+          const double thr = uu * ctot;
+          int cnt = 0;
+#pragma unroll
+          for (int c = 0; c < CPM; ++c)
+            cnt += (c < CPP && k0 + c < K && thr > excl + x[c]) ? 1 : 0;
+          cnt += __shfl_xor(cnt, 8);
+          cnt += __shfl_xor(cnt, 16);
+          cnt += __shfl_xor(cnt, 32);
+          const int label = cnt < K ? cnt : K - 1;
+#pragma unroll
+          for (int c = 0; c < CPM; ++c)
+            if (c < CPP) row[c] = (valid && k0 + c == label) ? 1.0 : 0.0;
+          if (part == 0 && valid && a.labels) a.labels[n] = label;
+        }
+      }
+
+// ------------------------------------------------------------------------------------------
 // Fused tile kernel.  NCB: 16-wide feature column blocks (F16 = 16*NCB); RBW: component
 // row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
 // ------------------------------------------------------------------------------------------
@@ -142,7 +250,9 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
   const int Kpad = K16 * 16;
   const int64_t N = a.N;
 
-  for (int e = tid; e < F16 * 2; e += kWG) fe[e] = a.feat[e];
+  // statistics modes may cover only the column blocks [cb0, cb0 + NCB) of a larger feature set
+  const uint8_t* featp = a.feat + (SRC == kSrcEstep ? 0 : 32 * a.cb0);
+  for (int e = tid; e < F16 * 2; e += kWG) fe[e] = featp[e];
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
 
   // Theta in MFMA A-operand layout: lane (i = lane&15, kk = lane>>4) of slice s of row-block rb holds
@@ -173,28 +283,29 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 
   double sc_lse = 0.0, sc_rl = 0.0;
 
-  // Z tile staging: every thread owns up to two elements of the (T, D) tile; the NEXT tile is
+  // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
-  // critical path (T*D <= 512 for D <= 16).
-  int zoff[2];
+  // critical path (T*D <= 512 for the fused E-step modes, Dz <= 16; <= 1024 for the statistics modes).
+  constexpr int ZPT = SRC == kSrcEstep ? 2 : 4;
+  int zoff[ZPT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < ZPT; ++i) {
     const int e = tid + kWG * i;
     const int pt = e / D;
     zoff[i] = e < T * D ? pt * ZS + (e - pt * D) : -1;
   }
-  double zr[2];
+  double zr[ZPT];
   auto load_z = [&](int64_t t) {
     const int64_t base = t * T * D, total = N * D;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ZPT; ++i) {
       const int64_t g = base + tid + kWG * i;
       zr[i] = (zoff[i] >= 0 && g < total) ? a.Z[g] : 0.0;
     }
   };
   auto store_z = [&](int64_t t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < ZPT; ++i)
       if (zoff[i] >= 0) Zs[zoff[i]] = zr[i];
     if (tid < T) {
       Zs[tid * ZS + D] = (t * T + tid) < N ? 1.0 : 0.0;  // rows past N contribute nothing
@@ -300,103 +411,8 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 
       // ---- 4. normalise over k: 8 lanes per datum, 2*K16 consecutive components per lane ----------
       __builtin_amdgcn_s_setprio(2);
-      {
-        constexpr int CPM = 8 * RBW;  // most components a lane can own (Kpad <= 64 * RBW)
-        const int pt = 8 * wave + (lane & 7), part = lane >> 3;
-        const int CPP = 2 * K16, k0 = part * CPP;
-        const int64_t n = n0 + pt;
-        const bool valid = n < N;
-        double* row = Lt + pt * LS + k0;
-
-        // x[] holds l, then exp(l - max), then the weight written back — one register array
-        double x[CPM];
-#pragma unroll
-        for (int c = 0; c < CPM; ++c) x[c] = (c < CPP && k0 + c < K) ? row[c] : -INFINITY;
-        if (out_logp && valid) {
-#pragma unroll
-          for (int c = 0; c < CPM; ++c)
-            if (c < CPP && k0 + c < K) out_logp[(int64_t)(k0 + c) * N + n] = x[c];
-        }
-        double m = x[0];
-#pragma unroll
-        for (int c = 1; c < CPM; ++c) m = fmax(m, x[c]);
-        m = fmax(m, __shfl_xor(m, 8));
-        m = fmax(m, __shfl_xor(m, 16));
-        m = fmax(m, __shfl_xor(m, 32));
-
-        double ssum = 0.0, sel = 0.0;
-#pragma unroll
-        for (int c = 0; c < CPM; ++c) {
-          const double lc = x[c];
-          x[c] = exp_nonpos(lc - m, etab);              // inactive slots: l = -inf -> 0
-          ssum += x[c];
-          if constexpr (MODE == kGeneric) sel = fma(x[c], (c < CPP && k0 + c < K) ? lc : 0.0, sel);
-          if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 chains in flight bound the temporaries
-        }
-        ssum += __shfl_xor(ssum, 8);
-        ssum += __shfl_xor(ssum, 16);
-        ssum += __shfl_xor(ssum, 32);
-        if constexpr (MODE == kGeneric) {   // sum_k r l only feeds the entropy split of the ELBO (scalars[1..2])
-          sel += __shfl_xor(sel, 8);
-          sel += __shfl_xor(sel, 16);
-          sel += __shfl_xor(sel, 32);
-        }
-        const double lse = m + log(ssum);
-        const double inv = 1.0 / ssum;
-
-        if (part == 0 && valid) {
-          sc_lse += lse;
-          sc_rl += sel * inv;
-          if (out_lse) out_lse[n] = lse;
-        }
-
-        if (!gibbs) {
-          const double scale = valid ? inv : 0.0;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c) {
-            x[c] *= scale;
-            if (c < CPP) row[c] = x[c];
-          }
-          if (out_resp && valid) {
-#pragma unroll
-            for (int c = 0; c < CPM; ++c)
-              if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c];
-          }
-        } else {
-          // inverse-CDF draw (mimo/utils/stats.py:10-17): p_k = exp(l_k - lse) (= e_k / sum e),
-          // cum = cumsum_k p, label = #{k : u * cum[K-1] > cum[k]}.
-          double cum = 0.0;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c) {
-            cum = fma(x[c], inv, cum);
-            x[c] = cum;  // local inclusive cumulative sum
-          }
-          double incl = cum;  // inclusive scan over the 8 parts of this datum
-          {
-            double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
-            v = __shfl_up(incl, 16);        if (part >= 2) incl += v;
-            v = __shfl_up(incl, 32);        if (part >= 4) incl += v;
-          }
-          double excl = __shfl_up(incl, 8);
-          if (part == 0) excl = 0.0;
-          const double ctot = __shfl(excl + cum, 56 + (lane & 7));  // == last cumulative value
-          const double uu = a.u ? (valid ? a.u[n] : 0.0)
-                                : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
-          const double thr = uu * ctot;
-          int cnt = 0;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c)
-            cnt += (c < CPP && k0 + c < K && thr > excl + x[c]) ? 1 : 0;
-          cnt += __shfl_xor(cnt, 8);
-          cnt += __shfl_xor(cnt, 16);
-          cnt += __shfl_xor(cnt, 32);
-          const int label = cnt < K ? cnt : K - 1;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c)
-            if (c < CPP) row[c] = (valid && k0 + c == label) ? 1.0 : 0.0;
-          if (part == 0 && valid && a.labels) a.labels[n] = label;
-        }
-      }
+      normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
+                                sc_lse, sc_rl);
       STAMP(5);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();
@@ -435,8 +451,9 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 #endif
 
   // ---- per-workgroup partials ------------------------------------------------------------
-  const size_t pstride = (size_t)Kpad * F16 + 4;
-  double* P = a.partials + (size_t)blockIdx.x * pstride;
+  const int FT = a.F16_total;   // row stride of the partial block (= F16 unless this launch is one column group)
+  const size_t pstride = (size_t)Kpad * FT + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride + (SRC == kSrcEstep ? 0 : 16 * a.cb0);
 #pragma unroll
   for (int i = 0; i < RBW; ++i) {
     const int rb = wave + 4 * i;
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
       for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          P[(size_t)(16 * rb + q + 4 * r) * F16 + 16 * cb + j] = sacc[i][cb][r];
+          P[(size_t)(16 * rb + q + 4 * r) * FT + 16 * cb + j] = sacc[i][cb][r];
     }
   }
   sc_lse = wave_sum(sc_lse);
@@ -453,11 +470,122 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
   __syncthreads();
   if (lane == 0) { red[2 * wave] = sc_lse; red[2 * wave + 1] = sc_rl; }
   __syncthreads();
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = a.partials + (size_t)blockIdx.x * pstride + (size_t)Kpad * FT;
+    Ps[0] = (red[0] + red[2]) + (red[4] + red[6]);
+    Ps[1] = (red[1] + red[3]) + (red[5] + red[7]);
+    Ps[2] = MODE == kGeneric ? 1.0 : 0.0;   // > 0 after the reduction: split is valid
+    Ps[3] = 0.0;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Chunked E-step (no statistics) for shapes the fused kernel cannot hold: the F16 features are
+// processed in chunks of 16*kChunkNCB; per chunk the feature tile is rebuilt in LDS and the L tile
+// accumulates in registers.  Writes the responsibility table / labels (+ optional logp, lse) to
+// HBM; the statistics then come from fused_kernel<.., kModeWeights / kModeLabels> per column group.
+// ------------------------------------------------------------------------------------------
+template <int RBW>
+__global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs a) {
+  constexpr int T = kTile;
+  constexpr int NCBc = kChunkNCB, CF = 16 * NCBc, NSc = CF / 4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* Zs = reinterpret_cast<double*>(smem);
+  double* Ph = Zs + T * a.ZS;
+  double* Lt = Ph + T * a.RS;
+  double* red = Lt + T * a.LS;
+  double* etab = red + 16;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
+  const int ZS = a.ZS, RS = a.RS, LS = a.LS;
+  const int NS = F16 / 4, nchunk = (F16 + CF - 1) / CF;
+  const int64_t N = a.N;
+  const bool gibbs = a.gibbs != 0;
+  if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+  double sc_lse = 0.0, sc_rl = 0.0;
+  const int frow = tid & (T - 1), fgrp = tid >> 5;   // feature build: 8 groups x 16 features per chunk
+
+  for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const int64_t n0 = t * T;
+    __syncthreads();
+    {
+      const int64_t base = n0 * D, total = N * D;
+      for (int e = tid; e < T * D; e += kWG) {
+        const int pt = e / D, d = e - pt * D;
+        Zs[pt * ZS + d] = (base + e) < total ? a.Z[base + e] : 0.0;
+      }
+      if (tid < T) {
+        Zs[tid * ZS + D] = (n0 + tid) < N ? 1.0 : 0.0;
+        Zs[tid * ZS + D + 1] = 0.0;
+      }
+    }
+    d4 acc[RBW][2];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+      __syncthreads();   // z~ rows visible / previous chunk's MFMA reads of Ph are done
+      {
+        const double* zrow = Zs + frow * ZS;
+        double* prow = Ph + frow * RS + fgrp * (2 * NCBc);
+        const uint8_t* ft = a.feat + 2 * (ch * CF + fgrp * 2 * NCBc);
+#pragma unroll
+        for (int jj = 0; jj < 2 * NCBc; ++jj) {
+          const int f = ch * CF + fgrp * 2 * NCBc + jj;
+          prow[jj] = f < F16 ? zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]] : 0.0;
+        }
+      }
+      __syncthreads();
+      if (wave < K16) {
+        const double* p0 = Ph + j * RS + q;
+        const double* p1 = Ph + (16 + j) * RS + q;
+#pragma unroll 4
+        for (int s = 0; s < NSc; ++s) {
+          const int sg = ch * NSc + s;
+          if (sg < NS) {
+            const double b0 = p0[4 * s], b1 = p1[4 * s];
+#pragma unroll
+            for (int i = 0; i < RBW; ++i) {
+              if (wave + 4 * i < K16) {
+                const double av = a.theta[((size_t)(wave + 4 * i) * NS + sg) * 64 + lane];
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[i][1], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RBW; ++i) {
+      const int rb = wave + 4 * i;
+      if (rb < K16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Lt[j * LS + 16 * rb + q + 4 * r] = acc[i][0][r];
+          Lt[(16 + j) * LS + 16 * rb + q + 4 * r] = acc[i][1][r];
+        }
+      }
+    }
+    __syncthreads();
+    normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
+                                  sc_lse, sc_rl);
+  }
+  sc_lse = wave_sum(sc_lse);
+  sc_rl = wave_sum(sc_rl);
+  __syncthreads();
+  if (lane == 0) { red[2 * wave] = sc_lse; red[2 * wave + 1] = sc_rl; }
+  __syncthreads();
   if (tid == 0) {
-    P[(size_t)Kpad * F16 + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-    P[(size_t)Kpad * F16 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
-    P[(size_t)Kpad * F16 + 2] = MODE == kGeneric ? 1.0 : 0.0;   // > 0 after the reduction: split is valid
-    P[(size_t)Kpad * F16 + 3] = 0.0;
+    double* Ps = a.partials + (size_t)blockIdx.x * ((size_t)K16 * 16 * a.F16_total + 4) + (size_t)K16 * 16 * a.F16_total;
+    Ps[0] = (red[0] + red[2]) + (red[4] + red[6]);
+    Ps[1] = (red[1] + red[3]) + (red[5] + red[7]);
+    Ps[2] = 1.0;
+    Ps[3] = 0.0;
   }
 }
 
@@ -606,6 +734,28 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   if (!fn) { *unsupported = true; return hipSuccess; }
   const size_t lds = fused_lds_bytes(a);
   if (lds > 160 * 1024) { *unsupported = true; return hipSuccess; }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, a);
+  return hipGetLastError();
+}
+
+bool fused_covers(int K16, int ncb, int src) {
+  if (K16 > 16 || ncb < 1 || ncb > kMaxNCB) return false;
+  if (src == kSrcEstep && K16 > 4 && ncb > 4) return false;   // RBW = 4 E-step only for Dz <= 9
+  return true;
+}
+
+size_t chunked_lds_bytes(const KernelArgs& a) {
+  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + 64);
+}
+
+hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream) {
+  typedef void (*fn_t)(const KernelArgs);
+  fn_t fn = rbw_for(a.K16) == 1 ? estep_chunked_kernel<1> : estep_chunked_kernel<4>;
+  const size_t lds = chunked_lds_bytes(a);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

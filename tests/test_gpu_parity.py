@@ -9,7 +9,7 @@ import model_checks as mc
 
 pytestmark = pytest.mark.gpu
 
-GPU_GMM = [c for c in GMM_CASES if "d32" not in c]     # Dz=32 is beyond the fused kernels this round
+GPU_GMM = list(GMM_CASES)      # incl. Dz=32 (two-stage path: chunked E-step + statistics per column group)
 
 
 @pytest.mark.parametrize("name", GPU_GMM)
@@ -59,7 +59,9 @@ def _random_problem(rng, N, D, K):
 
 
 @pytest.mark.parametrize("N,D,K", [(0, 3, 2), (1, 1, 1), (31, 16, 16), (32, 2, 4), (33, 5, 70), (4099, 8, 256),
-                                    (4099, 12, 64), (20011, 16, 64), (1000, 9, 200), (777, 13, 17)])
+                                    (4099, 12, 64), (20011, 16, 64), (1000, 9, 200), (777, 13, 17),
+                                    # two-stage path (chunked E-step + column-group statistics)
+                                    (2051, 32, 128), (515, 32, 16), (700, 12, 200), (333, 20, 256), (100, 17, 3)])
 def test_engine_vs_oracle_seeded(engine, N, D, K):
     """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
     from oracle import mimo_oracle as O
