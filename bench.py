@@ -160,9 +160,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("MIMO_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from mimo_amd.engine import HipEngine
     from mimo_amd.sharded import ShardedEngine
@@ -177,8 +180,8 @@ def main():
     hip = HipEngine(local_rank)
     hip.set_stream(torch.cuda.current_stream().cuda_stream)
     hip.upload(X)                                  # borrows the device tensor (no copy)
-    engine = ShardedEngine(hip, row_offset=rank * N) if world > 1 else hip
-    if world > 1:
+    engine = ShardedEngine(hip, row_offset=rank * N) if dist is not None else hip
+    if dist is not None:
         hip.set_row_offset(rank * N)
     model = build_model(cfg, engine)
 
@@ -266,9 +269,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, X[:200_000].cpu().numpy())
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        try:                      # RCCL's banner sits in the C stdio buffer: drain it so the JSON line is last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,8 @@ class ShardedEngine:
         self.device = getattr(inner, "device", 0)
         self._row0 = int(row_offset)
         self._buf = None
-        self._device_path = hasattr(inner, "estep_device") and dist.get_backend(group) == "nccl"
+        self._nccl = dist.get_backend(group) == "nccl"
+        self._device_path = hasattr(inner, "estep_device") and self._nccl
         if self._device_path:
             import torch
             inner.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -67,13 +68,21 @@ class ShardedEngine:
         return self.inner.get_labels()
 
     # ---- the exchange step -------------------------------------------------------------------------
-    def _allreduce_host(self, S, extra):
+    def _allreduce_array(self, arr):
+        """Sum a host float64 array over the ranks (through a device tensor when the backend is RCCL,
+        which only reduces device memory)."""
         import torch
-        K, D = S.sx.shape
-        packed = np.concatenate([S.packed().ravel(), np.asarray(extra, dtype=float)])
-        t = torch.from_numpy(packed)
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        if self._nccl:
+            d = t.to(f"cuda:{self.device}")
+            self._dist.all_reduce(d, op=self._dist.ReduceOp.SUM, group=self.group)
+            return d.cpu().numpy()
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        out = t.numpy()
+        return t.numpy()
+
+    def _allreduce_host(self, S, extra):
+        K, D = S.sx.shape
+        out = self._allreduce_array(np.concatenate([S.packed().ravel(), np.asarray(extra, dtype=float)]))
         return SuffStats.from_packed(out[:K * (1 + D + D * D)], K, D), out[K * (1 + D + D * D):]
 
     def _device_buffer(self, K):
@@ -101,11 +110,31 @@ class ShardedEngine:
             return None, t
         return self._allreduce_host(S, sc)
 
-    def _allreduce_scalars(self, sc):
+    def estep_async(self, c, b, W):
+        """Enqueue the fused pass, the RCCL all-reduce of the statistic block and its copy to pinned host
+        memory on the shared stream; estep_wait() synchronises.  Host work in between overlaps all three."""
+        if not self._device_path:
+            self._pending = self.estep(c, b, W)
+            return
         import torch
-        t = torch.from_numpy(np.array(sc, dtype=float))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.numpy()
+        K = np.asarray(c).shape[0]
+        buf, slen = self._device_buffer(K)
+        self.inner.estep_device(c, b, W, buf.data_ptr(), buf.data_ptr() + 8 * slen)
+        self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
+        self._host.copy_(buf, non_blocking=True)
+        self._pending = (K, slen, torch.cuda.current_stream())
+
+    def estep_wait(self):
+        p, self._pending = self._pending, None
+        if not self._device_path:
+            return p
+        K, slen, stream = p
+        stream.synchronize()
+        out = self._host.numpy()
+        return SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
+
+    def _allreduce_scalars(self, sc):
+        return self._allreduce_array(np.array(sc, dtype=float))
 
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
         if self._device_path and stats and u is None and not return_labels and not keep_logp:
