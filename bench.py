@@ -125,8 +125,9 @@ def cpu_baseline(cfg, X_host):
         ll = O.gmm_expected_log_complete_likelihood(x, post, 'dirichlet', gpost, chunk=1024)
         r = O.responsibilities(ll)
         return O.gauss_weighted_statistics(x, r)
-    t0 = time.time(); sweep(X_host[:1024]); dt = time.time() - t0
-    rows = int(min(len(X_host), max(2048, 1024 * round(12.0 / max(dt, 1e-3)))))
+    sweep(X_host[:2048])                                   # warm the BLAS threads / caches
+    t0 = time.time(); sweep(X_host[:8192]); dt = time.time() - t0
+    rows = int(min(len(X_host), max(8192, 1024 * round(15.0 / max(dt / 8.0, 1e-4)))))   # ~15 s of CPU work
     t0 = time.time(); sweep(X_host[:rows]); dt = time.time() - t0
     threads = os.cpu_count()
     try:
@@ -266,7 +267,7 @@ def main():
         if vlb and vlb[0] is not None:
             out["elbo_first_last"] = [float(vlb[0]), float(vlb[-1])]
         if world == 1 and not args.no_cpu_baseline and mode == "vi":
-            out["cpu_baseline"] = cpu_baseline(cfg, X[:200_000].cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(cfg, X[:600_000].cpu().numpy())
         else:
             out["cpu_baseline"] = None
     if dist is not None:

@@ -38,6 +38,7 @@
 #include "mimo_kernels.h"
 
 #include <math.h>
+#include <utility>
 
 namespace mimo {
 
@@ -111,6 +112,37 @@ __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Compile-time feature map for the E-step modes (DS = Dz known at compile time): feature f of
+// z~ = [z, 1] is z~_a z~_b with (a,b) the f-th pair of the upper triangle, row-major; padded
+// features (f >= F) read the zero slot z~[D+1].
+// ------------------------------------------------------------------------------------------
+template <int D, int F>
+struct FeatAB {
+  static constexpr int find_a() {
+    int a = 0, base = 0;
+    while (a <= D && base + (D + 1 - a) <= F) { base += D + 1 - a; ++a; }
+    return a;
+  }
+  static constexpr int base_of(int a) {
+    int b = 0;
+    for (int i = 0; i < a; ++i) b += D + 1 - i;
+    return b;
+  }
+  static constexpr bool pad = F >= (D + 1) * (D + 2) / 2;
+  static constexpr int a = pad ? D + 1 : find_a();
+  static constexpr int b = pad ? D + 1 : a + (F - base_of(a));
+};
+
+// lane (row = lane & 31, parity = lane >> 5) of wave W writes features W*FW + 2i + parity, i < FW/2
+template <int D, int FW, int W, int... I>
+__device__ __forceinline__ void build_features_static(const double (&z)[D + 2], double* __restrict__ prow,
+                                                      const bool parity, std::integer_sequence<int, I...>) {
+  ((prow[W * FW + 2 * I] = (parity ? z[FeatAB<D, W * FW + 2 * I + 1>::a] : z[FeatAB<D, W * FW + 2 * I>::a]) *
+                           (parity ? z[FeatAB<D, W * FW + 2 * I + 1>::b] : z[FeatAB<D, W * FW + 2 * I>::b])),
+   ...);
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-datum normalisation over k of one 32-row tile held in LDS as Lt[row][component]:
 // 8 lanes per datum, 2*K16 consecutive components per lane, fully unrolled.  Softmax -> r written
 // back in place, or inverse-CDF categorical draw -> one-hot written back (+ label to HBM).
@@ -120,7 +152,7 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
                                                const double* __restrict__ etab, const int K, const int K16,
                                                const int64_t N, const int64_t n0, const int wave, const int lane,
                                                const bool gibbs, double* const out_logp, double* const out_resp,
-                                               double* const out_lse, double& sc_lse, double& sc_rl) {
+                                               double* const out_lse, double& sc_lse, double& sc_rl, double& sc_prod) {
         constexpr int CPM = 8 * RBW;  // most components a lane can own (Kpad <= 64 * RBW)
         const int pt = 8 * wave + (lane & 7), part = lane >> 3;
         const int CPP = 2 * K16, k0 = part * CPP;
@@ -161,13 +193,27 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           sel += __shfl_xor(sel, 16);
           sel += __shfl_xor(sel, 32);
         }
-        const double lse = m + log(ssum);
-        const double inv = 1.0 / ssum;
+        // 1 / sum: v_rcp_f64 seed + two Newton steps (5 dependent f64 ops instead of the IEEE divide's
+        // ~12; every one of them waits for a matrix-pipe slot); relative error <= 1 ulp-ish (2^-52).
+        double inv = __builtin_amdgcn_rcp(ssum);
+        inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+        inv = fma(fma(-ssum, inv, 1.0), inv, inv);
 
-        if (part == 0 && valid) {
-          sc_lse += lse;
-          sc_rl += sel * inv;
-          if (out_lse) out_lse[n] = lse;
+        double lse = 0.0;
+        if constexpr (MODE == kGeneric) {
+          lse = m + log(ssum);
+          if (part == 0 && valid) {
+            sc_lse += lse;
+            sc_rl += sel * inv;
+            if (out_lse) out_lse[n] = lse;
+          }
+        } else {
+          // fast modes only need sum_n lse_n = sum_n m_n + log prod_n ssum_n: the product of the per-datum
+          // sums (each in [1, K]) is accumulated and its log taken once per 64 tiles by the caller.
+          if (part == 0 && valid) {
+            sc_lse += m;
+            sc_prod *= ssum;
+          }
         }
 
         if (!gibbs) {
@@ -222,7 +268,7 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
 // Fused tile kernel.  NCB: 16-wide feature column blocks (F16 = 16*NCB); RBW: component
 // row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
 // ------------------------------------------------------------------------------------------
-template <int NCB, int RBW, int MODE>
+template <int NCB, int RBW, int MODE, int DS = 0>
 __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const KernelArgs a) {
   constexpr int SRC = MODE == kModeWeights ? kSrcWeights : MODE == kModeLabels ? kSrcLabels : kSrcEstep;
   // flags fold to constants in the two fast modes
@@ -281,7 +327,8 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) sacc[i][cb] = d4{0.0, 0.0, 0.0, 0.0};
 
-  double sc_lse = 0.0, sc_rl = 0.0;
+  double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
+  int prod_tiles = 0;
 
   // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
@@ -321,8 +368,10 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
   const int frow = tid & (T - 1), fgrp = tid >> 5;
   __syncthreads();  // feature table and exp table are in LDS
   uint32_t w[NCB];
+  if constexpr (DS == 0) {
 #pragma unroll
-  for (int jj = 0; jj < NCB; ++jj) w[jj] = reinterpret_cast<const uint32_t*>(fe)[fgrp * NCB + jj];
+    for (int jj = 0; jj < NCB; ++jj) w[jj] = reinterpret_cast<const uint32_t*>(fe)[fgrp * NCB + jj];
+  }
 
 #ifdef MIMO_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
@@ -338,7 +387,23 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
     // workgroup's MFMA stream, and at equal priority a dependent VALU chain gets one issue slot
     // per 64-cycle MFMA.
     __builtin_amdgcn_s_setprio(2);
-    {
+    if constexpr (DS > 0) {
+      // compile-time feature map: the z~ row goes to registers once, every product has static operands
+      double zl[DS + 2];
+      const double* zrow = Zs + frow * ZS;
+#pragma unroll
+      for (int d = 0; d <= DS; ++d) zl[d] = zrow[d];
+      zl[DS + 1] = 0.0;
+      double* prow = Ph + frow * RS + (lane >> 5);
+      constexpr int FW = 4 * NCB;
+      using Seq = std::make_integer_sequence<int, FW / 2>;
+      switch (wave) {   // scalar: no divergence
+        case 0: build_features_static<DS, FW, 0>(zl, prow, (lane >> 5) != 0, Seq{}); break;
+        case 1: build_features_static<DS, FW, 1>(zl, prow, (lane >> 5) != 0, Seq{}); break;
+        case 2: build_features_static<DS, FW, 2>(zl, prow, (lane >> 5) != 0, Seq{}); break;
+        default: build_features_static<DS, FW, 3>(zl, prow, (lane >> 5) != 0, Seq{}); break;
+      }
+    } else {
       const double* zrow = Zs + frow * ZS;
       double* prow = Ph + frow * RS + fgrp * (2 * NCB);
 #pragma unroll
@@ -412,7 +477,14 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
       // ---- 4. normalise over k: 8 lanes per datum, 2*K16 consecutive components per lane ----------
       __builtin_amdgcn_s_setprio(2);
       normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
-                                sc_lse, sc_rl);
+                                sc_lse, sc_rl, sc_prod);
+      if constexpr (MODE != kGeneric) {
+        if (++prod_tiles == 64) {   // K^64 <= 256^64 = 2^512 stays inside the float64 range
+          sc_lse += log(sc_prod);
+          sc_prod = 1.0;
+          prod_tiles = 0;
+        }
+      }
       STAMP(5);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();
@@ -465,6 +537,7 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
           P[(size_t)(16 * rb + q + 4 * r) * FT + 16 * cb + j] = sacc[i][cb][r];
     }
   }
+  if constexpr (MODE == kFastVI || MODE == kFastGibbs) sc_lse += log(sc_prod);
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
   __syncthreads();
@@ -506,7 +579,7 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
   const int64_t N = a.N;
   const bool gibbs = a.gibbs != 0;
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
-  double sc_lse = 0.0, sc_rl = 0.0;
+  double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
   const int frow = tid & (T - 1), fgrp = tid >> 5;   // feature build: 8 groups x 16 features per chunk
 
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
@@ -573,7 +646,7 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
     }
     __syncthreads();
     normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
-                                  sc_lse, sc_rl);
+                                  sc_lse, sc_rl, sc_prod);
   }
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
@@ -665,60 +738,64 @@ int fused_grid(const KernelArgs& a, int num_cu) {
   return (int)g;
 }
 
+bool fused_covers(int K16, int ncb, int src) {
+  if (K16 > 16 || ncb < 1 || ncb > kMaxNCB) return false;
+  if (src == kSrcEstep && K16 > 4 && ncb > 4) return false;   // RBW = 4 E-step only for Dz <= 9
+  return true;
+}
+
 typedef void (*fused_fn)(const KernelArgs);
 
-template <int NCB, int RBW>
-static fused_fn pick_mode(int mode) {
+constexpr int ncb_of(int D) { return ((D + 1) * (D + 2) / 2 + 15) / 16; }
+
+// E-step modes: one instantiation per Dz (compile-time feature map)
+template <int D, int RBW>
+static fused_fn pick_estep_mode(int mode) {
   switch (mode) {
-    case kFastVI: return fused_kernel<NCB, RBW, kFastVI>;
-    case kFastGibbs: return fused_kernel<NCB, RBW, kFastGibbs>;
-    case kGeneric: return fused_kernel<NCB, RBW, kGeneric>;
-    case kModeWeights: return fused_kernel<NCB, RBW, kModeWeights>;
-    case kModeLabels: return fused_kernel<NCB, RBW, kModeLabels>;
+    case kFastVI: return fused_kernel<ncb_of(D), RBW, kFastVI, D>;
+    case kFastGibbs: return fused_kernel<ncb_of(D), RBW, kFastGibbs, D>;
+    case kGeneric: return fused_kernel<ncb_of(D), RBW, kGeneric, D>;
   }
   return nullptr;
 }
 
 template <int RBW>
-static fused_fn pick_ncb(int ncb, int mode) {
-  switch (ncb) {
-    case 1: return pick_mode<1, RBW>(mode);
-    case 2: return pick_mode<2, RBW>(mode);
-    case 3: return pick_mode<3, RBW>(mode);
-    case 4: return pick_mode<4, RBW>(mode);
-    case 5: return pick_mode<5, RBW>(mode);
-    case 6: return pick_mode<6, RBW>(mode);
-    case 7: return pick_mode<7, RBW>(mode);
-    case 8: return pick_mode<8, RBW>(mode);
-    case 9: return pick_mode<9, RBW>(mode);
-    case 10: return pick_mode<10, RBW>(mode);
+static fused_fn pick_estep(int D, int mode) {
+  switch (D) {
+    case 1: return pick_estep_mode<1, RBW>(mode);
+    case 2: return pick_estep_mode<2, RBW>(mode);
+    case 3: return pick_estep_mode<3, RBW>(mode);
+    case 4: return pick_estep_mode<4, RBW>(mode);
+    case 5: return pick_estep_mode<5, RBW>(mode);
+    case 6: return pick_estep_mode<6, RBW>(mode);
+    case 7: return pick_estep_mode<7, RBW>(mode);
+    case 8: return pick_estep_mode<8, RBW>(mode);
+    case 9: return pick_estep_mode<9, RBW>(mode);
+    default: break;
+  }
+  if constexpr (RBW == 1) {
+    switch (D) {
+      case 10: return pick_estep_mode<10, 1>(mode);
+      case 11: return pick_estep_mode<11, 1>(mode);
+      case 12: return pick_estep_mode<12, 1>(mode);
+      case 13: return pick_estep_mode<13, 1>(mode);
+      case 14: return pick_estep_mode<14, 1>(mode);
+      case 15: return pick_estep_mode<15, 1>(mode);
+      case 16: return pick_estep_mode<16, 1>(mode);
+    }
   }
   return nullptr;
 }
 
-// RBW = 4 E-step variants are built for NCB <= 4 (Dz <= 9); statistics-only modes for every NCB.
-static fused_fn pick_rbw4(int ncb, int mode) {
-  if (mode == kModeWeights || mode == kModeLabels) {
-    switch (ncb) {
-      case 1: return mode == kModeWeights ? fused_kernel<1, 4, kModeWeights> : fused_kernel<1, 4, kModeLabels>;
-      case 2: return mode == kModeWeights ? fused_kernel<2, 4, kModeWeights> : fused_kernel<2, 4, kModeLabels>;
-      case 3: return mode == kModeWeights ? fused_kernel<3, 4, kModeWeights> : fused_kernel<3, 4, kModeLabels>;
-      case 4: return mode == kModeWeights ? fused_kernel<4, 4, kModeWeights> : fused_kernel<4, 4, kModeLabels>;
-      case 5: return mode == kModeWeights ? fused_kernel<5, 4, kModeWeights> : fused_kernel<5, 4, kModeLabels>;
-      case 6: return mode == kModeWeights ? fused_kernel<6, 4, kModeWeights> : fused_kernel<6, 4, kModeLabels>;
-      case 7: return mode == kModeWeights ? fused_kernel<7, 4, kModeWeights> : fused_kernel<7, 4, kModeLabels>;
-      case 8: return mode == kModeWeights ? fused_kernel<8, 4, kModeWeights> : fused_kernel<8, 4, kModeLabels>;
-      case 9: return mode == kModeWeights ? fused_kernel<9, 4, kModeWeights> : fused_kernel<9, 4, kModeLabels>;
-      case 10: return mode == kModeWeights ? fused_kernel<10, 4, kModeWeights> : fused_kernel<10, 4, kModeLabels>;
-    }
-    return nullptr;
-  }
+// statistics modes: table-driven feature build, one instantiation per column-block count
+template <int RBW>
+static fused_fn pick_stats(int ncb, int mode) {
+#define MIMO_STATS_CASE(n) case n: return mode == kModeWeights ? fused_kernel<n, RBW, kModeWeights> : fused_kernel<n, RBW, kModeLabels>;
   switch (ncb) {
-    case 1: return pick_mode<1, 4>(mode);
-    case 2: return pick_mode<2, 4>(mode);
-    case 3: return pick_mode<3, 4>(mode);
-    case 4: return pick_mode<4, 4>(mode);
+    MIMO_STATS_CASE(1) MIMO_STATS_CASE(2) MIMO_STATS_CASE(3) MIMO_STATS_CASE(4) MIMO_STATS_CASE(5)
+    MIMO_STATS_CASE(6) MIMO_STATS_CASE(7) MIMO_STATS_CASE(8) MIMO_STATS_CASE(9) MIMO_STATS_CASE(10)
   }
+#undef MIMO_STATS_CASE
   return nullptr;
 }
 
@@ -729,8 +806,10 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   int mode = src == kSrcWeights ? kModeWeights : src == kSrcLabels ? kModeLabels : kGeneric;
   if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse) mode = a.gibbs ? kFastGibbs : kFastVI;
   fused_fn fn = nullptr;
-  if (a.K16 <= 16 && ncb >= 1 && ncb <= kMaxNCB)
-    fn = rbw_for(a.K16) == 1 ? pick_ncb<1>(ncb, mode) : pick_rbw4(ncb, mode);
+  if (fused_covers(a.K16, ncb, src)) {
+    if (src == kSrcEstep) fn = rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
+    else fn = rbw_for(a.K16) == 1 ? pick_stats<1>(ncb, mode) : pick_stats<4>(ncb, mode);
+  }
   if (!fn) { *unsupported = true; return hipSuccess; }
   const size_t lds = fused_lds_bytes(a);
   if (lds > 160 * 1024) { *unsupported = true; return hipSuccess; }
@@ -739,12 +818,6 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, a);
   return hipGetLastError();
-}
-
-bool fused_covers(int K16, int ncb, int src) {
-  if (K16 > 16 || ncb < 1 || ncb > kMaxNCB) return false;
-  if (src == kSrcEstep && K16 > 4 && ncb > 4) return false;   // RBW = 4 E-step only for Dz <= 9
-  return true;
 }
 
 size_t chunked_lds_bytes(const KernelArgs& a) {
