@@ -285,7 +285,89 @@ def ilr_case(name, N, dx, dy, K, kind, seed, vi_iters=20):
     print(name, "ok")
 
 
+def driver_traces_case(name, N, D, K, kind, seed, iters=8):
+    """EM (gmm.py:77-103), MAP (gmm.py:176-204) and SVI (gmm.py:300-326) traces with fixed seeds
+    (numpy.random for responsibilities / parameter draws, random for the minibatch indices)."""
+    import random
+    from mimo.distributions import Categorical, StackedGaussiansWithPrecision
+    from mimo.mixtures import MixtureOfGaussians
+    npr.seed(seed)
+    X = make_data(N, D)
+    out = dict(X=X, gating_kind=np.array(kind), K=np.array(K), D=np.array(D), seed=np.array(seed), iters=np.array(iters))
+    # EM from seeded random responsibilities
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=StackedGaussiansWithPrecision(size=K, dim=D))
+    npr.seed(seed + 10)
+    out["em_loglik"] = np.array(lik.max_likelihood(X.copy(), randomize=True, maxiter=iters, progress_bar=False))
+    out["em_mus"], out["em_lmbdas"], out["em_probs"] = lik.components.mus, lik.components.lmbdas, np.array(lik.gating.probs)
+
+    def fresh():
+        gating = make_gating(K, kind)
+        prior = StackedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K,)),
+                                      psis=np.stack(K * [np.eye(D)]), nus=(D + 3.) * np.ones((K,)))
+        comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior)
+        return BayesianMixtureOfGaussians(gating=gating, components=comps)
+    npr.seed(seed + 20)
+    m = fresh()
+    put(out, "prior", nw_params(m.components.prior))
+    put(out, "gprior", gating_params(m.gating.prior, kind))
+    if kind == 'dirichlet':
+        m.gating.prior.alphas = 2. * np.ones(K)          # mode() needs alphas > 1
+        m.gating.posterior.alphas = 2. * np.ones(K)
+        out["gprior_alphas"] = m.gating.prior.alphas
+        npr.seed(seed + 21)
+        out["map_logprob"] = np.array(m.max_aposteriori(X.copy(), randomize=True, maxiter=iters, progress_bar=False))
+        out["map_mus"] = m.components.likelihood.mus
+    # SVI
+    npr.seed(seed + 30)
+    m = fresh()
+    if kind == 'dirichlet':
+        m.gating.prior.alphas = 2. * np.ones(K)
+        m.gating.posterior.alphas = 2. * np.ones(K)
+    npr.seed(seed + 31); random.seed(seed + 32)
+    out["svi_vlb"] = np.array(m.meanfield_stochastic_descent(X.copy(), randomize=True, maxiter=iters, step_size=5e-2,
+                                                             batch_size=64, progress_bar=False))
+    put(out, "svi_post", nw_params(m.components.posterior))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
+def ilr_svi_case(name, N, dx, dy, K, seed, iters=6):
+    """ILR SVI trace (ilr.py:245-277) — what examples/ilr/evaluate_*.py run by default."""
+    import random
+    npr.seed(seed)
+    X = make_data(N, dx)
+    Atrue = npr.randn(4, dy, dx)
+    Y = np.ascontiguousarray(np.einsum('ndl,nl->nd', Atrue[npr.randint(4, size=N)], X) + 0.3 * npr.randn(N, dy))
+    dc = dx + 1
+    gating = make_gating(K, 'stick')
+    bprior = StackedNormalWisharts(size=K, dim=dx, mus=np.zeros((K, dx)), kappas=1e-2 * np.ones((K,)),
+                                   psis=np.stack(K * [1e2 * np.eye(dx)]), nus=(dx + 1.) * np.ones((K,)) + 1e-16)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior)
+    mprior = StackedMatrixNormalWisharts(K, dc, dy, Ms=np.zeros((K, dy, dc)), Ks=np.stack(K * [1e-2 * np.eye(dc)]),
+                                         psis=np.stack(K * [np.eye(dy)]), nus=(dy + 1.) * np.ones((K,)) + 1e-16)
+    models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dc, dy, mprior, affine=True)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis, models=models)
+    out = dict(X=X, Y=Y, gating_kind=np.array('stick'), K=np.array(K), seed=np.array(seed), iters=np.array(iters))
+    put(out, "bprior", nw_params(ilr.basis.prior)); put(out, "mprior", mnw_params(ilr.models.prior))
+    put(out, "gprior", gating_params(ilr.gating.prior, 'stick'))
+    ilr.init_transform(X, Y)
+    npr.seed(seed + 1); random.seed(seed + 2)
+    ilr.resample(X.copy(), Y.copy(), init_labels='random', maxiter=3, progress_bar=False)
+    out["gibbs_probs"] = np.array(ilr.gating.likelihood.probs)
+    out["gibbs_As"] = ilr.models.likelihood.As
+    vlb = ilr.meanfield_stochastic_descent(X.copy(), Y.copy(), randomize=False, maxiter=iters, step_size=5e-1,
+                                           batch_size=64, progress_bar=False)
+    out["svi_vlb"] = np.array(vlb)
+    put(out, "svi_mpost", mnw_params(ilr.models.posterior))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "drivers":
+        driver_traces_case("drivers_d3_k5_dir", N=600, D=3, K=5, kind='dirichlet', seed=1347)
+        ilr_svi_case("ilr_svi_dx2_dy1_k8", N=500, dx=2, dy=1, K=8, seed=1348)
+        sys.exit(0)
     # fixture-size versions of BASELINE.json configs C1..C5 (true D; K capped for file size, one full-K case)
     gmm_case("gmm_c1_d2_k4_dir", N=257, D=2, K=4, kind='dirichlet', seed=1337)
     gmm_case("gmm_c2_d16_k16_dir", N=257, D=16, K=16, kind='dirichlet', seed=1338)
@@ -297,3 +379,5 @@ if __name__ == "__main__":
     ilr_case("ilr_dx1_dy1_k6_dir", N=300, dx=1, dy=1, K=6, kind='dirichlet', seed=1344)
     gibbs_trace_case("gibbs_c1_trace", N=500, D=2, K=4, kind='dirichlet', seed=1345)
     gibbs_trace_case("gibbs_stick_trace", N=400, D=3, K=6, kind='stick', seed=1346)
+    driver_traces_case("drivers_d3_k5_dir", N=600, D=3, K=5, kind='dirichlet', seed=1347)
+    ilr_svi_case("ilr_svi_dx2_dy1_k8", N=500, dx=2, dy=1, K=8, seed=1348)

@@ -204,3 +204,57 @@ def check_ilr_vi_trace(name, engine, tol=1e-7):
     assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
     for a, b in zip(ilr.models.posterior.params, mnw_of(g, "vi_mpost")):
         assert rel_err(a, b) < 1e-5
+
+
+def check_driver_traces(name, engine, tol=1e-8):
+    """EM / MAP / SVI drivers against seeded traces of the reference (gmm.py:77-103,176-204,300-326)."""
+    import random
+    from mimo_amd.distributions import Categorical, StackedGaussiansWithPrecision
+    from mimo_amd.mixtures import MixtureOfGaussians
+    g = load_golden(name)
+    X, K, D, seed, iters = g["X"], int(g["K"]), int(g["D"]), int(g["seed"]), int(g["iters"])
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=StackedGaussiansWithPrecision(K, D, engine=engine),
+                             engine=engine)
+    npr.seed(seed + 10)
+    ll = lik.max_likelihood(X, randomize=True, maxiter=iters, progress_bar=False)
+    assert rel_err(np.array(ll), g["em_loglik"]) < tol
+    assert rel_err(lik.components.mus, g["em_mus"]) < 1e-6 and rel_err(lik.gating.probs, g["em_probs"]) < 1e-6
+    assert np.all(np.diff(ll) >= -1e-8 * abs(ll[-1]))          # EM log-likelihood monotone (em_toy.py:47)
+
+    def fresh():
+        kind, gating = make_gating(g, K)
+        prior = StackedNormalWisharts(size=K, dim=D, **{k: g["prior_" + k] for k in ("mus", "kappas", "psis", "nus")})
+        comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior, engine=engine)
+        return BayesianMixtureOfGaussians(gating=gating, components=comps, engine=engine)
+    m = fresh()
+    npr.seed(seed + 21)
+    lp = m.max_aposteriori(X, randomize=True, maxiter=iters, progress_bar=False)
+    assert rel_err(np.array(lp), g["map_logprob"]) < tol
+    assert rel_err(m.components.likelihood.mus, g["map_mus"]) < 1e-6
+
+    m = fresh()
+    npr.seed(seed + 31)
+    random.seed(seed + 32)
+    vlb = m.meanfield_stochastic_descent(X, randomize=True, maxiter=iters, step_size=5e-2, batch_size=64,
+                                         progress_bar=False)
+    assert rel_err(np.array(vlb), g["svi_vlb"]) < tol
+    for a, b in zip(m.components.posterior.params, nw_of(g, "svi_post")):
+        assert rel_err(a, b) < 1e-7
+
+
+def check_ilr_svi(name, engine, tol=1e-7):
+    """ILR: scaling transform + seeded Gibbs warm-up + SVI, as examples/ilr/evaluate_*.py run it."""
+    import random
+    g = load_golden(name)
+    kind, ilr = build_ilr(g, engine)
+    ilr.init_transform(g["X"], g["Y"])
+    npr.seed(int(g["seed"]) + 1)
+    random.seed(int(g["seed"]) + 2)
+    ilr.resample(g["X"], g["Y"], init_labels='random', maxiter=3, progress_bar=False)
+    assert rel_err(ilr.gating.likelihood.probs, g["gibbs_probs"]) < 1e-9
+    assert rel_err(ilr.models.likelihood.As, g["gibbs_As"]) < 1e-7
+    vlb = ilr.meanfield_stochastic_descent(g["X"], g["Y"], randomize=False, maxiter=int(g["iters"]), step_size=5e-1,
+                                           batch_size=64, progress_bar=False)
+    assert rel_err(np.array(vlb), g["svi_vlb"]) < tol
+    for a, b in zip(ilr.models.posterior.params, mnw_of(g, "svi_mpost")):
+        assert rel_err(a, b) < 1e-6

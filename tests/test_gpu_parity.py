@@ -37,6 +37,14 @@ def test_ilr_vi_trace(name, engine):
     mc.check_ilr_vi_trace(name, engine)
 
 
+def test_em_map_svi_driver_traces(engine):
+    mc.check_driver_traces("drivers_d3_k5_dir", engine)
+
+
+def test_ilr_scaled_gibbs_then_svi(engine):
+    mc.check_ilr_svi("ilr_svi_dx2_dy1_k8", engine)
+
+
 def test_unsupported_shapes_fail_loudly(engine):
     from mimo_amd import _lib
     with pytest.raises(_lib.MimoHipError):

@@ -32,6 +32,14 @@ def test_ilr_vi_trace(name):
     mc.check_ilr_vi_trace(name, OracleEngine())
 
 
+def test_em_map_svi_driver_traces():
+    mc.check_driver_traces("drivers_d3_k5_dir", OracleEngine())
+
+
+def test_ilr_scaled_gibbs_then_svi():
+    mc.check_ilr_svi("ilr_svi_dx2_dy1_k8", OracleEngine())
+
+
 def test_batched_samplers_match_the_reference_law():
     """The batched (Generator) Normal-Wishart / Matrix-Normal-Wishart samplers of the fast Gibbs path
     have the same first two moments as the reference-order samplers."""
