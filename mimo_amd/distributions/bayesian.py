@@ -13,11 +13,9 @@ import copy
 
 import numpy as np
 
-from mimo_amd.utils.abstraction import Statistics as Stats
-from mimo_amd import engine as _engine
 from mimo_amd.distributions.gating import Categorical
 from mimo_amd.distributions.gaussian import StackedGaussiansWithPrecision
-from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision, joint_rows
+from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision
 
 
 def stick_acc_counts(counts):

@@ -22,7 +22,6 @@ from tqdm import tqdm
 from mimo_amd import engine as _engine
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
-from mimo_amd.distributions.bayesian import CategoricalWithDirichlet, CategoricalWithStickBreaking  # noqa: F401
 
 
 def _component_stats(S):

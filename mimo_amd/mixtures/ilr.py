@@ -45,17 +45,6 @@ def embed_joint(basis_cbw, models_cbw, gating_log, dx):
     return c1 + c2 + gating_log, b, W
 
 
-def embed_basis(basis_cbw, dz):
-    """The input-density term alone, zero-padded to z-space (for the per-block ELBO pieces)."""
-    c1, b1, W1 = basis_cbw
-    K, dx = b1.shape
-    W = np.zeros((K, dz, dz))
-    b = np.zeros((K, dz))
-    W[:, :dx, :dx] = W1
-    b[:, :dx] = b1
-    return c1, b, W
-
-
 class MixtureOfLinearGaussians:
     """reference: mimo/mixtures/ilr.py:21-84"""
 
