@@ -264,6 +264,14 @@ def main():
                                  "frac_of_8TBs": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "kernel_evals_per_s": N * K / (k_ms * 1e-3),
         }
+        try:     # HBM bytes per launch measured with rocprofv3 PMC counters for this workload (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                t = json.load(f).get(args.config)
+            if t and not args.rows:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_hbm_traffic.json"
+        except Exception:
+            pass
         if vlb and vlb[0] is not None:
             out["elbo_first_last"] = [float(vlb[0]), float(vlb[-1])]
         if world == 1 and not args.no_cpu_baseline and mode == "vi":
