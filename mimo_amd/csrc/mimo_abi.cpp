@@ -152,7 +152,8 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   memset(a, 0, sizeof *a);
   a->Z = ctx->Z; a->N = ctx->N; a->D = ctx->D; a->K = K; a->K16 = (K + 15) / 16;
   a->F16 = ctx->F16;
-  a->ZS = (ctx->D + 2) | 1;
+  a->ZS = (ctx->D + 2) | 1;      // odd stride: conflict-free row reads
+  if (a->K16 > 12) a->ZS = ctx->D + 2;   // K > 192: every byte counts to keep two workgroups per CU (<= 80 KB each)
   a->RS = ctx->F16 + 1;   // odd stride: conflict-free under the ds_read2_b64 / ds_write2_b64 banking the compiler emits
   a->F16_total = ctx->F16;
   a->cb0 = 0;

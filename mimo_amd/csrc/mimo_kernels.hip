@@ -38,11 +38,16 @@
 #include "mimo_kernels.h"
 
 #include <math.h>
+#include <type_traits>
 #include <utility>
 
 namespace mimo {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+#ifndef MIMO_EXP_CHAINS
+#define MIMO_EXP_CHAINS 8   // independent exp chains the normalise phase keeps in flight (register-array variant)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  key = (seed_lo, seed_hi), counter = (row_lo, row_hi,
@@ -152,7 +157,8 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
                                                const double* __restrict__ etab, const int K, const int K16,
                                                const int64_t N, const int64_t n0, const int wave, const int lane,
                                                const bool gibbs, double* const out_logp, double* const out_resp,
-                                               double* const out_lse, double& sc_lse, double& sc_rl, double& sc_prod) {
+                                               double* const out_lse, double& sc_lse, double& sc_rl, double& sc_prod,
+                                               int* __restrict__ labs) {
         constexpr int CPM = 8 * RBW;  // most components a lane can own (Kpad <= 64 * RBW)
         const int pt = 8 * wave + (lane & 7), part = lane >> 3;
         const int CPP = 2 * K16, k0 = part * CPP;
@@ -183,7 +189,7 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           x[c] = exp_nonpos(lc - m, etab);              // inactive slots: l = -inf -> 0
           ssum += x[c];
           if constexpr (MODE == kGeneric) sel = fma(x[c], (c < CPP && k0 + c < K) ? lc : 0.0, sel);
-          if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 chains in flight bound the temporaries
+          if (MIMO_EXP_CHAINS < 8 && (c & (MIMO_EXP_CHAINS - 1)) == MIMO_EXP_CHAINS - 1) __builtin_amdgcn_sched_barrier(0);   // bounded ILP
         }
         ssum += __shfl_xor(ssum, 8);
         ssum += __shfl_xor(ssum, 16);
@@ -229,12 +235,14 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
               if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c];
           }
         } else {
-          // inverse-CDF draw (mimo/utils/stats.py:10-17): p_k = exp(l_k - lse) (= e_k / sum e),
-          // cum = cumsum_k p, label = #{k : u * cum[K-1] > cum[k]}.
+          // inverse-CDF draw (mimo/utils/stats.py:10-17): label = #{k : u * cum[K-1] > cum[k]} with
+          // cum = cumsum_k exp(l_k - lse).  The count is invariant to the common factor 1/sum e, so the
+          // UNNORMALISED cumulative sums E_k = sum_{j<=k} e_j are compared with u * E_K (same labels up
+          // to last-bit ties; no per-component scaling, no one-hot table: only the label is kept).
           double cum = 0.0;
 #pragma unroll
           for (int c = 0; c < CPM; ++c) {
-            cum = fma(x[c], inv, cum);
+            cum += x[c];
             x[c] = cum;  // local inclusive cumulative sum
           }
           double incl = cum;  // inclusive scan over the 8 parts of this datum
@@ -248,28 +256,155 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           const double ctot = __shfl(excl + cum, 56 + (lane & 7));  // == last cumulative value
           const double uu = a.u ? (valid ? a.u[n] : 0.0)
                                 : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
-          const double thr = uu * ctot;
+          const double tl = uu * ctot - excl;   // threshold in this lane's local cumulative scale
           int cnt = 0;
 #pragma unroll
           for (int c = 0; c < CPM; ++c)
-            cnt += (c < CPP && k0 + c < K && thr > excl + x[c]) ? 1 : 0;
+            cnt += (c < CPP && k0 + c < K && tl > x[c]) ? 1 : 0;
           cnt += __shfl_xor(cnt, 8);
           cnt += __shfl_xor(cnt, 16);
           cnt += __shfl_xor(cnt, 32);
           const int label = cnt < K ? cnt : K - 1;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c)
-            if (c < CPP) row[c] = (valid && k0 + c == label) ? 1.0 : 0.0;
-          if (part == 0 && valid && a.labels) a.labels[n] = label;
+          if (part == 0) {
+            labs[pt] = valid ? label : -1;      // the statistics phase builds its one-hot operand from this
+            if (valid && a.labels) a.labels[n] = label;
+          }
         }
+}
+
+// Same contract as normalise_tile for lanes that own up to 8*RBW components (RBW > 1): the values are
+// processed in chunks of 8 that live in LDS between the passes (max / exp+sum / scale or cumulative),
+// so only 8 of them are in registers at a time.  Each lane re-reads only what it wrote itself.
+template <int RBW, int MODE>
+__device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, double* __restrict__ Lt, const int LS,
+                                                       const double* __restrict__ etab, const int K, const int K16,
+                                                       const int64_t N, const int64_t n0, const int wave,
+                                                       const int lane, const bool gibbs, double* const out_logp,
+                                                       double* const out_resp, double* const out_lse,
+                                                       double& sc_lse, double& sc_rl, double& sc_prod,
+                                                       int* __restrict__ labs) {
+  const int pt = 8 * wave + (lane & 7), part = lane >> 3;
+  const int CPP = 2 * K16, k0 = part * CPP;
+  const int64_t n = n0 + pt;
+  const bool valid = n < N;
+  double* row = Lt + pt * LS + k0;
+  auto active = [&](int c) { return c < CPP && k0 + c < K; };
+
+  double m = -INFINITY;
+#pragma unroll
+  for (int ch = 0; ch < RBW; ++ch) {
+    if (8 * ch < CPP) {
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c = 8 * ch + cc;
+        const double l = active(c) ? row[c] : -INFINITY;
+        if (out_logp && valid && active(c)) out_logp[(int64_t)(k0 + c) * N + n] = l;
+        m = fmax(m, l);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one chunk of LDS reads in flight at a time (register pressure)
+  }
+  m = fmax(m, __shfl_xor(m, 8));
+  m = fmax(m, __shfl_xor(m, 16));
+  m = fmax(m, __shfl_xor(m, 32));
+
+  double ssum = 0.0, sel = 0.0, cum = 0.0;
+#pragma unroll
+  for (int ch = 0; ch < RBW; ++ch) {
+    if (8 * ch < CPP) {
+      double x[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) x[cc] = active(8 * ch + cc) ? row[8 * ch + cc] : -INFINITY;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const double lc = x[cc];
+        x[cc] = exp_nonpos(lc - m, etab);
+        ssum += x[cc];
+        if constexpr (MODE == kGeneric) sel = fma(x[cc], active(8 * ch + cc) ? lc : 0.0, sel);
+        if ((cc & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (gibbs) {   // Gibbs keeps the running (unnormalised) cumulative sum instead of e itself
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) { cum += x[cc]; x[cc] = cum; }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc)
+        if (8 * ch + cc < CPP) row[8 * ch + cc] = x[cc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  ssum += __shfl_xor(ssum, 8);
+  ssum += __shfl_xor(ssum, 16);
+  ssum += __shfl_xor(ssum, 32);
+  if constexpr (MODE == kGeneric) {
+    sel += __shfl_xor(sel, 8);
+    sel += __shfl_xor(sel, 16);
+    sel += __shfl_xor(sel, 32);
+  }
+  double inv = __builtin_amdgcn_rcp(ssum);
+  inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+  inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+  if constexpr (MODE == kGeneric) {
+    const double lse = m + log(ssum);
+    if (part == 0 && valid) {
+      sc_lse += lse;
+      sc_rl += sel * inv;
+      if (out_lse) out_lse[n] = lse;
+    }
+  } else {
+    if (part == 0 && valid) {
+      sc_lse += m;
+      sc_prod *= ssum;
+    }
+  }
+
+  if (!gibbs) {
+    const double scale = valid ? inv : 0.0;
+#pragma unroll
+    for (int c = 0; c < 8 * RBW; ++c) {
+      if (c < CPP) {
+        const double r = row[c] * scale;
+        row[c] = r;
+        if (out_resp && valid && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = r;
+      }
+      if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // scale-invariant inverse CDF on the unnormalised cumulative sums written by the exp pass
+    double incl = cum;
+    {
+      double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
+      v = __shfl_up(incl, 16);        if (part >= 2) incl += v;
+      v = __shfl_up(incl, 32);        if (part >= 4) incl += v;
+    }
+    double excl = __shfl_up(incl, 8);
+    if (part == 0) excl = 0.0;
+    const double ctot = __shfl(excl + cum, 56 + (lane & 7));
+    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+    const double tl = uu * ctot - excl;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 8 * RBW; ++c) {
+      if (c < CPP) cnt += (k0 + c < K && tl > row[c]) ? 1 : 0;
+      if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    cnt += __shfl_xor(cnt, 8);
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    const int label = cnt < K ? cnt : K - 1;
+    if (part == 0) {
+      labs[pt] = valid ? label : -1;
+      if (valid && a.labels) a.labels[n] = label;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // Fused tile kernel.  NCB: 16-wide feature column blocks (F16 = 16*NCB); RBW: component
 // row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
 // ------------------------------------------------------------------------------------------
 template <int NCB, int RBW, int MODE, int DS = 0>
-__global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3)) ? 2 : 1)) void fused_kernel(const KernelArgs a) {
   constexpr int SRC = MODE == kModeWeights ? kSrcWeights : MODE == kModeLabels ? kSrcLabels : kSrcEstep;
   // flags fold to constants in the two fast modes
   const bool gibbs = MODE == kFastVI ? false : MODE == kFastGibbs ? true : a.gibbs != 0;
@@ -287,6 +422,7 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
   double* red = Lt + T * a.LS;                   // [16]      block-reduction scratch
   double* etab = red + 16;                       // [64]      2^(j/64) for exp_nonpos
   uint8_t* fe = reinterpret_cast<uint8_t*>(etab + 64);  // [F16][2]
+  int* labs = reinterpret_cast<int*>(red);       // [32] labels of the tile's rows (red is idle until the epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches and SGPR bases
@@ -311,8 +447,11 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
   double ring[PF];
   // scalar base of this wave's first row block + per-lane element; slice offsets are immediates
   const double* thw = a.theta + (size_t)wave * NS * 64;
+  // element order of the stream: pass h (RP row blocks at a time), contraction step s, row block i2 of the pass
+  constexpr int RP = RBW >= 2 ? 2 : 1;
   auto theta_slice = [&](int e) -> double {
-    const int s = e / RBW, i = e % RBW;
+    const int h = e / (NS * RP), rem = e % (NS * RP);
+    const int s = rem / RP, i = h * RP + rem % RP;
     return thw[(4 * i * NS + s) * 64 + lane];
   };
   const double* const thw0 = thw;
@@ -423,11 +562,7 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
         Lt[pt * LS + k] = (k < K && n < N) ? a.resp[(int64_t)k * N + n] : 0.0;
       }
     } else if constexpr (SRC == kSrcLabels) {
-      for (int e = tid; e < T * Kpad; e += kWG) {
-        const int pt = e & (T - 1), k = e >> 5;
-        const int64_t n = n0 + pt;
-        Lt[pt * LS + k] = (n < N && a.labels[n] == k) ? 1.0 : 0.0;
-      }
+      if (tid < T) labs[tid] = (n0 + tid) < N ? a.labels[n0 + tid] : -1;   // one-hot operand is built on the fly
     }
     STAMP(1);
     __builtin_amdgcn_s_setprio(0);
@@ -441,31 +576,44 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
       if (wave < K16) {   // wave-uniform (scalar) test: this wave owns at least row block `wave`
         thw = thw0;
         asm volatile("" : "+s"(thw));  // opaque per tile: slice addresses = scalar base + immediates, not 2*NE hoisted VGPRs
-        d4 acc[RBW][2];
-#pragma unroll
-        for (int i = 0; i < RBW; ++i) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
         const double* p0 = Ph + j * RS + q;
         const double* p1 = Ph + (16 + j) * RS + q;
-        double b0 = 0.0, b1 = 0.0;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const int s = e / RBW, i = e % RBW;
-          const double av = ring[e % PF];
-          ring[e % PF] = theta_slice((e + PF) % NE);   // wraps into the next tile's first slices
-          if (i == 0) { b0 = p0[4 * s]; b1 = p1[4 * s]; }
-          if (RBW == 1 || wave + 4 * i < K16) {
-            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[i][1], 0, 0, 0);
-          }
-        }
+        for (int h = 0; h < RBW / RP; ++h) {       // RP row blocks per pass bound the live accumulators
+          if (RBW == 1 || wave + 4 * h * RP < K16) {   // scalar: the pass has at least one live row block
+            d4 acc[RP][2];
 #pragma unroll
-        for (int i = 0; i < RBW; ++i) {
-          const int rb = wave + 4 * i;
-          if (rb < K16) {
+            for (int i2 = 0; i2 < RP; ++i2) { acc[i2][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i2][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+            double b0 = 0.0, b1 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              Lt[j * LS + 16 * rb + q + 4 * r] = acc[i][0][r];
-              Lt[(16 + j) * LS + 16 * rb + q + 4 * r] = acc[i][1][r];
+            for (int ee = 0; ee < NS * RP; ++ee) {   // straight-line: a dead second row block of the pass
+              const int e = h * NS * RP + ee;         // multiplies zero-padded Theta (results never stored)
+              const int s = ee / RP, i2 = ee % RP;
+              const double av = ring[e % PF];
+              ring[e % PF] = theta_slice((e + PF) % NE);   // wraps into the next tile's first slices
+              if (i2 == 0) { b0 = p0[4 * s]; b1 = p1[4 * s]; }
+              acc[i2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[i2][0], 0, 0, 0);
+              acc[i2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[i2][1], 0, 0, 0);
+            }
+            double* lw0 = Lt + j * LS + 16 * wave + q;
+            asm volatile("" : "+v"(lw0));
+            double* lw1 = lw0 + 16 * LS;
+#pragma unroll
+            for (int i2 = 0; i2 < RP; ++i2) {
+              const int i = h * RP + i2;
+              if (RBW == 1 || wave + 4 * i < K16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  lw0[64 * i + 4 * r] = acc[i2][0][r];
+                  lw1[64 * i + 4 * r] = acc[i2][1][r];
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int ee = 0; ee < NS * RP; ++ee) {   // dead pass: keep the Theta ring in step
+              const int e = h * NS * RP + ee;
+              ring[e % PF] = theta_slice((e + PF) % NE);
             }
           }
         }
@@ -476,8 +624,12 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
 
       // ---- 4. normalise over k: 8 lanes per datum, 2*K16 consecutive components per lane ----------
       __builtin_amdgcn_s_setprio(2);
-      normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
-                                sc_lse, sc_rl, sc_prod);
+      if constexpr (RBW == 1)
+        normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
+                                  sc_lse, sc_rl, sc_prod, labs);
+      else
+        normalise_tile_chunked<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp,
+                                          out_lse, sc_lse, sc_rl, sc_prod, labs);
       if constexpr (MODE != kGeneric) {
         if (++prod_tiles == 64) {   // K^64 <= 256^64 = 2^512 stays inside the float64 range
           sc_lse += log(sc_prod);
@@ -494,22 +646,58 @@ __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : 1)) void fused_kernel(const Ke
     // ---- 5. S += R . Phi ----------------------------------------------------------------
     // step s contracts the 4 rows {s, s+8, s+16, s+24}: A lane (i = j, kk = q) = R[8q+s][16rb+j],
     // B lane (kk = q, col = j) = Phi[8q+s][16cb+j].
-    if (do_stats) {
+    if (do_stats && wave < K16) {
+      // per-tile opaque bases: every operand address below is base + s * stride + immediate, instead of
+      // 8 * (RBW + 1) loop-invariant addresses the compiler would otherwise pin in (and spill from) VGPRs
+      const double* ltq = Lt + 8 * q * LS + 16 * wave + j;
+      const double* phq = Ph + 8 * q * RS + j;
+      asm volatile("" : "+v"(ltq), "+v"(phq));
+      // straight-line body for NACT active row blocks of this wave (no branch inside: LDS reads pipeline
+      // across the 8 steps); the B operand of a step is read once and reused by all NACT row blocks
+      // LAB: the weights are one-hot(labels) -> A operand = (label of row 8q+s == this lane's component)
+      auto stats_body = [&](auto nact_c, auto lab_c) {
+        constexpr int NACT = decltype(nact_c)::value;
+        constexpr bool LAB = decltype(lab_c)::value;
+        const int comp0 = 16 * wave + j;
 #pragma unroll
-      for (int i = 0; i < RBW; ++i) {
-        const int rb = wave + 4 * i;
-        if (rb < K16) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const int pt = 8 * q + s;
-            const double av = Lt[pt * LS + 16 * rb + j];
-            const double* pb = Ph + pt * RS + j;
+        for (int s = 0; s < 8; ++s) {
+          const double* lts = ltq + s * LS;
+          const double* pb = phq + s * RS;
+          int lab = 0;
+          if constexpr (LAB) lab = labs[8 * q + s];
+          if constexpr (NACT == 1) {
+            const double av = LAB ? (lab == comp0 ? 1.0 : 0.0) : lts[0];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * cb], sacc[i][cb], 0, 0, 0);
+              sacc[0][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * cb], sacc[0][cb], 0, 0, 0);
+          } else {
+            double bv[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[cb] = pb[16 * cb];
+#pragma unroll
+            for (int i = 0; i < NACT; ++i) {
+              const double av = LAB ? (lab == comp0 + 64 * i ? 1.0 : 0.0) : lts[64 * i];
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb)
+                sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[cb], sacc[i][cb], 0, 0, 0);
+            }
           }
         }
-      }
+      };
+      auto stats_nact = [&](auto lab_c) {
+        if constexpr (RBW == 1) {
+          stats_body(std::integral_constant<int, 1>{}, lab_c);
+        } else {
+          const int nact = (K16 - wave + 3) >> 2;   // scalar: row blocks wave, wave+4, ... below K16
+          if (nact >= 4) stats_body(std::integral_constant<int, 4>{}, lab_c);
+          else if (nact == 3) stats_body(std::integral_constant<int, 3>{}, lab_c);
+          else if (nact == 2) stats_body(std::integral_constant<int, 2>{}, lab_c);
+          else stats_body(std::integral_constant<int, 1>{}, lab_c);
+        }
+      };
+      if constexpr (MODE == kFastGibbs || MODE == kModeLabels) stats_nact(std::true_type{});
+      else if constexpr (MODE == kGeneric) { if (gibbs) stats_nact(std::true_type{}); else stats_nact(std::false_type{}); }
+      else stats_nact(std::false_type{});
     }
 
     // ---- 1'. stage the next tile's z~ rows (Zs was last read before the barrier after step 2)
@@ -569,6 +757,7 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
   double* Lt = Ph + T * a.RS;
   double* red = Lt + T * a.LS;
   double* etab = red + 16;
+  int* labs = reinterpret_cast<int*>(red);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -645,8 +834,12 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
       }
     }
     __syncthreads();
-    normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
-                                  sc_lse, sc_rl, sc_prod);
+    if constexpr (RBW == 1)
+      normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
+                                    sc_lse, sc_rl, sc_prod, labs);
+    else
+      normalise_tile_chunked<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp,
+                                            a.lse, sc_lse, sc_rl, sc_prod, labs);
   }
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
@@ -731,7 +924,9 @@ size_t fused_lds_bytes(const KernelArgs& a) {
 static int rbw_for(int K16) { return K16 <= 4 ? 1 : 4; }
 
 int fused_grid(const KernelArgs& a, int num_cu) {
-  const int per_cu = rbw_for(a.K16) == 1 ? 2 : 1;
+  // two workgroups per CU wherever registers (launch bounds above) and LDS (<= 80 KB each) allow
+  const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3;
+  const int per_cu = (regs2 && fused_lds_bytes(a) <= 80 * 1024) ? 2 : 1;
   int64_t g = (int64_t)num_cu * per_cu;
   if (g > a.ntiles) g = a.ntiles;
   if (g < 1) g = 1;

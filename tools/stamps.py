@@ -5,17 +5,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mimo_amd._lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmimo_hip_stamps.so")
 from mimo_amd.engine import HipEngine
-N, D, K = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000, 16, 64
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+GIBBS = len(sys.argv) > 4 and sys.argv[4] == "gibbs"
 rng = np.random.default_rng(0)
 Z = rng.standard_normal((N, D)); A = rng.standard_normal((K, D, D))
 W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D); b = rng.standard_normal((K, D)); c = rng.standard_normal(K)
 eng = HipEngine(0); eng.upload(Z)
-for _ in range(3): eng.estep(c, b, W)
+for it in range(3):
+    if GIBBS: eng.gibbs_labels(c, b, W, seed=1, sweep=it, return_labels=False)
+    else: eng.estep(c, b, W)
 out = (C.c_double * 8)()
 lib = L.load(); lib.mimo_debug_stamps.argtypes = [C.POINTER(C.c_double)]
 assert lib.mimo_debug_stamps(out) == 0
 names = ["wait B0 (top barrier)", "feature build", "wait B2", "E-step MFMA + Lt write", "wait B3", "normalise (softmax)",
          "wait B4", "stats MFMA + z staging"]
-tot = sum(out); ntile = (N + 31) // 32 / 512
+grid = 512 if (K <= 64 or D <= 8) else 256
+tot = sum(out); ntile = (N + 31) // 32 / grid
 print(f"cycles per wave per tile: total {tot/ntile:.0f}")
 for n, v in zip(names, out): print(f"  {n:28s} {v/ntile:8.0f}  {100*v/tot:5.1f}%")
