@@ -168,8 +168,10 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
 // (c, b, W) -> Theta[k][f] -> MFMA A-operand image [K16][F16/4][64] on the device.
 //   f = (D,D): c_k ; (a,D): b_k[a] ; (a,a): -W_aa/2 ; (a,b), a<b: -(W_ab + W_ba)/2
 static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, F16 = ctx->F16, NS = F16 / 4;
-  const int K16 = ((K + 15) / 16 <= 4) ? 4 : 16;   // every wave streams 1 (K<=64) or 4 row blocks; unused ones are zero
+  const int D = ctx->D, F16 = ctx->F16;
+  const int K16 = ((K + 15) / 16 <= 4) ? 4 : 16;   // every wave streams 1 (K<=64) or up to 4 row blocks; unused ones are zero
+  // fused kernels step through F16/4 slices per row block; the chunked E-step through whole chunks
+  const int NS = fused_covers((K + 15) / 16, F16 / 16, kSrcEstep) ? F16 / 4 : chunked_ns_pad(F16);
   const size_t count = (size_t)K16 * NS * 64;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
@@ -266,9 +268,10 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
       stats_src = e.gibbs ? kSrcLabels : kSrcWeights;
     }
     if (a.do_stats) {
-      for (int cb0 = 0; cb0 < ncb_total; cb0 += kMaxNCB) {
+      const int gmax = stats_group_ncb(a.K16);
+      for (int cb0 = 0; cb0 < ncb_total; cb0 += gmax) {
         KernelArgs g = st;
-        const int ncb = ncb_total - cb0 < kMaxNCB ? ncb_total - cb0 : kMaxNCB;
+        const int ncb = ncb_total - cb0 < gmax ? ncb_total - cb0 : gmax;
         g.cb0 = cb0; g.F16 = 16 * ncb; g.RS = g.F16 + 1; g.F16_total = a.F16;
         g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
         if (cb0 > 0) g.write_scalars = 0;

@@ -11,7 +11,7 @@ constexpr int kTile = 32;       // data rows per tile
 constexpr int kMaxNCB = 10;     // 16-wide feature column blocks one launch accumulates
 constexpr int kMaxFusedD = 16;  // largest Dz the single-pass fused kernels cover (F = 153 features)
 constexpr int kMaxD = 32;       // largest Dz overall (two-stage path: chunked E-step + statistics per column group)
-constexpr int kChunkNCB = 8;    // feature column blocks per chunk of the chunked E-step (128 features)
+constexpr int kChunkNCB = 9;    // feature column blocks per chunk of the chunked E-step (144 features; Dz=32 -> 4 chunks)
 
 // Where the per-tile weight table R (rows x K) comes from.
 enum Source : int { kSrcEstep = 0, kSrcWeights = 1, kSrcLabels = 2 };
@@ -60,8 +60,10 @@ int fused_grid(const KernelArgs& a, int num_cu);
 hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
 // chunked E-step for shapes outside the fused kernels (Dz > 16, or K > 64 with Dz > 9): no statistics
 size_t chunked_lds_bytes(const KernelArgs& a);
+int chunked_ns_pad(int F16);      // contraction steps of the Theta image padded to whole chunks
 hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream);
 bool fused_covers(int K16, int ncb, int src);
+int stats_group_ncb(int K16);   // feature column blocks one statistics launch can accumulate for this K
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream);

@@ -404,7 +404,8 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
 // row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
 // ------------------------------------------------------------------------------------------
 template <int NCB, int RBW, int MODE, int DS = 0>
-__global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3)) ? 2 : 1)) void fused_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3) || (MODE > kGeneric && RBW * NCB <= 12)) ? 2 : 1))
+void fused_kernel(const KernelArgs a) {
   constexpr int SRC = MODE == kModeWeights ? kSrcWeights : MODE == kModeLabels ? kSrcLabels : kSrcEstep;
   // flags fold to constants in the two fast modes
   const bool gibbs = MODE == kFastVI ? false : MODE == kFastGibbs ? true : a.gibbs != 0;
@@ -556,10 +557,20 @@ __global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3)) 
       }
     }
     if constexpr (SRC == kSrcWeights) {
-      for (int e = tid; e < T * Kpad; e += kWG) {
-        const int pt = e & (T - 1), k = e >> 5;
-        const int64_t n = n0 + pt;
-        Lt[pt * LS + k] = (k < K && n < N) ? a.resp[(int64_t)k * N + n] : 0.0;
+      // weight tile (32 rows x Kpad) from the K-major table: 8 * RBW independent loads per thread, issued
+      // back to back (a runtime-bound loop would expose one HBM round trip per iteration)
+      const int pt = tid & (T - 1), kq = tid >> 5;
+      const int64_t n = n0 + pt;
+      double wv[8 * RBW];
+#pragma unroll
+      for (int it = 0; it < 8 * RBW; ++it) {
+        const int k = kq + 8 * it;
+        wv[it] = (k < K && n < N) ? a.resp[(int64_t)k * N + n] : 0.0;
+      }
+#pragma unroll
+      for (int it = 0; it < 8 * RBW; ++it) {
+        const int k = kq + 8 * it;
+        if (k < Kpad) Lt[pt * LS + k] = wv[it];
       }
     } else if constexpr (SRC == kSrcLabels) {
       if (tid < T) labs[tid] = (n0 + tid) < N ? a.labels[n0 + tid] : -1;   // one-hot operand is built on the fly
@@ -685,10 +696,13 @@ __global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3)) 
         }
       };
       auto stats_nact = [&](auto lab_c) {
+        const int nact = (K16 - wave + 3) >> 2;   // scalar: row blocks wave, wave+4, ... below K16
         if constexpr (RBW == 1) {
           stats_body(std::integral_constant<int, 1>{}, lab_c);
+        } else if constexpr (RBW == 2) {
+          if (nact >= 2) stats_body(std::integral_constant<int, 2>{}, lab_c);
+          else stats_body(std::integral_constant<int, 1>{}, lab_c);
         } else {
-          const int nact = (K16 - wave + 3) >> 2;   // scalar: row blocks wave, wave+4, ... below K16
           if (nact >= 4) stats_body(std::integral_constant<int, 4>{}, lab_c);
           else if (nact == 3) stats_body(std::integral_constant<int, 3>{}, lab_c);
           else if (nact == 2) stats_body(std::integral_constant<int, 2>{}, lab_c);
@@ -748,15 +762,18 @@ __global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3)) 
 // HBM; the statistics then come from fused_kernel<.., kModeWeights / kModeLabels> per column group.
 // ------------------------------------------------------------------------------------------
 template <int RBW>
-__global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(const KernelArgs a) {
   constexpr int T = kTile;
   constexpr int NCBc = kChunkNCB, CF = 16 * NCBc, NSc = CF / 4;
+  constexpr int RP = RBW >= 2 ? 2 : 1, NPASS = RBW / RP, LE = NSc * RP, PF = 6;
+  static_assert(LE % PF == 0, "ring slots must line up across blocks");
   extern __shared__ __align__(16) unsigned char smem[];
   double* Zs = reinterpret_cast<double*>(smem);
   double* Ph = Zs + T * a.ZS;
   double* Lt = Ph + T * a.RS;
   double* red = Lt + T * a.LS;
   double* etab = red + 16;
+  uint8_t* fe = reinterpret_cast<uint8_t*>(etab + 64);   // [nchunk * CF][2]
   int* labs = reinterpret_cast<int*>(red);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -764,12 +781,28 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
   const int ZS = a.ZS, RS = a.RS, LS = a.LS;
-  const int NS = F16 / 4, nchunk = (F16 + CF - 1) / CF;
+  const int nchunk = (F16 + CF - 1) / CF, NSP = nchunk * NSc;   // Theta image is zero-padded to NSP steps
+  const int NB = nchunk * NPASS;                                 // (chunk, pass) blocks per tile
   const int64_t N = a.N;
   const bool gibbs = a.gibbs != 0;
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+  for (int e = tid; e < nchunk * CF * 2; e += kWG) fe[e] = e < F16 * 2 ? a.feat[e] : (uint8_t)(D + 1);
   double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
-  const int frow = tid & (T - 1), fgrp = tid >> 5;   // feature build: 8 groups x 16 features per chunk
+  const int frow = tid & (T - 1), fgrp = tid >> 5;   // feature build: 8 groups x 2*NCBc features per chunk
+
+  // Theta stream: block bl = (chunk, pass) consumes LE slices in the order (step s, row block i2 of the
+  // pass); a 6-deep register ring prefetches across block and tile boundaries.
+  const double* thw = a.theta + (size_t)wave * NSP * 64 + lane;
+  auto block_base = [&](int bl) {
+    const int ch = bl / NPASS, h = bl - ch * NPASS;
+    return thw + ((size_t)(4 * h * RP) * NSP + (size_t)ch * NSc) * 64;
+  };
+  auto slice = [&](const double* base, int ee) { return base[((size_t)(4 * (ee % RP)) * NSP + ee / RP) * 64]; };
+  double ring[PF];
+  if (wave < K16) {
+#pragma unroll
+    for (int e = 0; e < PF; ++e) ring[e] = slice(block_base(0), e);
+  }
 
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
@@ -794,30 +827,34 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
       {
         const double* zrow = Zs + frow * ZS;
         double* prow = Ph + frow * RS + fgrp * (2 * NCBc);
-        const uint8_t* ft = a.feat + 2 * (ch * CF + fgrp * 2 * NCBc);
+        const uint8_t* ft = fe + 2 * (ch * CF + fgrp * 2 * NCBc);
 #pragma unroll
-        for (int jj = 0; jj < 2 * NCBc; ++jj) {
-          const int f = ch * CF + fgrp * 2 * NCBc + jj;
-          prow[jj] = f < F16 ? zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]] : 0.0;
-        }
+        for (int jj = 0; jj < 2 * NCBc; ++jj) prow[jj] = zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]];
       }
       __syncthreads();
       if (wave < K16) {
         const double* p0 = Ph + j * RS + q;
         const double* p1 = Ph + (16 + j) * RS + q;
-#pragma unroll 4
-        for (int s = 0; s < NSc; ++s) {
-          const int sg = ch * NSc + s;
-          if (sg < NS) {
-            const double b0 = p0[4 * s], b1 = p1[4 * s];
 #pragma unroll
-            for (int i = 0; i < RBW; ++i) {
-              if (wave + 4 * i < K16) {
-                const double av = a.theta[((size_t)(wave + 4 * i) * NS + sg) * 64 + lane];
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[i][1], 0, 0, 0);
-              }
+        for (int h = 0; h < NPASS; ++h) {
+          const int bl = ch * NPASS + h;
+          const double* base = block_base(bl);
+          const double* nbase = block_base(bl + 1 == NB ? 0 : bl + 1);
+          if (RBW == 1 || wave + 4 * h * RP < K16) {
+            double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int ee = 0; ee < LE; ++ee) {
+              const int s = ee / RP, i2 = ee % RP;
+              const double av = ring[ee % PF];
+              ring[ee % PF] = ee + PF < LE ? slice(base, ee + PF) : slice(nbase, ee + PF - LE);
+              if (i2 == 0) { b0 = p0[4 * s]; b1 = p1[4 * s]; }
+              acc[h * RP + i2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[h * RP + i2][0], 0, 0, 0);
+              acc[h * RP + i2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[h * RP + i2][1], 0, 0, 0);
             }
+          } else {
+#pragma unroll
+            for (int ee = 0; ee < LE; ++ee)   // dead pass: keep the ring in step
+              ring[ee % PF] = ee + PF < LE ? slice(base, ee + PF) : slice(nbase, ee + PF - LE);
           }
         }
       }
@@ -834,12 +871,14 @@ __global__ __launch_bounds__(kWG, 1) void estep_chunked_kernel(const KernelArgs 
       }
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(2);
     if constexpr (RBW == 1)
       normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
                                     sc_lse, sc_rl, sc_prod, labs);
     else
       normalise_tile_chunked<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp,
                                             a.lse, sc_lse, sc_rl, sc_prod, labs);
+    __builtin_amdgcn_s_setprio(0);
   }
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
@@ -921,22 +960,32 @@ size_t fused_lds_bytes(const KernelArgs& a) {
   return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + 64) + (size_t)a.F16 * 2;
 }
 
+// row blocks per wave: the fused E-step kernels exist for 1 and 4; the statistics modes and the chunked
+// E-step also for 2 (K <= 128), which halves the accumulator registers they pin
 static int rbw_for(int K16) { return K16 <= 4 ? 1 : 4; }
+static int rbw_stats(int K16) { return K16 <= 4 ? 1 : K16 <= 8 ? 2 : 4; }
 
 int fused_grid(const KernelArgs& a, int num_cu) {
   // two workgroups per CU wherever registers (launch bounds above) and LDS (<= 80 KB each) allow
-  const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3;
-  const int per_cu = (regs2 && fused_lds_bytes(a) <= 80 * 1024) ? 2 : 1;
+  const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3 || a.K16 <= 8;   // (larger launches simply queue)
+  KernelArgs t = a;
+  if (t.F16 / 16 > kChunkNCB) { t.F16 = 16 * kChunkNCB; t.RS = t.F16 + 1; }   // two-stage path: per-launch feature tile
+  const int per_cu = (regs2 && fused_lds_bytes(t) <= 80 * 1024) ? 2 : 1;
   int64_t g = (int64_t)num_cu * per_cu;
   if (g > a.ntiles) g = a.ntiles;
   if (g < 1) g = 1;
   return (int)g;
 }
 
+static int rbw_stats(int K16);
+
+// K > 128 runs 4 row blocks per wave: 5 column blocks (160 accumulator registers) per launch, else 10
+int stats_group_ncb(int K16) { return rbw_stats(K16) == 4 ? 5 : kMaxNCB; }
+
 bool fused_covers(int K16, int ncb, int src) {
   if (K16 > 16 || ncb < 1 || ncb > kMaxNCB) return false;
-  if (src == kSrcEstep && K16 > 4 && ncb > 4) return false;   // RBW = 4 E-step only for Dz <= 9
-  return true;
+  if (src == kSrcEstep) return K16 <= 4 || ncb <= 4;   // RBW = 4 E-step only for Dz <= 9
+  return ncb <= stats_group_ncb(K16);
 }
 
 typedef void (*fused_fn)(const KernelArgs);
@@ -1003,7 +1052,8 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   fused_fn fn = nullptr;
   if (fused_covers(a.K16, ncb, src)) {
     if (src == kSrcEstep) fn = rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
-    else fn = rbw_for(a.K16) == 1 ? pick_stats<1>(ncb, mode) : pick_stats<4>(ncb, mode);
+    else fn = rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
+            : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
   }
   if (!fn) { *unsupported = true; return hipSuccess; }
   const size_t lds = fused_lds_bytes(a);
@@ -1015,13 +1065,20 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   return hipGetLastError();
 }
 
+int chunked_ns_pad(int F16) {
+  const int CF = 16 * kChunkNCB;
+  return (F16 + CF - 1) / CF * (CF / 4);
+}
+
 size_t chunked_lds_bytes(const KernelArgs& a) {
-  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + 64);
+  const int CF = 16 * kChunkNCB, nchunk = (a.F16 + CF - 1) / CF;
+  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + 64) + (size_t)nchunk * CF * 2;
 }
 
 hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  fn_t fn = rbw_for(a.K16) == 1 ? estep_chunked_kernel<1> : estep_chunked_kernel<4>;
+  fn_t fn = rbw_stats(a.K16) == 1 ? estep_chunked_kernel<1>
+            : rbw_stats(a.K16) == 2 ? estep_chunked_kernel<2> : estep_chunked_kernel<4>;
   const size_t lds = chunked_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
