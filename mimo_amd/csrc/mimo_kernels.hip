@@ -14,21 +14,23 @@
 // categorical draw over k sits between the two products and never leaves LDS.  A workgroup
 // (4 wavefronts) walks a grid-stride sequence of 32-row tiles:
 //
-//   1. coalesced read of the (32, D) tile of Z into LDS                      (only HBM read)
+//   1. coalesced read of the (32, D) tile of Z into LDS (the next tile is prefetched into registers)
 //   2. feature tile Phi (32 x F16) built once in LDS, shared by all waves and both products
-//   3. L tile = Theta.Phi': Theta's MFMA A-operand slices live in registers for the whole
-//      kernel (wave w owns component row-blocks w, w+4, ...)
+//   3. L tile = Theta.Phi': Theta's MFMA A-operand slices stream from the L2-resident operand image
+//      through a small register ring (wave w owns component row-blocks w, w+4, ...)
 //   4. per-datum normalisation over k (8 lanes per datum): softmax -> r, or inverse-CDF
-//      categorical draw (host uniforms or in-kernel Philox4x32-10) -> one-hot r
+//      categorical draw (host uniforms or in-kernel Philox4x32-10) -> label
 //   5. S += R.Phi accumulated in registers across all tiles of the workgroup
 //
 // Per-workgroup partial S blocks are written once at the end and summed in a fixed order by
 // reduce_partials (no float atomics: results are run-to-run identical).
 //
-// LDS bank layout (MI355X_MICROARCH.md, LDS): ds_read_b64 is serviced per 32-lane half over
-// 64 dword banks.  The feature tile row stride RS = F16 + 2 doubles (RS = 2 mod 4) makes both
-// MFMA operand reads conflict-free: step 3 reads Phi[row j][4s + q] (16 rows x 2 features per
-// half), step 5 reads Phi[row 8q + s][16cb + j] (2 rows 8 apart x 16 features per half).
+// The float64 VALU shares its pipe with the float64 MFMA on gfx950 (tools/f64_rates.hip), so the
+// non-matrix phases are written for few, independent f64 instructions; see DESIGN.md section 4.
+//
+// LDS bank layout (MI355X_MICROARCH.md, LDS): the feature tile row stride RS = F16 + 1 doubles (odd) is
+// conflict-free under the ds_read2_b64 / ds_write2_b64 forms hipcc emits for both MFMA operand patterns:
+// step 3 reads Phi[row j][4s + q], step 5 reads Phi[row 8q + s][16cb + j].
 //
 // Reference behaviour reproduced (paths relative to the reference root):
 //   mimo/distributions/gaussian.py:510-521, bayesian.py:287-301, lingauss.py:330-345,
