@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -67,6 +68,12 @@ struct mimo_ctx {
 };
 
 static std::string g_err;
+
+// feature-tile row padding (doubles); MIMO_RS_PAD overrides for bank-conflict experiments
+static int rs_pad() {
+  static const int v = [] { const char* e = getenv("MIMO_RS_PAD"); return e ? atoi(e) : 1; }();
+  return v;
+}
 #ifdef MIMO_STAMPS
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_grid = 0;
@@ -154,7 +161,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->F16 = ctx->F16;
   a->ZS = (ctx->D + 2) | 1;      // odd stride: conflict-free row reads
   if (a->K16 > 12) a->ZS = ctx->D + 2;   // K > 192: every byte counts to keep two workgroups per CU (<= 80 KB each)
-  a->RS = ctx->F16 + 1;   // odd stride: conflict-free under the ds_read2_b64 / ds_write2_b64 banking the compiler emits
+  a->RS = ctx->F16 + rs_pad();
   a->F16_total = ctx->F16;
   a->cb0 = 0;
   a->write_scalars = 1;

@@ -46,6 +46,9 @@
 namespace mimo {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// explicit global address space: a generic pointer that went through an opaque asm loads with flat_load,
+// which also counts on lgkmcnt and would make every LDS-operand wait an L2 round trip
+typedef const double __attribute__((address_space(1)))* gptr_t;
 
 #ifndef MIMO_EXP_CHAINS
 #define MIMO_EXP_CHAINS 8   // independent exp chains the normalise phase keeps in flight (register-array variant)
@@ -415,7 +418,9 @@ void fused_kernel(const KernelArgs a) {
   double* const out_resp = MODE == kGeneric ? a.resp : nullptr;
   double* const out_lse = MODE == kGeneric ? a.lse : nullptr;
   const bool do_stats = (MODE == kFastVI || MODE == kFastGibbs) ? true : a.do_stats != 0;
-  constexpr int NS = 4 * NCB;  // contraction steps of 4 features
+  constexpr int NSI = 4 * NCB;  // contraction steps of 4 features in the Theta image (row-block stride)
+  // steps actually needed: with Dz known at compile time the zero-padded tail of the last column block is skipped
+  constexpr int NS = DS > 0 ? ((DS + 1) * (DS + 2) / 2 + 3) / 4 : NSI;
   constexpr int T = kTile;
 
   extern __shared__ __align__(16) unsigned char smem[];
@@ -447,17 +452,22 @@ void fused_kernel(const KernelArgs a) {
   // consumed and wrapping into the next tile, instead of pinning 2*NS*RBW VGPRs.
   constexpr int NE = NS * RBW;
   constexpr int PF = NE < 8 ? NE : 8;
+  // The stream is padded to NEP (a multiple of the ring depth) with dummy refills, so that element e of
+  // EVERY tile sits in slot e % PF (otherwise the wrap-around prefetch lands one tile's first slices in
+  // the wrong slots whenever NE % PF != 0).
+  constexpr int NEP = (NE + PF - 1) / PF * PF;
   double ring[PF];
   // scalar base of this wave's first row block + per-lane element; slice offsets are immediates
-  const double* thw = a.theta + (size_t)wave * NS * 64;
+  gptr_t thw = (gptr_t)(a.theta + (size_t)wave * NSI * 64);
   // element order of the stream: pass h (RP row blocks at a time), contraction step s, row block i2 of the pass
   constexpr int RP = RBW >= 2 ? 2 : 1;
   auto theta_slice = [&](int e) -> double {
+    if (e >= NE) e = 0;   // padding element: any valid slice, never consumed
     const int h = e / (NS * RP), rem = e % (NS * RP);
     const int s = rem / RP, i = h * RP + rem % RP;
-    return thw[(4 * i * NS + s) * 64 + lane];
+    return thw[(4 * i * NSI + s) * 64 + lane];
   };
-  const double* const thw0 = thw;
+  const gptr_t thw0 = thw;
   if constexpr (SRC == kSrcEstep) {
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = theta_slice(e);
@@ -597,19 +607,27 @@ void fused_kernel(const KernelArgs a) {
             d4 acc[RP][2];
 #pragma unroll
             for (int i2 = 0; i2 < RP; ++i2) { acc[i2][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i2][1] = d4{0.0, 0.0, 0.0, 0.0}; }
-            double b0 = 0.0, b1 = 0.0;
+            // B operands are read two contraction steps ahead of their MFMAs (an LDS read is ~2-3 MFMA
+            // issue slots away); sched_barriers keep hipcc from sinking the reads back to their use
+            double bq0[3], bq1[3];
+            bq0[0] = p0[0]; bq1[0] = p1[0];
+            if (NS > 1) { bq0[1] = p0[4]; bq1[1] = p1[4]; }
 #pragma unroll
-            for (int ee = 0; ee < NS * RP; ++ee) {   // straight-line: a dead second row block of the pass
-              const int e = h * NS * RP + ee;         // multiplies zero-padded Theta (results never stored)
-              const int s = ee / RP, i2 = ee % RP;
-              const double av = ring[e % PF];
-              ring[e % PF] = theta_slice((e + PF) % NE);   // wraps into the next tile's first slices
-              if (i2 == 0) { b0 = p0[4 * s]; b1 = p1[4 * s]; }
-              acc[i2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[i2][0], 0, 0, 0);
-              acc[i2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[i2][1], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) {     // straight-line: a dead second row block of the pass
+              if (s + 2 < NS) { bq0[(s + 2) % 3] = p0[4 * (s + 2)]; bq1[(s + 2) % 3] = p1[4 * (s + 2)]; }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i2 = 0; i2 < RP; ++i2) {   // multiplies zero-padded Theta (results never stored)
+                const int e = h * NS * RP + s * RP + i2;
+                const double av = ring[e % PF];
+                ring[e % PF] = theta_slice((e + PF) % NEP);   // wraps into the next tile's first slices
+                acc[i2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq0[s % 3], acc[i2][0], 0, 0, 0);
+                acc[i2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq1[s % 3], acc[i2][1], 0, 0, 0);
+              }
             }
-            double* lw0 = Lt + j * LS + 16 * wave + q;
-            asm volatile("" : "+v"(lw0));
+            int lw_off = j * LS + 16 * wave + q;
+            asm volatile("" : "+v"(lw_off));
+            double* lw0 = Lt + lw_off;
             double* lw1 = lw0 + 16 * LS;
 #pragma unroll
             for (int i2 = 0; i2 < RP; ++i2) {
@@ -626,10 +644,12 @@ void fused_kernel(const KernelArgs a) {
 #pragma unroll
             for (int ee = 0; ee < NS * RP; ++ee) {   // dead pass: keep the Theta ring in step
               const int e = h * NS * RP + ee;
-              ring[e % PF] = theta_slice((e + PF) % NE);
+              ring[e % PF] = theta_slice((e + PF) % NEP);
             }
           }
         }
+#pragma unroll
+        for (int e = NE; e < NEP; ++e) ring[e % PF] = theta_slice((e + PF) % NEP);   // stream padding
       }
       STAMP(3);
       __syncthreads();
@@ -662,9 +682,12 @@ void fused_kernel(const KernelArgs a) {
     if (do_stats && wave < K16) {
       // per-tile opaque bases: every operand address below is base + s * stride + immediate, instead of
       // 8 * (RBW + 1) loop-invariant addresses the compiler would otherwise pin in (and spill from) VGPRs
-      const double* ltq = Lt + 8 * q * LS + 16 * wave + j;
-      const double* phq = Ph + 8 * q * RS + j;
-      asm volatile("" : "+v"(ltq), "+v"(phq));
+      // (the OFFSETS are made opaque, not the pointers: a pointer that went through an asm loses its LDS
+      // address space and every read would become a flat_load with a full vmcnt/lgkmcnt drain)
+      int lt_off = 8 * q * LS + 16 * wave + j, ph_off = 8 * q * RS + j;
+      asm volatile("" : "+v"(lt_off), "+v"(ph_off));
+      const double* ltq = Lt + lt_off;
+      const double* phq = Ph + ph_off;
       // straight-line body for NACT active row blocks of this wave (no branch inside: LDS reads pipeline
       // across the 8 steps); the B operand of a step is read once and reused by all NACT row blocks
       // LAB: the weights are one-hot(labels) -> A operand = (label of row 8q+s == this lane's component)
@@ -672,29 +695,29 @@ void fused_kernel(const KernelArgs a) {
         constexpr int NACT = decltype(nact_c)::value;
         constexpr bool LAB = decltype(lab_c)::value;
         const int comp0 = 16 * wave + j;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        // operands of step s+1 are read before the MFMAs of step s are issued
+        double avq[2][NACT], bvq[2][NCB];
+        auto fetch = [&](int s, int slot) {
           const double* lts = ltq + s * LS;
           const double* pb = phq + s * RS;
           int lab = 0;
           if constexpr (LAB) lab = labs[8 * q + s];
-          if constexpr (NACT == 1) {
-            const double av = LAB ? (lab == comp0 ? 1.0 : 0.0) : lts[0];
+#pragma unroll
+          for (int i = 0; i < NACT; ++i)
+            avq[slot][i] = LAB ? (lab == comp0 + 64 * i ? 1.0 : 0.0) : lts[64 * i];
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) bvq[slot][cb] = pb[16 * cb];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          if (s + 1 < 8) fetch(s + 1, (s + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NACT; ++i)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              sacc[0][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * cb], sacc[0][cb], 0, 0, 0);
-          } else {
-            double bv[NCB];
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) bv[cb] = pb[16 * cb];
-#pragma unroll
-            for (int i = 0; i < NACT; ++i) {
-              const double av = LAB ? (lab == comp0 + 64 * i ? 1.0 : 0.0) : lts[64 * i];
-#pragma unroll
-              for (int cb = 0; cb < NCB; ++cb)
-                sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[cb], sacc[i][cb], 0, 0, 0);
-            }
-          }
+              sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(avq[s & 1][i], bvq[s & 1][cb], sacc[i][cb], 0, 0, 0);
         }
       };
       auto stats_nact = [&](auto lab_c) {
@@ -794,12 +817,12 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 
   // Theta stream: block bl = (chunk, pass) consumes LE slices in the order (step s, row block i2 of the
   // pass); a 6-deep register ring prefetches across block and tile boundaries.
-  const double* thw = a.theta + (size_t)wave * NSP * 64 + lane;
+  gptr_t thw = (gptr_t)(a.theta + (size_t)wave * NSP * 64 + lane);
   auto block_base = [&](int bl) {
     const int ch = bl / NPASS, h = bl - ch * NPASS;
     return thw + ((size_t)(4 * h * RP) * NSP + (size_t)ch * NSc) * 64;
   };
-  auto slice = [&](const double* base, int ee) { return base[((size_t)(4 * (ee % RP)) * NSP + ee / RP) * 64]; };
+  auto slice = [&](gptr_t base, int ee) { return base[((size_t)(4 * (ee % RP)) * NSP + ee / RP) * 64]; };
   double ring[PF];
   if (wave < K16) {
 #pragma unroll
@@ -840,8 +863,8 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 #pragma unroll
         for (int h = 0; h < NPASS; ++h) {
           const int bl = ch * NPASS + h;
-          const double* base = block_base(bl);
-          const double* nbase = block_base(bl + 1 == NB ? 0 : bl + 1);
+          gptr_t base = block_base(bl);
+          gptr_t nbase = block_base(bl + 1 == NB ? 0 : bl + 1);
           if (RBW == 1 || wave + 4 * h * RP < K16) {
             double b0 = 0.0, b1 = 0.0;
 #pragma unroll

@@ -104,6 +104,29 @@ def test_engine_vs_oracle_seeded(engine, N, D, K):
     assert np.array_equal(engine.get_labels(), ref_p)
 
 
+@pytest.mark.parametrize("D,K", [(7, 20), (8, 33), (10, 64), (11, 5), (13, 40), (15, 64), (16, 64), (8, 200), (3, 256)])
+def test_many_tiles_per_workgroup(engine, D, K):
+    """N large enough that every workgroup walks several tiles (the Theta ring wraps from tile to tile):
+    fused E-step, Gibbs labels and statistics against the oracle for every ring geometry."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    N = 32 * 512 * 3 + 77
+    rng = np.random.default_rng(100 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0)
+    n, sx, sxx = O.packed_stats(Z, np.exp(L - lse))
+    S, sc = engine.estep(c, b, W)                       # fast mode
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-12 * abs(lse.sum())
+    S2, sc2 = engine.estep(c, b, W, keep_lse=True)      # generic mode
+    assert rel_err(S2.sxx, sxx) < 1e-11 and rel_err(engine.get_lse(), lse) < 1e-12
+    lab, S3 = engine.gibbs_labels(c, b, W, seed=3, sweep=9)
+    ref = O.sample_discrete_from_log(L, O.philox_uniforms(3, np.arange(N), 9))
+    assert np.array_equal(lab, ref) and np.array_equal(S3.n, np.bincount(ref, minlength=K))
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the

@@ -6,7 +6,7 @@ from collections import defaultdict
 acc = defaultdict(list)
 for p in glob.glob("gpurun_out/pmc_quick/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
-        if "fused_kernel<10, 1, 0>" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "fused_kernel<10, 1, 0" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print({k: sum(v)/len(v) for k, v in acc.items()})
 d = json.loads(open("gpurun_out/pmc_quick_bench.json").read().strip().splitlines()[-1]); print(d["roofline"]["kernel_ms"], d["value"])
 PY
