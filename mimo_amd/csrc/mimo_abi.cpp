@@ -77,6 +77,7 @@ static int rs_pad() {
 #ifdef MIMO_STAMPS
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_grid = 0;
+extern "C" int mimo_debug_stamps_grid() { return g_stamps_grid; }
 extern "C" int mimo_debug_stamps(double* out8) {   // mean cycles per wave of each phase, last launch
   std::vector<unsigned long long> h((size_t)g_stamps_grid * 32);
   if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -225,7 +226,7 @@ static void drain_profile(mimo_ctx* ctx) {
 static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
   const int K = a.K, D = a.D;
   const int Kpad = a.K16 * 16;
-  const int grid = fused_grid(a, ctx->num_cu);
+  const int grid = fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;

@@ -55,7 +55,7 @@ inline int feat_index(int D, int a, int b) {  // a <= b <= D
 }
 
 size_t fused_lds_bytes(const KernelArgs& a);
-int fused_grid(const KernelArgs& a, int num_cu);
+int fused_grid(const KernelArgs& a, int num_cu, int src);
 // returns hipSuccess or an error; sets *unsupported when (K, D, src) has no kernel
 hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
 // chunked E-step for shapes outside the fused kernels (Dz > 16, or K > 64 with Dz > 9): no statistics

@@ -38,6 +38,8 @@
 //   mimo/utils/stats.py:8-21 (inverse-CDF draw: label = #{k : u*cum_K > cum_k});
 //   gaussian.py:491-502, lingauss.py:306-322, categorical.py:35-43 (statistics).
 #include "mimo_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 #include <math.h>
 #include <type_traits>
@@ -990,18 +992,6 @@ size_t fused_lds_bytes(const KernelArgs& a) {
 static int rbw_for(int K16) { return K16 <= 4 ? 1 : 4; }
 static int rbw_stats(int K16) { return K16 <= 4 ? 1 : K16 <= 8 ? 2 : 4; }
 
-int fused_grid(const KernelArgs& a, int num_cu) {
-  // two workgroups per CU wherever registers (launch bounds above) and LDS (<= 80 KB each) allow
-  const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3 || a.K16 <= 8;   // (larger launches simply queue)
-  KernelArgs t = a;
-  if (t.F16 / 16 > kChunkNCB) { t.F16 = 16 * kChunkNCB; t.RS = t.F16 + 1; }   // two-stage path: per-launch feature tile
-  const int per_cu = (regs2 && fused_lds_bytes(t) <= 80 * 1024) ? 2 : 1;
-  int64_t g = (int64_t)num_cu * per_cu;
-  if (g > a.ntiles) g = a.ntiles;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
 static int rbw_stats(int K16);
 
 // K > 128 runs 4 row blocks per wave: 5 column blocks (160 accumulator registers) per launch, else 10
@@ -1068,18 +1058,54 @@ static fused_fn pick_stats(int ncb, int mode) {
   return nullptr;
 }
 
-hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream,
-                        bool* unsupported) {
-  *unsupported = false;
+static fused_fn resolve_fused(const KernelArgs& a, int src) {
   const int ncb = a.F16 / 16;
   int mode = src == kSrcWeights ? kModeWeights : src == kSrcLabels ? kModeLabels : kGeneric;
   if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse) mode = a.gibbs ? kFastGibbs : kFastVI;
-  fused_fn fn = nullptr;
-  if (fused_covers(a.K16, ncb, src)) {
-    if (src == kSrcEstep) fn = rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
-    else fn = rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
-            : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
+  if (!fused_covers(a.K16, ncb, src)) return nullptr;
+  if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
+  return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
+         : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
+}
+
+// Workgroups resident per CU for the kernel this launch resolves to (registers + LDS), from the runtime's
+// occupancy calculator; the persistent grid is sized to exactly that, capped at kMaxWGPerCU (beyond it the
+// per-workgroup partial blocks and the tail imbalance cost more than the extra latency hiding returns).
+constexpr int kMaxWGPerCU = 4;
+int fused_grid(const KernelArgs& a, int num_cu, int src) {
+  int per_cu = 0;
+  if (fused_fn fn = resolve_fused(a, src)) {
+    const size_t lds = fused_lds_bytes(a);
+    if (lds <= 160 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) == hipSuccess) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), kWG, lds) ==
+          hipSuccess)
+        per_cu = nb;
+    }
+    (void)hipGetLastError();
   }
+  if (per_cu <= 0) {   // two-stage path (or no answer): registers allow two workgroups unless RBW = 4 with wide tiles
+    const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3 || a.K16 <= 8;
+    KernelArgs t = a;
+    if (t.F16 / 16 > kChunkNCB) { t.F16 = 16 * kChunkNCB; t.RS = t.F16 + 1; }   // per-launch feature tile
+    per_cu = (regs2 && fused_lds_bytes(t) <= 80 * 1024) ? 2 : 1;
+  }
+  int cap = kMaxWGPerCU;
+  if (const char* e = getenv("MIMO_WG_PER_CU")) cap = atoi(e) > 0 ? atoi(e) : cap;   // tuning knob
+  if (per_cu > cap) per_cu = cap;
+  if (getenv("MIMO_DEBUG")) fprintf(stderr, "[mimo] fused_grid: K16=%d F16=%d src=%d -> %d workgroups/CU\n", a.K16, a.F16, src, per_cu);
+  int64_t g = (int64_t)num_cu * per_cu;
+  if (g > a.ntiles) g = a.ntiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream,
+                        bool* unsupported) {
+  *unsupported = false;
+  fused_fn fn = resolve_fused(a, src);
   if (!fn) { *unsupported = true; return hipSuccess; }
   const size_t lds = fused_lds_bytes(a);
   if (lds > 160 * 1024) { *unsupported = true; return hipSuccess; }

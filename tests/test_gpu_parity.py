@@ -104,7 +104,8 @@ def test_engine_vs_oracle_seeded(engine, N, D, K):
     assert np.array_equal(engine.get_labels(), ref_p)
 
 
-@pytest.mark.parametrize("D,K", [(7, 20), (8, 33), (10, 64), (11, 5), (13, 40), (15, 64), (16, 64), (8, 200), (3, 256)])
+@pytest.mark.parametrize("D,K", [(7, 20), (8, 33), (10, 64), (11, 5), (13, 40), (15, 64), (16, 64), (8, 200), (3, 256),
+                                 (32, 128), (20, 16), (12, 100), (16, 128), (24, 70)])
 def test_many_tiles_per_workgroup(engine, D, K):
     """N large enough that every workgroup walks several tiles (the Theta ring wraps from tile to tile):
     fused E-step, Gibbs labels and statistics against the oracle for every ring geometry."""

@@ -21,7 +21,7 @@ lib = L.load(); lib.mimo_debug_stamps.argtypes = [C.POINTER(C.c_double)]
 assert lib.mimo_debug_stamps(out) == 0
 names = ["wait B0 (top barrier)", "feature build", "wait B2", "E-step MFMA + Lt write", "wait B3", "normalise (softmax)",
          "wait B4", "stats MFMA + z staging"]
-grid = 512 if (K <= 64 or D <= 8) else 256
+grid = lib.mimo_debug_stamps_grid()
 tot = sum(out); ntile = (N + 31) // 32 / grid
 print(f"cycles per wave per tile: total {tot/ntile:.0f}")
 for n, v in zip(names, out): print(f"  {n:28s} {v/ntile:8.0f}  {100*v/tot:5.1f}%")
