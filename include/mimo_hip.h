@@ -142,6 +142,26 @@ int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, dou
  * (mimo/mixtures/gmm.py:353-355, ilr.py:310-312).  table == NULL uses the resident resp table. */
 int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int flags, double* out);
 
+/* Posterior-predictive mixture moments for every resident row x_n (Z = the inputs, Dz = dx).
+ * Replaces: BayesianMixtureOfLinearGaussians.meanfield_prediction and its helpers
+ * (mimo/mixtures/ilr.py:339-372, 374-430) together with
+ * StackedGaussiansWithNormalWisharts.log_posterior_predictive_gaussian (bayesian.py:303-313) and
+ * StackedLinearGaussiansWithMatrixNormalWisharts.posterior_predictive_gaussian (bayesian.py:949-962).
+ *   (c, b, W)[K]   canonical form of  log E[pi_k] + log N(x; basis predictive)   over x
+ *   M  (K, dy, dc) posterior mean regression matrices, dc = dx + affine (x~ = [x, 1])
+ *   Q  (K, dc, dc) cs_kn = 1 + x~' Q_k x~           (Q_k = K_k^-1)
+ *   Cc (K, dy, dy) expert predictive covariance at cs = 1:  V_kn = cs_kn Cc_k  (= (df_k psi_k)^-1)
+ *   mode 0: mixture moments  mu = sum_k w m_k, covar = sum_k w (V + m m') - mu mu'   (ilr.py:364-372)
+ *   mode 1: moments of the arg-max-weight component                                   (ilr.py:395-398)
+ *   y (N, dy), P (K, dy, dy) = Cc_k^-1, ld (K) = logdet P_k  -> nlpd (N) =
+ *       -logsumexp_k [ log N(y_n; m_kn, (P_k / cs_kn)^-1) + log(w_kn + tiny) ]        (ilr.py:405-409);
+ *       all four NULL to skip.  Outputs on the host: mu (N, dy), covar (N, dy, dy).
+ * dy <= 8; MIMO_E_UNSUPPORTED otherwise. */
+int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                 const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
+                 const double* y, const double* P, const double* ld,
+                 double* mu, double* covar, double* nlpd);
+
 /* ---- copy-outs of device-resident tables ----------------------------------------------- */
 int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
 int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);

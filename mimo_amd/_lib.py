@@ -35,6 +35,8 @@ SIGNATURES = {
     "mimo_weighted_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mimo_label_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mimo_table_entropy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _dp]),
+    "mimo_predict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                               _vp, _vp, _vp, _vp, _vp, _vp]),
     "mimo_get_resp": (C.c_int, [_vp, _vp]),
     "mimo_get_logp": (C.c_int, [_vp, _vp]),
     "mimo_get_lse": (C.c_int, [_vp, _vp]),

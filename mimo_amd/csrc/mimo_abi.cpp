@@ -561,6 +561,61 @@ int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int fl
   return MIMO_OK;
 }
 
+int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                 const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
+                 const double* y, const double* P, const double* ld,
+                 double* mu, double* covar, double* nlpd) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "mimo_predict: no data resident (call mimo_upload)");
+  if (!c || !b || !W || !M || !Q || !Cc || !mu || !covar || K < 1 || (mode != 0 && mode != 1))
+    return fail(ctx, MIMO_E_INVALID, "mimo_predict: bad arguments");
+  const bool want_nlpd = nlpd != nullptr;
+  if (want_nlpd && (!y || !P || !ld)) return fail(ctx, MIMO_E_INVALID, "mimo_predict: nlpd needs y, P and ld");
+  const int dx = ctx->D, dc = dx + (affine ? 1 : 0);
+  const int64_t N = ctx->N;
+  const size_t ng = (size_t)K * (1 + dx + (size_t)dx * dx), nM = (size_t)K * dy * dc, nQ = (size_t)K * dc * dc,
+               nC = (size_t)K * dy * dy;
+  const size_t nparam = ng + nM + nQ + 2 * nC + K;
+  const size_t nout = (size_t)N * (dy + (size_t)dy * dy + 1), nin = want_nlpd ? (size_t)N * dy : 0;
+  // parameters | outputs | y, all in the staged-weights workspace
+  if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, nparam + nout + nin + 1))) return rc;
+  std::vector<double> h(nparam);
+  double* q = h.data();
+  for (int k = 0; k < K; ++k) {
+    *q++ = c[k];
+    memcpy(q, b + (size_t)k * dx, sizeof(double) * dx); q += dx;
+    memcpy(q, W + (size_t)k * dx * dx, sizeof(double) * dx * dx); q += (size_t)dx * dx;
+  }
+  memcpy(q, M, sizeof(double) * nM); q += nM;
+  memcpy(q, Q, sizeof(double) * nQ); q += nQ;
+  memcpy(q, Cc, sizeof(double) * nC); q += nC;
+  if (want_nlpd) { memcpy(q, P, sizeof(double) * nC); memcpy(q + nC, ld, sizeof(double) * K); }
+  else memset(q, 0, sizeof(double) * (nC + K));
+  double* d = ctx->win;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h.data(), nparam * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PredictArgs a{};
+  a.Z = ctx->Z; a.N = N; a.dx = dx; a.dc = dc; a.dy = dy; a.K = K; a.mode = mode;
+  a.gate = d; a.M = d + ng; a.Q = a.M + nM; a.Cc = a.Q + nQ; a.P = a.Cc + nC; a.ld = a.P + nC;
+  double* out = d + nparam;
+  a.mu = out; a.covar = out + (size_t)N * dy; a.nlpd = want_nlpd ? a.covar + (size_t)N * dy * dy : nullptr;
+  if (want_nlpd) {
+    double* yd = out + nout;
+    HIP_TRY(ctx, hipMemcpyAsync(yd, y, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    a.y = yd;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // h (pageable) must be consumed before it goes away
+  bool unsupported = false;
+  HIP_TRY(ctx, launch_predict(a, ctx->stream, &unsupported));
+  if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "mimo_predict: dy=%d (max %d) or dx=%d not supported", dy, kMaxPredictDy, dx);
+  if (N > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(mu, a.mu, (size_t)N * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(covar, a.covar, (size_t)N * dy * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (want_nlpd) HIP_TRY(ctx, hipMemcpyAsync(nlpd, a.nlpd, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIMO_OK;
+}
+
 static int copy_out(mimo_ctx* ctx, void* dst, const void* src, size_t bytes, bool valid, const char* what) {
   int rc = bind(ctx); if (rc) return rc;
   if (!dst) return fail(ctx, MIMO_E_INVALID, "%s: destination is NULL", what);

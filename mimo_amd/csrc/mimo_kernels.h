@@ -74,4 +74,19 @@ hipError_t launch_table_entropy(const double* table, int64_t count, double* part
 // host mirror of the in-kernel counter-based generator
 double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep);
 
+// Posterior-predictive mixture moments (mimo_predict): one thread per row of Z.
+struct PredictArgs {
+  const double* Z; int64_t N; int dx, dc, dy, K, mode;   // dc = dx + affine
+  const double* gate;   // [K][1 + dx + dx*dx]  canonical (c, b, W) of the log-weights
+  const double* M;      // [K][dy][dc]
+  const double* Q;      // [K][dc][dc]   cs = 1 + x~' Q x~
+  const double* Cc;     // [K][dy][dy]   covar = cs * Cc
+  const double* y;      // [N][dy] or null
+  const double* P;      // [K][dy][dy]   precision at cs = 1 (for the predictive log-density), or null
+  const double* ld;     // [K]           logdet P
+  double* mu; double* covar; double* nlpd;
+};
+constexpr int kMaxPredictDy = 8;
+hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupported);
+
 }  // namespace mimo

@@ -922,6 +922,152 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 }
 
 // out[e] = sum_g partials[g][e] in a fixed order (4 interleaved chains, then a fixed tree).
+
+// ------------------------------------------------------------------------------------------
+// Posterior-predictive mixture moments (mimo/mixtures/ilr.py:339-372,374-430): for every row x_n
+//   l_k   = c_k + b_k.x - 1/2 x'W_k x                 log gating mean + log basis predictive
+//   w_k   = softmax_k l_k
+//   m_k   = M_k x~,  cs_k = 1 + x~'Q_k x~,  V_k = cs_k C_k      expert predictive mean / covariance
+//   average: mu = sum_k w_k m_k,  covar = sum_k w_k (V_k + m_k m_k') - mu mu'
+//   mode   : k* = argmax_k w_k,   mu = m_k*,  covar = V_k*
+//   nlpd (y given) = -logsumexp_k [ log N(y; m_k, (P_k / cs_k)^-1) + log(w_k + tiny) ]
+// One thread per row, the K loop streams the per-component blocks through scalar loads (uniform
+// addresses), x~ lives in a thread-private LDS column (runtime dx), the dy + dy^2 accumulators in
+// registers (DY is a template parameter).  Online softmax: one pass over k for the moments.
+// Inference-time N is small; this is VALU work by design.
+// ------------------------------------------------------------------------------------------
+template <int DY>
+__global__ __launch_bounds__(256) void predict_kernel(const PredictArgs a) {
+  extern __shared__ double xs[];   // [dc][256]
+  const int tid = threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * 256 + tid;
+  const bool valid = n < a.N;
+  const int dx = a.dx, dc = a.dc, K = a.K;
+  for (int i = 0; i < dx; ++i) xs[i * 256 + tid] = valid ? a.Z[n * dx + i] : 0.0;
+  if (dc > dx) xs[dx * 256 + tid] = 1.0;
+  auto X = [&](int i) { return xs[i * 256 + tid]; };
+
+  auto gate = [&](int k) {
+    const double* t = a.gate + (size_t)k * (1 + dx + dx * dx);
+    double l = t[0];
+    for (int i = 0; i < dx; ++i) {
+      double q = 0.0;
+      for (int j = 0; j < dx; ++j) q = fma(t[1 + dx + i * dx + j], X(j), q);
+      l = fma(X(i), t[1 + i] - 0.5 * q, l);
+    }
+    return l;
+  };
+  auto expert = [&](int k, double (&m)[DY], double& cs) {
+    const double* Mk = a.M + (size_t)k * DY * dc;
+    const double* Qk = a.Q + (size_t)k * dc * dc;
+#pragma unroll
+    for (int d = 0; d < DY; ++d) m[d] = 0.0;
+    double q = 0.0;
+    for (int i = 0; i < dc; ++i) {
+      const double xi = X(i);
+      double r = 0.0;
+      for (int j = 0; j < dc; ++j) r = fma(Qk[i * dc + j], X(j), r);
+      q = fma(xi, r, q);
+#pragma unroll
+      for (int d = 0; d < DY; ++d) m[d] = fma(Mk[d * dc + i], xi, m[d]);
+    }
+    cs = 1.0 + q;
+  };
+
+  double mx = -INFINITY, ssum = 0.0;
+  double amu[DY], aS[DY][DY];
+#pragma unroll
+  for (int d = 0; d < DY; ++d) {
+    amu[d] = 0.0;
+#pragma unroll
+    for (int e = 0; e < DY; ++e) aS[d][e] = 0.0;
+  }
+  int best = 0;
+  for (int k = 0; k < K; ++k) {
+    const double l = gate(k);
+    if (a.mode == 1) {          // argmax only (first maximum, as np.argmax)
+      if (l > mx) { mx = l; best = k; }
+      continue;
+    }
+    if (l > mx) {               // rescale the running sums to the new maximum
+      const double sc = exp(mx - l);
+      ssum *= sc;
+#pragma unroll
+      for (int d = 0; d < DY; ++d) {
+        amu[d] *= sc;
+#pragma unroll
+        for (int e = 0; e < DY; ++e) aS[d][e] *= sc;
+      }
+      mx = l;
+    }
+    const double w = exp(l - mx);
+    double m[DY], cs;
+    expert(k, m, cs);
+    const double* Ck = a.Cc + (size_t)k * DY * DY;
+    ssum += w;
+#pragma unroll
+    for (int d = 0; d < DY; ++d) {
+      amu[d] = fma(w, m[d], amu[d]);
+#pragma unroll
+      for (int e = 0; e < DY; ++e) aS[d][e] = fma(w, fma(cs, Ck[d * DY + e], m[d] * m[e]), aS[d][e]);
+    }
+  }
+  double lse = 0.0;
+  if (a.mode == 1) {
+    double m[DY], cs;
+    expert(best, m, cs);
+    const double* Ck = a.Cc + (size_t)best * DY * DY;
+    if (valid) {
+#pragma unroll
+      for (int d = 0; d < DY; ++d) {
+        a.mu[n * DY + d] = m[d];
+#pragma unroll
+        for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = cs * Ck[d * DY + e];
+      }
+    }
+    if (a.nlpd) {               // the log-normaliser is still needed for the weights inside nlpd
+      ssum = 0.0;
+      for (int k = 0; k < K; ++k) ssum += exp(gate(k) - mx);
+    }
+  } else if (valid) {
+    const double inv = 1.0 / ssum;
+#pragma unroll
+    for (int d = 0; d < DY; ++d) amu[d] *= inv;
+#pragma unroll
+    for (int d = 0; d < DY; ++d) {
+      a.mu[n * DY + d] = amu[d];
+#pragma unroll
+      for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = aS[d][e] * inv - amu[d] * amu[e];
+    }
+  }
+  if (a.nlpd) {
+    lse = mx + log(ssum);
+    double yv[DY];
+#pragma unroll
+    for (int d = 0; d < DY; ++d) yv[d] = valid ? a.y[n * DY + d] : 0.0;
+    double tm = -INFINITY, ts = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double w = exp(gate(k) - lse);
+      double m[DY], cs;
+      expert(k, m, cs);
+      const double* Pk = a.P + (size_t)k * DY * DY;
+      double q = 0.0;
+#pragma unroll
+      for (int d = 0; d < DY; ++d) {
+        double r = 0.0;
+#pragma unroll
+        for (int e = 0; e < DY; ++e) r = fma(Pk[d * DY + e], yv[e] - m[e], r);
+        q = fma(yv[d] - m[d], r, q);
+      }
+      const double lpl = -0.5 * q / cs - 0.5 * DY * 1.8378770664093453 + 0.5 * (a.ld[k] - DY * log(cs));
+      const double t = lpl + log(w + 2.2250738585072014e-308);
+      if (t > tm) { ts = ts * exp(tm - t) + 1.0; tm = t; }
+      else ts += exp(t - tm);
+    }
+    if (valid) a.nlpd[n] = -(tm + log(ts));
+  }
+}
+
 __global__ void reduce_partials(const double* __restrict__ partials, int G, int64_t stride,
                                 double* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1161,6 +1307,22 @@ hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int 
   const int64_t total = (int64_t)K * feat_count(D);
   hipLaunchKernelGGL(unpack_stats, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, stream,
                      reduced, feat, K, D, F16, S_packed, scalars3);
+  return hipGetLastError();
+}
+
+hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupported) {
+  typedef void (*fn_t)(const PredictArgs);
+  static const fn_t table[kMaxPredictDy] = {predict_kernel<1>, predict_kernel<2>, predict_kernel<3>, predict_kernel<4>,
+                                            predict_kernel<5>, predict_kernel<6>, predict_kernel<7>, predict_kernel<8>};
+  *unsupported = a.dy < 1 || a.dy > kMaxPredictDy || a.dc > kMaxD + 1;
+  if (*unsupported) return hipSuccess;
+  if (a.N <= 0) return hipSuccess;
+  fn_t fn = table[a.dy - 1];
+  const size_t lds = (size_t)a.dc * 256 * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3((unsigned)((a.N + 255) / 256)), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 

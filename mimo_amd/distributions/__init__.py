@@ -1,7 +1,9 @@
 from .gating import Categorical, Dirichlet, TruncatedStickBreaking
 from .wishart import Wishart
-from .gaussian import StackedGaussiansWithPrecision
-from .lingauss import StackedLinearGaussiansWithPrecision
-from .composite import StackedNormalWisharts, StackedMatrixNormalWisharts
+from .gaussian import StackedGaussiansWithPrecision, TiedGaussiansWithPrecision
+from .lingauss import StackedLinearGaussiansWithPrecision, TiedLinearGaussiansWithPrecision
+from .composite import (StackedNormalWisharts, StackedMatrixNormalWisharts, TiedNormalWisharts,
+                        TiedMatrixNormalWisharts)
 from .bayesian import (CategoricalWithDirichlet, CategoricalWithStickBreaking,
-                       StackedGaussiansWithNormalWisharts, StackedLinearGaussiansWithMatrixNormalWisharts)
+                       StackedGaussiansWithNormalWisharts, StackedLinearGaussiansWithMatrixNormalWisharts,
+                       TiedGaussiansWithNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts)

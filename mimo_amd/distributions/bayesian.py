@@ -14,8 +14,13 @@ import copy
 import numpy as np
 
 from mimo_amd.distributions.gating import Categorical
-from mimo_amd.distributions.gaussian import StackedGaussiansWithPrecision
-from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision
+from mimo_amd.distributions.gaussian import StackedGaussiansWithPrecision, TiedGaussiansWithPrecision
+from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision, TiedLinearGaussiansWithPrecision
+
+
+_STUDENTT_DEFECT = ("dist='studentt' has no observable behaviour in the reference for stacked blocks: "
+                    "mimo/utils/stats.py:79 divides a (K,N) array by a (K,) vector and mimo/mixtures/ilr.py:355 "
+                    "contracts a 4-D array with a 3-index subscript — both raise")
 
 
 def stick_acc_counts(counts):
@@ -173,6 +178,45 @@ class StackedGaussiansWithNormalWisharts(_ConjugateBlock):
         eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
         return eng.get_logp(self.size)
 
+    # ---- posterior predictive (bayesian.py:303-323) ---------------------------------------------
+    def posterior_predictive_gaussian(self):
+        """Moment-matched Gaussian N(m_k, (df_k/(1 + 1/kappa_k) psi_k)^-1), df = nu - D + 1."""
+        mus, kappas, psis, nus = self.posterior.params
+        dfs = nus - self.dim + 1
+        cs = 1. + 1. / kappas
+        return mus, (dfs / cs)[:, None, None] * psis
+
+    def predictive_canonical(self):
+        """(c, b, W) of log N(x; posterior_predictive_gaussian()) — stacked_mvn_logpdf (stats.py:53-66)."""
+        mus, lmbdas = self.posterior_predictive_gaussian()
+        b = np.einsum('kdl,kl->kd', lmbdas, mus)
+        c = - 0.5 * np.einsum('kd,kd->k', mus, b) - 0.5 * self.dim * np.log(2. * np.pi)\
+            + 0.5 * np.linalg.slogdet(lmbdas)[1]
+        return c, b, lmbdas
+
+    def log_posterior_predictive_gaussian(self, x):
+        eng = self.likelihood._bind(np.reshape(x, (-1, self.dim)))
+        eng.estep(*self.predictive_canonical(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def posterior_predictive_studentt(self):
+        mus, lmbdas = self.posterior_predictive_gaussian()
+        return mus, lmbdas, self.posterior.nus - self.dim + 1
+
+    def log_posterior_predictive_studentt(self, x):
+        raise NotImplementedError(_STUDENTT_DEFECT)
+
+
+class TiedGaussiansWithNormalWisharts(StackedGaussiansWithNormalWisharts):
+    """Gaussians with one shared precision under a TiedNormalWisharts prior/posterior (bayesian.py:326-340).
+    The kernels see K identical W_k; the pooling happens in the posterior's nat_to_std."""
+
+    def __init__(self, size, dim, prior, likelihood=None, engine=None):
+        if likelihood is None:
+            mus, lmbdas = prior.rvs()
+            likelihood = TiedGaussiansWithPrecision(size=size, dim=dim, mus=mus, lmbdas=lmbdas, engine=engine)
+        super().__init__(size, dim, prior, likelihood, engine=engine)
+
 
 class StackedLinearGaussiansWithMatrixNormalWisharts(_ConjugateBlock):
     """reference: bayesian.py:796-912 + 915-985 (stacked)."""
@@ -217,3 +261,63 @@ class StackedLinearGaussiansWithMatrixNormalWisharts(_ConjugateBlock):
         eng = self.likelihood._bind(x, y)
         eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
         return eng.get_logp(self.size)
+
+    # ---- posterior predictive (bayesian.py:949-985) ---------------------------------------------
+    def predictive_blocks(self):
+        """Per-component blocks of the Gaussian posterior predictive of y | x:
+        mean M_k x~, precision P_k / cs_kn with P_k = df_k psi_k, cs_kn = 1 + x~' K_k^-1 x~.
+        Returns M, Q = K^-1, Cc = P^-1, P, logdet P."""
+        Ms, Ks, psis, nus = self.posterior.params
+        dfs = nus - self.likelihood.row_dim + 1
+        P = dfs[:, None, None] * psis
+        return Ms, np.linalg.inv(Ks), np.linalg.inv(P), P, np.linalg.slogdet(P)[1]
+
+    def _scale_table(self, x):
+        """cs (K, N) = 1 + x~' K_k^-1 x~ on the engine (a quadratic form of x: c + b.x - x'Wx/2)."""
+        _, Q, _, _, _ = self.predictive_blocks()
+        dx = self.likelihood.input_dim
+        if self.likelihood.affine:
+            c, b, W = 1. + Q[:, dx, dx], 2. * Q[:, :dx, dx], - 2. * Q[:, :dx, :dx]
+        else:
+            c, b, W = np.ones(self.size), np.zeros((self.size, dx)), - 2. * Q
+        from mimo_amd import engine as _engine
+        eng = _engine.bind(self.likelihood.engine, np.ascontiguousarray(x))
+        eng.estep(c, np.ascontiguousarray(b), np.ascontiguousarray(W), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def posterior_predictive_gaussian(self, x):
+        """-> mus (K, N, dy), lmbdas (K, N, dy, dy)  (bayesian.py:949-962)."""
+        x = np.reshape(x, (-1, self.likelihood.input_dim))
+        Ms, _, _, P, _ = self.predictive_blocks()
+        xt = np.hstack((x, np.ones((len(x), 1)))) if self.likelihood.affine else x
+        mus = np.einsum('kdl,nl->knd', Ms, xt)
+        lmbdas = P[:, None, :, :] / self._scale_table(x)[:, :, None, None]
+        return mus, lmbdas
+
+    def log_posterior_predictive_gaussian(self, x, y):
+        """(K, N) table log N(y_n; M_k x~_n, lmbda_kn^-1): what bayesian.py:964-966 intends (the reference
+        passes the (K,N,dy) means to a routine written for (K,dy) means and raises, stats.py:57)."""
+        mus, lmbdas = self.posterior_predictive_gaussian(x)
+        r = np.reshape(y, (-1, self.likelihood.output_dim))[None, :, :] - mus
+        d = r.shape[-1]
+        return - 0.5 * np.einsum('knd,kndl,knl->kn', r, lmbdas, r) - 0.5 * d * np.log(2. * np.pi)\
+            + 0.5 * np.linalg.slogdet(lmbdas)[1]
+
+    def posterior_predictive_studentt(self, x):
+        mus, lmbdas = self.posterior_predictive_gaussian(x)
+        return mus, lmbdas, self.posterior.nus - self.likelihood.row_dim + 1
+
+    def log_posterior_predictive_studentt(self, x, y):
+        raise NotImplementedError(_STUDENTT_DEFECT)
+
+
+class TiedLinearGaussiansWithMatrixNormalWisharts(StackedLinearGaussiansWithMatrixNormalWisharts):
+    """Linear-Gaussian experts with one shared output precision under a TiedMatrixNormalWisharts
+    prior/posterior (bayesian.py:988-1003) — the `models` block of examples/ilr/evaluate_*.py."""
+
+    def __init__(self, size, column_dim, row_dim, prior, likelihood=None, affine=True, engine=None):
+        if likelihood is None:
+            As, lmbdas = prior.rvs()
+            likelihood = TiedLinearGaussiansWithPrecision(size, column_dim, row_dim, As=As, lmbdas=lmbdas,
+                                                          affine=affine, engine=engine)
+        super().__init__(size, column_dim, row_dim, prior, likelihood, affine=affine, engine=engine)

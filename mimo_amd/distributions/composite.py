@@ -2,6 +2,8 @@
 
 StackedNormalWisharts        <-> mimo/distributions/composite.py:19-256
 StackedMatrixNormalWisharts  <-> mimo/distributions/composite.py:550-783 (+ matrix.py:10-175)
+TiedNormalWisharts           <-> mimo/distributions/composite.py:259-283   (one precision shared by all K)
+TiedMatrixNormalWisharts     <-> mimo/distributions/composite.py:786-808
 
 These classes produce the per-component parameter block the kernels consume (expected statistics
 -> canonical (c, b, W)) and consume the sufficient-statistic block the kernels produce
@@ -290,3 +292,40 @@ class StackedMatrixNormalWisharts:
 
     def cross_entropy(self, other):
         return other.log_partition() - other.log_base() - self._inner(other.nat_param, self.expected_statistics())
+
+
+class _TiedNatParam:
+    """Tied posteriors pool the Wishart block over k in nat_to_std, so the natural parameters read back
+    are those of the pooled standard parameters, not the ones assigned (the reference recomputes them on
+    every read: composite.py:166-172) — the assigned block must not be memoised."""
+
+    @property
+    def nat_param(self):
+        return self._cached('nat', lambda: self.std_to_nat(self.params))
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+
+class TiedNormalWisharts(_TiedNatParam, StackedNormalWisharts):
+    """K Normal-Wisharts whose Wishart factor is shared: psi = inv(mean_k(psi_k^-1 block)), nu = mean_k nu_k
+    (composite.py:273-283)."""
+
+    def nat_to_std(self, natparam):
+        a, b, c, d = natparam
+        mus = a / b[:, None]
+        psi = np.linalg.inv(np.mean(c - b[:, None, None] * _outer(mus, mus), axis=0))
+        nu = np.mean(d + self.dim)
+        return mus, b, np.array(self.size * [psi]), np.array(self.size * [nu])
+
+
+class TiedMatrixNormalWisharts(_TiedNatParam, StackedMatrixNormalWisharts):
+    """composite.py:798-808."""
+
+    def nat_to_std(self, natparam):
+        a, b, c, d = natparam
+        Ms = a @ np.linalg.inv(b)
+        psi = np.linalg.inv(np.mean(c - Ms @ b @ np.swapaxes(Ms, 1, 2), axis=0))
+        nu = np.mean(d + self.row_dim + 1. - self.column_dim)
+        return Ms, b, np.array(self.size * [psi]), np.array(self.size * [nu])

@@ -165,3 +165,16 @@ class StackedGaussiansWithPrecision:
         sigmas = symmetrize(sigmas) + 1e-16 * np.eye(self.dim)
         assert np.all(np.linalg.eigvalsh(sigmas) > 0.)
         self.mus, self.lmbdas = mus, np.linalg.inv(sigmas)
+
+
+class TiedGaussiansWithPrecision(StackedGaussiansWithPrecision):
+    """K Gaussians sharing one precision matrix (gaussian.py:545-572): same E-step form (W_k all equal),
+    pooled covariance in the M-step."""
+
+    def max_likelihood(self, data, weights=None, stats=None):
+        xk, nk, xxTk, _ = stats if stats is not None else self.weighted_statistics(data, weights)
+        mus = xk / nk[:, None]
+        sigma = (np.sum(xxTk, axis=0) - np.einsum('k,kd,kl->dl', nk, mus, mus)) / np.sum(nk)
+        sigma = symmetrize(sigma) + 1e-16 * np.eye(self.dim)
+        assert np.all(np.linalg.eigvalsh(sigma) > 0.)
+        self.mus, self.lmbdas = mus, np.array(self.size * [np.linalg.inv(sigma)])

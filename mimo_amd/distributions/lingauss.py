@@ -178,6 +178,24 @@ class StackedLinearGaussiansWithPrecision:
         self.As, self.lmbdas = As, np.linalg.inv(sigmas)
 
 
+class TiedLinearGaussiansWithPrecision(StackedLinearGaussiansWithPrecision):
+    """K linear-Gaussian experts sharing one output precision (lingauss.py:370-398).
+
+    max_likelihood implements the pooled estimate the reference evidently intends,
+        sigma = (sum_k yyT_k - sum_k A_k yxT_k') / sum_k n_k,
+    mirroring TiedGaussiansWithPrecision (gaussian.py:550-572).  The reference's own method cannot be
+    used as a parity anchor: it keeps the (K, d, d) block `yyT` and divides it by the (K,) vector `n`
+    (lingauss.py:379-387), which raises a broadcasting error unless d == K — no golden vector exists."""
+
+    def max_likelihood(self, x, y, weights=None, stats=None):
+        yxTk, xxTk, yyTk, nk = stats if stats is not None else self.weighted_statistics(x, y, weights)
+        As = np.swapaxes(np.linalg.solve(xxTk, np.swapaxes(yxTk, 1, 2)), 1, 2)
+        sigma = (np.sum(yyTk, axis=0) - np.sum(As @ np.swapaxes(yxTk, 1, 2), axis=0)) / np.sum(nk)
+        sigma = symmetrize(sigma) + 1e-16 * np.eye(self.output_dim)
+        assert np.all(np.linalg.eigvalsh(sigma) > 0.)
+        self.As, self.lmbdas = As, np.array(self.size * [np.linalg.inv(sigma)])
+
+
 _joint_cache = {}
 
 

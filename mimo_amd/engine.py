@@ -217,6 +217,29 @@ class HipEngine:
             self._check(self._lib.mimo_table_entropy(self._ctx, _ptr(table), table.size, 0, C.byref(out)))
         return out.value
 
+    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
+        """Posterior-predictive mixture moments of every resident row (mimo_predict).
+        Returns (mu (N,dy), covar (N,dy,dy), nlpd (N) | None)."""
+        c, b, W, K = self._params(c, b, W)
+        M, Q, Cc = _f64(M), _f64(Q), _f64(Cc)
+        dy, dc = M.shape[1], self.D + (1 if affine else 0)
+        if M.shape != (K, dy, dc) or Q.shape != (K, dc, dc) or Cc.shape != (K, dy, dy):
+            raise ValueError(f"predictive blocks {M.shape}, {Q.shape}, {Cc.shape} do not match K={K}, dy={dy}, dc={dc}")
+        if mode not in ('average', 'mode'):
+            raise NotImplementedError(mode)
+        mu, covar = np.empty((self.N, dy)), np.empty((self.N, dy, dy))
+        nlpd = None
+        if y is not None:
+            y, P, ld = _f64(y).reshape(self.N, dy), _f64(P), _f64(ld)
+            if P.shape != (K, dy, dy) or ld.shape != (K,):
+                raise ValueError("nlpd needs P (K,dy,dy) and ld (K,)")
+            nlpd = np.empty(self.N)
+        self._check(self._lib.mimo_predict(
+            self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(M), _ptr(Q), _ptr(Cc), dy, 1 if affine else 0,
+            0 if mode == 'average' else 1, _ptr(y) if y is not None else None, _ptr(P) if y is not None else None,
+            _ptr(ld) if y is not None else None, _ptr(mu), _ptr(covar), _ptr(nlpd) if y is not None else None))
+        return mu, covar, nlpd
+
     # -- copy-outs ------------------------------------------------------------------------
     def get_resp(self, K=None):
         out = np.empty((int(K if K is not None else self._K), self.N))

@@ -23,6 +23,7 @@ class Standardizer:
     def fit(self, a):
         a = np.asarray(a, dtype=float)
         self.mean_ = a.mean(axis=0)
+        self.var_ = a.var(axis=0)
         self.scale_ = a.std(axis=0)
         self.scale_[self.scale_ == 0.] = 1.
         return self
@@ -103,7 +104,7 @@ class MixtureOfLinearGaussians:
 
 
 class BayesianMixtureOfLinearGaussians:
-    """reference: mimo/mixtures/ilr.py:87-323 (prediction :325-430 is outside the hot path)."""
+    """reference: mimo/mixtures/ilr.py:87-430."""
 
     def __init__(self, size, input_dim, output_dim, gating, basis, models, scale=False, engine=None):
         self.size = size
@@ -340,3 +341,76 @@ class BayesianMixtureOfLinearGaussians:
     def variational_lowerbound(self, x, y, resp):
         return self._vlb_prior_terms() + self.variational_lowerbound_data(x, y, resp)\
             + self.variational_lowerbound_labels(resp)
+
+    # ---- posterior-predictive path (ilr.py:325-430) ---------------------------------------------
+    def _predictive_gate(self):
+        """(c, b, W) over x of  log E_q[pi_k] + log N(x; basis posterior predictive)  (ilr.py:339-345)."""
+        c, b, W = self.basis.predictive_canonical()
+        return c + np.log(self.gating.posterior.mean()), b, W
+
+    @staticmethod
+    def _check_dist(dist):
+        if dist != 'gaussian':
+            from mimo_amd.distributions.bayesian import _STUDENTT_DEFECT
+            raise NotImplementedError(_STUDENTT_DEFECT)
+
+    def meanfield_predictive_weights(self, x, dist='gaussian'):
+        """(K, N) softmax_k of the gate, on the engine (x already in model coordinates)."""
+        self._check_dist(dist)
+        eng = _engine.bind(self.engine, np.ascontiguousarray(np.reshape(x, (-1, self.input_dim)), dtype=float))
+        eng.estep(*self._predictive_gate(), stats=False, keep_resp=True)
+        return eng.get_resp(self.size)
+
+    def meanfield_predictive_activation(self, x, dist='gaussian'):
+        """ilr.py:325-337 — as the weights, from raw inputs."""
+        x = np.reshape(x, (-1, self.input_dim))
+        return self.meanfield_predictive_weights(self.input_transform.transform(x) if self.scale else x, dist)
+
+    def meanfield_predictive_moments(self, x, dist='gaussian'):
+        """ilr.py:350-358: mus (K,N,dy), covars (K,N,dy,dy) = cs_kn (df_k psi_k)^-1."""
+        self._check_dist(dist)
+        x = np.reshape(x, (-1, self.input_dim))
+        Ms, _, Cc, _, _ = self.models.predictive_blocks()
+        xt = np.hstack((x, np.ones((len(x), 1)))) if self.affine else x
+        return np.einsum('kdl,nl->knd', Ms, xt), self.models._scale_table(x)[:, :, None, None] * Cc[:, None, :, :]
+
+    def meanfiled_log_predictive_likelihood(self, x, y, dist='gaussian'):
+        """(sic, ilr.py:360-363)"""
+        self._check_dist(dist)
+        return self.models.log_posterior_predictive_gaussian(x, y)
+
+    @staticmethod
+    def mixture_moments(mus, covars, weights):
+        """ilr.py:364-372 for caller-supplied tables (the fused path never builds them)."""
+        mu = np.einsum('knd,kn->nd', mus, weights)
+        covar = np.einsum('kndl,kn->ndl', covars + np.einsum('knd,knl->kndl', mus, mus), weights)\
+            - np.einsum('nd,nl->ndl', mu, mu)
+        return mu, covar
+
+    def meanfield_prediction(self, x, y=None, prediction='average', dist='gaussian', incremental=False,
+                             variance='diagonal'):
+        """ilr.py:374-430.  One fused pass over the inputs (mimo_predict): gate softmax, expert predictive
+        moments and their mixture (or the arg-max component) per row; the (K,N,.) tables of the reference
+        are never materialised.  With y the negative log predictive density the reference intends at
+        :405-409 is returned as well (its own call raises for stacked models — see the oracle)."""
+        self._check_dist(dist)
+        if prediction not in ('average', 'mode'):
+            raise NotImplementedError(prediction)
+        x = np.reshape(x, (-1, self.input_dim))
+        if y is not None:
+            y = np.reshape(y, (-1, self.output_dim))
+        xx = self.input_transform.transform(x) if self.scale else x
+        yy = (self.output_transform.transform(y) if self.scale else y) if y is not None else None
+        Ms, Q, Cc, P, ld = self.models.predictive_blocks()
+        eng = _engine.bind(self.engine, np.ascontiguousarray(xx, dtype=float))
+        mu, covar, nlpd = eng.predict(*self._predictive_gate(), Ms, Q, Cc, affine=self.affine, mode=prediction,
+                                      y=None if yy is None else np.ascontiguousarray(yy), P=P, ld=ld)
+        if self.scale:
+            mu = self.output_transform.inverse_transform(mu)
+            mat = np.diag(np.sqrt(self.output_transform.var_))
+            covar = np.einsum('kh,...hj,ji->...ki', mat, covar, mat.T)
+        if incremental:
+            mu += x[:, :self.output_dim]
+        var = np.vstack(list(map(np.diag, covar))) if len(covar) else np.zeros((0, self.output_dim))
+        out = (mu, var if variance == 'diagonal' else covar, np.sqrt(var))
+        return out + (nlpd,) if y is not None else out

@@ -139,6 +139,27 @@ def stick_probs_from_betas(betas_head):
     return probs
 
 
+def stick_mean(gammas, deltas):
+    """TruncatedStickBreaking.mean (dirichlet.py:177-186): stick probabilities of the mean betas."""
+    return stick_probs_from_betas((gammas / (gammas + deltas))[:-1])
+
+
+def tied_nw_nat_to_std(a, b, c, d, D):
+    """TiedNormalWisharts.nat_to_std (composite.py:273-283): the Wishart block is pooled over k."""
+    mus = a / b[:, None]
+    psi = np.linalg.inv(np.mean(c - np.einsum('k,kd,kl->kdl', b, mus, mus), axis=0))
+    nu = np.mean(d + D)
+    return mus, b, np.array(len(b) * [psi]), np.array(len(b) * [nu])
+
+
+def tied_mnw_nat_to_std(a, b, c, d, row_dim, column_dim):
+    """TiedMatrixNormalWisharts.nat_to_std (composite.py:798-808)."""
+    Ms = np.einsum('kdl,klh->kdh', a, np.linalg.inv(b))
+    psi = np.linalg.inv(np.mean(c - np.einsum('kdl,klm,khm->kdh', Ms, b, Ms), axis=0))
+    nu = np.mean(d + row_dim + 1 - column_dim)
+    return Ms, b, np.array(len(b) * [psi]), np.array(len(b) * [nu])
+
+
 def gating_expected_log(gating_type, post):
     """gmm.py:246-252 — E[log pi_k] for Dirichlet, or E_log_stick_k + sum_{j<k} E_log_rest_j."""
     if gating_type == 'dirichlet':
@@ -578,3 +599,98 @@ def canonical_eval(z, c, b, W):
 def packed_stats(z, weights):
     """(n_k, sum r z, sum r z z') for z rows — the engine's packed output, computed naively."""
     return weights.sum(1), weights @ z, np.einsum('kn,nd,ne->kde', weights, z, z, optimize=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# posterior-predictive path (SURVEY.md section 8(f) rank 3)
+# ---------------------------------------------------------------------------------------------
+def stacked_mvn_logpdf(xs, mus, lmbdas):
+    """mimo/utils/stats.py:53-66 (stacked_multivariate_gaussian_loglik) -> (K, N)."""
+    d = mus.shape[-1]
+    xc = xs[:, None, :] - mus[None, :, :]
+    log_exps = - 0.5 * np.einsum('nkd,kdl,nkl->kn', xc, lmbdas, xc)
+    log_norms = - 0.5 * d * np.log(2. * np.pi) + 0.5 * np.linalg.slogdet(lmbdas)[1]
+    return log_norms[:, None] + log_exps
+
+
+def nw_posterior_predictive_gaussian(post):
+    """bayesian.py:303-309: moment-matched Gaussian of the Normal-Wishart posterior predictive."""
+    mus, kappas, psis, nus = post
+    dfs = nus - mus.shape[-1] + 1
+    cs = 1. + 1. / kappas
+    return mus, np.einsum('k,kdl->kdl', dfs / cs, psis)
+
+
+def mnw_posterior_predictive_gaussian(x, post, affine=True):
+    """bayesian.py:949-962 -> mus (K,N,dy), lmbdas (K,N,dy,dy)."""
+    Ms, Ks, psis, nus = post
+    if affine:
+        x = np.hstack((x, np.ones((len(x), 1))))
+    dfs = nus - Ms.shape[1] + 1
+    mus = np.einsum('kdl,nl->knd', Ms, x)
+    cs = 1. + np.einsum('nd,kdl,nl->kn', x, np.linalg.inv(Ks), x)
+    lmbdas = np.einsum('kdl,k,kn->kndl', psis, dfs, 1. / cs)
+    return mus, lmbdas
+
+
+def ilr_predictive_weights(x, bpost, gating_mean):
+    """ilr.py:339-348 (dist='gaussian')."""
+    log_pp = stacked_mvn_logpdf(x, *nw_posterior_predictive_gaussian(bpost))
+    log_weight = np.log(gating_mean)[:, None] + log_pp
+    return np.exp(log_weight - logsumexp(log_weight, axis=0, keepdims=True))
+
+
+def mixture_moments(mus, covars, weights):
+    """ilr.py:364-372."""
+    mu = np.einsum('knd,kn->nd', mus, weights)
+    covar = np.einsum('kndl,kn->ndl', covars + np.einsum('knd,knl->kndl', mus, mus), weights)\
+        - np.einsum('nd,nl->ndl', mu, mu)
+    return mu, covar
+
+
+def ilr_meanfield_prediction(x, bpost, mpost, gating_mean, prediction='average', affine=True, y=None):
+    """ilr.py:374-409 on already-transformed inputs (the scaling steps :384-389,411-414 are host-side
+    affine maps).  With y: the predictive log-density the reference INTENDS at :405-409 — its own call
+    raises for stacked models (stats.py:57 broadcasts (N,1,d) against (1,K,N,d)), so nlpd has no golden
+    vector; the formula is log N(y_n; mu_kn, lmbda_kn^-1) per (k, n)."""
+    weights = ilr_predictive_weights(x, bpost, gating_mean)
+    mus, lmbdas = mnw_posterior_predictive_gaussian(x, mpost, affine)
+    covars = np.linalg.inv(lmbdas)
+    if prediction == 'mode':
+        k = np.argmax(weights, axis=0)
+        idx = (k, range(len(k)), ...)
+        mu, covar = mus[idx], covars[idx]
+    else:
+        mu, covar = mixture_moments(mus, covars, weights)
+    nlpd = None
+    if y is not None:
+        r = y[None, :, :] - mus
+        d = y.shape[-1]
+        log_pl = - 0.5 * np.einsum('knd,kndl,knl->kn', r, lmbdas, r) - 0.5 * d * np.log(2. * np.pi)\
+            + 0.5 * np.linalg.slogdet(lmbdas)[1]
+        nlpd = - logsumexp(log_pl + np.log(weights + np.finfo(np.float64).tiny), axis=0)
+    return mu, covar, nlpd
+
+
+def predict_canonical(z, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
+    """What mimo_predict computes, stated on its own arguments (include/mimo_hip.h)."""
+    L = canonical_eval(z, c, b, W)
+    weights = np.exp(L - logsumexp(L, axis=0, keepdims=True))
+    xt = np.hstack((z, np.ones((len(z), 1)))) if affine else z
+    mus = np.einsum('kdl,nl->knd', M, xt)
+    cs = 1. + np.einsum('nd,kdl,nl->kn', xt, Q, xt)
+    covars = np.einsum('kn,kdl->kndl', cs, Cc)
+    if mode == 'mode':
+        k = np.argmax(L, axis=0)
+        idx = (k, range(len(k)), ...)
+        mu, covar = mus[idx], covars[idx]
+    else:
+        mu, covar = mixture_moments(mus, covars, weights)
+    nlpd = None
+    if y is not None:
+        r = y[None, :, :] - mus
+        d = y.shape[-1]
+        log_pl = - 0.5 * np.einsum('knd,kdl,knl->kn', r, P, r) / cs - 0.5 * d * np.log(2. * np.pi)\
+            + 0.5 * (ld[:, None] - d * np.log(cs))
+        nlpd = - logsumexp(log_pl + np.log(weights + np.finfo(np.float64).tiny), axis=0)
+    return mu, covar, nlpd

@@ -363,7 +363,111 @@ def ilr_svi_case(name, N, dx, dy, K, seed, iters=6):
     print(name, "ok")
 
 
+def tied_gmm_case(name, N, D, K, seed, iters=6):
+    """Tied-covariance GMM (composite.py:259-283, bayesian.py:326-340, gaussian.py:545-572): seeded Gibbs
+    sweeps, a VI trace and an EM trace."""
+    from mimo.distributions import (TiedNormalWisharts, TiedGaussiansWithNormalWisharts, TiedGaussiansWithPrecision,
+                                    Categorical)
+    from mimo.mixtures import MixtureOfGaussians
+    npr.seed(seed)
+    X = make_data(N, D)
+    out = dict(X=X, K=np.array(K), D=np.array(D), seed=np.array(seed), iters=np.array(iters), gating_kind=np.array('dirichlet'))
+    gating = make_gating(K, 'dirichlet')
+    prior = TiedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K,)),
+                               psis=np.stack(K * [np.eye(D)]), nus=(D + 2.) * np.ones((K,)))
+    npr.seed(seed + 1)
+    comps = TiedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior)
+    m = BayesianMixtureOfGaussians(gating=gating, components=comps)
+    put(out, "prior", nw_params(prior)); put(out, "gprior", gating_params(gating.prior, 'dirichlet'))
+    npr.seed(seed + 2)
+    m.resample(X.copy(), init_labels='random', maxiter=3, progress_bar=False)
+    out["gibbs_mus"], out["gibbs_lmbdas"] = m.components.likelihood.mus, m.components.likelihood.lmbdas
+    put(out, "gibbs_post", nw_params(m.components.posterior))
+    out["gibbs_nat2"] = m.components.posterior.nat_param[2]       # recomputed from the pooled psi on read
+    npr.seed(seed + 3)
+    vlb = m.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=iters, tol=0., progress_bar=False)
+    out["vi_vlb"] = np.array(vlb)
+    put(out, "vi_post", nw_params(m.components.posterior))
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=TiedGaussiansWithPrecision(size=K, dim=D))
+    npr.seed(seed + 4)
+    out["em_loglik"] = np.array(lik.max_likelihood(X.copy(), randomize=True, maxiter=iters, progress_bar=False))
+    out["em_mus"], out["em_lmbdas"] = lik.components.mus, lik.components.lmbdas
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
+def tied_ilr_prediction_case(name, N, K, seed, gibbs_iters=4, svi_iters=5, vi_iters=5, dx=1, dy=1):
+    """The flow of examples/ilr/evaluate_sine.py:88-155 at fixture size: scaled data, Normal-Wishart basis,
+    TIED Matrix-Normal-Wishart models, stick-breaking gating; Gibbs -> SVI -> VI -> prior := posterior ->
+    meanfield_prediction (ilr.py:325-430): average / mode, diagonal / full variance, Gaussian predictive."""
+    import random
+    from mimo.distributions import TiedMatrixNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts
+    npr.seed(seed)
+    t = np.linspace(0., 4. * np.pi, N)
+    if dx == 1:
+        X = (t + 0.1 * npr.randn(N))[:, None]
+    else:
+        X = np.column_stack([t + 0.1 * npr.randn(N)] + [npr.randn(N) for _ in range(dx - 1)])
+    Y = np.column_stack([3. * np.sin(t + 0.5 * j) + 0.3 * npr.randn(N) for j in range(dy)])
+    if dx > 1:
+        Y = Y + 0.5 * X[:, 1:2]
+    train = np.r_[0:N // 4, N // 2:3 * N // 4]
+    Xtr, Ytr = np.ascontiguousarray(X[train]), np.ascontiguousarray(Y[train])
+    dc = dx + 1
+    gating = make_gating(K, 'stick')
+    bprior = StackedNormalWisharts(size=K, dim=dx, mus=np.zeros((K, dx)), kappas=1e-2 * np.ones((K,)),
+                                   psis=np.stack(K * [1e2 * np.eye(dx)]), nus=(dx + 1.) * np.ones((K,)) + 1e-16)
+    npr.seed(seed + 1)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior)
+    mprior = TiedMatrixNormalWisharts(K, dc, dy, Ms=np.zeros((K, dy, dc)), Ks=np.stack(K * [1e-2 * np.eye(dc)]),
+                                      psis=np.stack(K * [1e1 * np.eye(dy)]), nus=(dy + 1.) * np.ones((K,)) + 1e-16)
+    models = TiedLinearGaussiansWithMatrixNormalWisharts(K, dc, dy, mprior, affine=True)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis, models=models)
+    out = dict(X=X, Y=Y, Xtr=Xtr, Ytr=Ytr, gating_kind=np.array('stick'), K=np.array(K), seed=np.array(seed),
+               gibbs_iters=np.array(gibbs_iters), svi_iters=np.array(svi_iters), vi_iters=np.array(vi_iters))
+    put(out, "bprior", nw_params(ilr.basis.prior)); put(out, "mprior", mnw_params(ilr.models.prior))
+    put(out, "gprior", gating_params(ilr.gating.prior, 'stick'))
+    ilr.init_transform(Xtr, Ytr)
+    npr.seed(seed + 2); random.seed(seed + 3)
+    ilr.resample(Xtr.copy(), Ytr.copy(), init_labels='random', maxiter=gibbs_iters, progress_bar=False)
+    out["gibbs_As"], out["gibbs_lmbdas"] = ilr.models.likelihood.As, ilr.models.likelihood.lmbdas
+    put(out, "gibbs_mpost", mnw_params(ilr.models.posterior))
+    out["svi_vlb"] = np.array(ilr.meanfield_stochastic_descent(Xtr.copy(), Ytr.copy(), randomize=False, maxiter=svi_iters,
+                                                               step_size=5e-1, batch_size=64, progress_bar=False))
+    put(out, "svi_mpost", mnw_params(ilr.models.posterior))
+    out["vi_vlb"] = np.array(ilr.meanfield_coordinate_descent(Xtr.copy(), Ytr.copy(), randomize=False, maxiter=vi_iters,
+                                                              tol=0., progress_bar=False))
+    put(out, "vi_mpost", mnw_params(ilr.models.posterior)); put(out, "vi_bpost", nw_params(ilr.basis.posterior))
+    put(out, "vi_gpost", gating_params(ilr.gating.posterior, 'stick'))
+    ilr.basis.prior = ilr.basis.posterior
+    ilr.models.prior = ilr.models.posterior
+    # prediction on ALL inputs (train + held-out), every variant
+    # dist='studentt' raises in the reference for stacked blocks (stats.py:79 divides (K,N) by (K,);
+    # ilr.py:355 contracts a 4-D array with 'ndl') — only the Gaussian predictive has observable behaviour
+    for dist in ('gaussian',):
+        xx = ilr.input_transform.transform(X)
+        out[f"pred_weights_{dist}"] = ilr.meanfield_predictive_weights(xx, dist)
+        out[f"pred_activation_{dist}"] = ilr.meanfield_predictive_activation(X.copy(), dist)
+        mus, covars = ilr.meanfield_predictive_moments(xx, dist)
+        out[f"pred_mus_{dist}"], out[f"pred_covars_{dist}"] = mus, covars
+        for pred in ('average', 'mode'):
+            # (with y the reference raises: stacked_mvn_logpdf gets (K,N,d) means, stats.py:57 — no nlpd vector)
+            mu, var, std = ilr.meanfield_prediction(X.copy(), prediction=pred, dist=dist)
+            out[f"pred_{pred}_{dist}_mu"], out[f"pred_{pred}_{dist}_var"] = mu, var
+            out[f"pred_{pred}_{dist}_std"] = std
+    mu, covar, std = ilr.meanfield_prediction(X.copy(), prediction='average', variance='full')
+    out["pred_average_gaussian_covar"] = covar
+    out["basis_logpred_gaussian"] = ilr.basis.log_posterior_predictive_gaussian(ilr.input_transform.transform(X))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tied":
+        tied_gmm_case("tied_gmm_d3_k5", N=500, D=3, K=5, seed=1349)
+        tied_ilr_prediction_case("tied_ilr_sine_k8", N=400, K=8, seed=1350)
+        tied_ilr_prediction_case("tied_ilr_dx3_dy2_k6", N=300, K=6, seed=1351, dx=3, dy=2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "drivers":
         driver_traces_case("drivers_d3_k5_dir", N=600, D=3, K=5, kind='dirichlet', seed=1347)
         ilr_svi_case("ilr_svi_dx2_dy1_k8", N=500, dx=2, dy=1, K=8, seed=1348)
@@ -381,3 +485,6 @@ if __name__ == "__main__":
     gibbs_trace_case("gibbs_stick_trace", N=400, D=3, K=6, kind='stick', seed=1346)
     driver_traces_case("drivers_d3_k5_dir", N=600, D=3, K=5, kind='dirichlet', seed=1347)
     ilr_svi_case("ilr_svi_dx2_dy1_k8", N=500, dx=2, dy=1, K=8, seed=1348)
+    tied_gmm_case("tied_gmm_d3_k5", N=500, D=3, K=5, seed=1349)
+    tied_ilr_prediction_case("tied_ilr_sine_k8", N=400, K=8, seed=1350)
+    tied_ilr_prediction_case("tied_ilr_dx3_dy2_k6", N=300, K=6, seed=1351, dx=3, dy=2)

@@ -8,7 +8,9 @@ from conftest import load_golden, rel_err, gating_of, nw_of, mnw_of
 from mimo_amd.distributions import (Dirichlet, TruncatedStickBreaking, CategoricalWithDirichlet,
                                     CategoricalWithStickBreaking, StackedNormalWisharts,
                                     StackedGaussiansWithNormalWisharts, StackedMatrixNormalWisharts,
-                                    StackedLinearGaussiansWithMatrixNormalWisharts)
+                                    StackedLinearGaussiansWithMatrixNormalWisharts, TiedNormalWisharts,
+                                    TiedGaussiansWithNormalWisharts, TiedGaussiansWithPrecision,
+                                    TiedMatrixNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts)
 from mimo_amd.mixtures import BayesianMixtureOfGaussians, BayesianMixtureOfLinearGaussians
 
 
@@ -258,3 +260,104 @@ def check_ilr_svi(name, engine, tol=1e-7):
     assert rel_err(np.array(vlb), g["svi_vlb"]) < tol
     for a, b in zip(ilr.models.posterior.params, mnw_of(g, "svi_mpost")):
         assert rel_err(a, b) < 1e-6
+
+
+def check_tied_gmm(name, engine, tol=1e-8):
+    """Tied-covariance GMM: seeded Gibbs sweeps, VI trace, EM trace."""
+    from mimo_amd.distributions import Categorical
+    from mimo_amd.mixtures import MixtureOfGaussians
+    g = load_golden(name)
+    X, K, D, seed, iters = g["X"], int(g["K"]), int(g["D"]), int(g["seed"]), int(g["iters"])
+    kind, gating = make_gating(g, K)
+    prior = TiedNormalWisharts(size=K, dim=D, **{k: g["prior_" + k] for k in ("mus", "kappas", "psis", "nus")})
+    npr.seed(seed + 1)
+    comps = TiedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior, engine=engine)
+    m = BayesianMixtureOfGaussians(gating=gating, components=comps, engine=engine)
+    npr.seed(seed + 2)
+    m.resample(X, init_labels='random', maxiter=3, progress_bar=False, label_rng='host')
+    assert rel_err(m.components.likelihood.mus, g["gibbs_mus"]) < tol
+    assert rel_err(m.components.likelihood.lmbdas, g["gibbs_lmbdas"]) < tol
+    for a, b in zip(m.components.posterior.params, nw_of(g, "gibbs_post")):
+        assert rel_err(a, b) < tol
+    assert np.allclose(m.components.posterior.psis, m.components.posterior.psis[0])       # one shared psi
+    assert rel_err(m.components.posterior.nat_param[2], g["gibbs_nat2"]) < tol           # recomputed on read
+    npr.seed(seed + 3)
+    vlb = m.meanfield_coordinate_descent(X, randomize=False, maxiter=iters, tol=0., progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    for a, b in zip(m.components.posterior.params, nw_of(g, "vi_post")):
+        assert rel_err(a, b) < 1e-6
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=TiedGaussiansWithPrecision(K, D, engine=engine),
+                             engine=engine)
+    npr.seed(seed + 4)
+    ll = lik.max_likelihood(X, randomize=True, maxiter=iters, progress_bar=False)
+    assert rel_err(np.array(ll), g["em_loglik"]) < tol
+    assert rel_err(lik.components.mus, g["em_mus"]) < 1e-6 and rel_err(lik.components.lmbdas, g["em_lmbdas"]) < 1e-6
+
+
+def check_tied_ilr_prediction(name, engine, tol=1e-7):
+    """examples/ilr/evaluate_sine.py at fixture size: tied MNW experts, Gibbs -> SVI -> VI -> prediction."""
+    import random
+    g = load_golden(name)
+    K, seed = int(g["K"]), int(g["seed"])
+    X, Y, Xtr, Ytr = g["X"], g["Y"], g["Xtr"], g["Ytr"]
+    dx, dy = X.shape[1], Y.shape[1]
+    kind, gating = make_gating(g, K)
+    bprior = StackedNormalWisharts(size=K, dim=dx, **{k: g["bprior_" + k] for k in ("mus", "kappas", "psis", "nus")})
+    npr.seed(seed + 1)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior, engine=engine)
+    mprior = TiedMatrixNormalWisharts(K, dx + 1, dy, **{k: g["mprior_" + k] for k in ("Ms", "Ks", "psis", "nus")})
+    models = TiedLinearGaussiansWithMatrixNormalWisharts(K, dx + 1, dy, mprior, affine=True, engine=engine)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis,
+                                           models=models, engine=engine)
+    ilr.init_transform(Xtr, Ytr)
+    npr.seed(seed + 2)
+    random.seed(seed + 3)
+    ilr.resample(Xtr, Ytr, init_labels='random', maxiter=int(g["gibbs_iters"]), progress_bar=False, label_rng='host')
+    assert rel_err(ilr.models.likelihood.As, g["gibbs_As"]) < tol
+    assert rel_err(ilr.models.likelihood.lmbdas, g["gibbs_lmbdas"]) < tol
+    for a, b in zip(ilr.models.posterior.params, mnw_of(g, "gibbs_mpost")):
+        assert rel_err(a, b) < tol
+    vlb = ilr.meanfield_stochastic_descent(Xtr, Ytr, randomize=False, maxiter=int(g["svi_iters"]), step_size=5e-1,
+                                           batch_size=64, progress_bar=False)
+    assert rel_err(np.array(vlb), g["svi_vlb"]) < tol
+    for a, b in zip(ilr.models.posterior.params, mnw_of(g, "svi_mpost")):
+        assert rel_err(a, b) < 1e-6
+    vlb = ilr.meanfield_coordinate_descent(Xtr, Ytr, randomize=False, maxiter=int(g["vi_iters"]), tol=0.,
+                                           progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    for a, b in zip(ilr.models.posterior.params, mnw_of(g, "vi_mpost")):
+        assert rel_err(a, b) < 1e-6
+    for a, b in zip(ilr.basis.posterior.params, nw_of(g, "vi_bpost")):
+        assert rel_err(a, b) < 1e-6
+    check_prediction(ilr, g, tol=1e-6)
+
+
+def check_prediction(ilr, g, tol):
+    """meanfield_prediction and its helpers (ilr.py:325-430) against the reference's outputs."""
+    X, Y = g["X"], g["Y"]
+    xx = ilr.input_transform.transform(X)
+    assert rel_err(ilr.basis.log_posterior_predictive_gaussian(xx), g["basis_logpred_gaussian"]) < tol
+    assert rel_err(ilr.meanfield_predictive_weights(xx), g["pred_weights_gaussian"]) < tol
+    assert rel_err(ilr.meanfield_predictive_activation(X), g["pred_activation_gaussian"]) < tol
+    mus, covars = ilr.meanfield_predictive_moments(xx)
+    assert rel_err(mus, g["pred_mus_gaussian"]) < tol and rel_err(covars, g["pred_covars_gaussian"]) < tol
+    for pred in ("average", "mode"):
+        mu, var, std = ilr.meanfield_prediction(X, prediction=pred)
+        assert rel_err(mu, g[f"pred_{pred}_gaussian_mu"]) < tol, pred
+        assert rel_err(var, g[f"pred_{pred}_gaussian_var"]) < tol, pred
+        assert rel_err(std, g[f"pred_{pred}_gaussian_std"]) < tol, pred
+    mu, covar, std = ilr.meanfield_prediction(X, prediction='average', variance='full')
+    assert rel_err(covar, g["pred_average_gaussian_covar"]) < tol
+    # nlpd: no reference vector (the reference raises); consistent with its own tables
+    from scipy.special import logsumexp
+    mu, var, std, nlpd = ilr.meanfield_prediction(X, Y, prediction='average')
+    yy = ilr.output_transform.transform(Y)
+    log_pl = ilr.meanfiled_log_predictive_likelihood(xx, yy)
+    ref = - logsumexp(log_pl + np.log(ilr.meanfield_predictive_weights(xx) + np.finfo(float).tiny), axis=0)
+    assert rel_err(nlpd, ref) < tol
+    try:
+        ilr.meanfield_prediction(X, dist='studentt')
+    except NotImplementedError:
+        pass
+    else:
+        raise AssertionError("studentt must be rejected")

@@ -78,6 +78,10 @@ class OracleEngine:
         with np.errstate(invalid='ignore', divide='ignore'):
             return float(-np.nansum(t * np.log(t)))
 
+    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
+        f = lambda a: None if a is None else np.asarray(a, float)
+        return O.predict_canonical(self.Z, f(c), f(b), f(W), f(M), f(Q), f(Cc), affine, mode, f(y), f(P), f(ld))
+
     def get_resp(self, K=None):
         return self._resp
 

@@ -45,6 +45,49 @@ def test_ilr_scaled_gibbs_then_svi(engine):
     mc.check_ilr_svi("ilr_svi_dx2_dy1_k8", engine)
 
 
+def test_tied_gmm_gibbs_vi_em(engine):
+    mc.check_tied_gmm("tied_gmm_d3_k5", engine)
+
+
+@pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
+def test_tied_ilr_flow_and_prediction(name, engine):
+    mc.check_tied_ilr_prediction(name, engine)
+
+
+@pytest.mark.parametrize("N,dx,dy,K,affine", [(1000, 1, 1, 8, True), (777, 3, 2, 6, True), (4099, 8, 4, 64, True),
+                                              (513, 16, 8, 50, False), (300, 32, 3, 5, True), (1, 2, 2, 3, True),
+                                              (40001, 8, 4, 64, True)])
+def test_predict_kernel_vs_oracle(engine, N, dx, dy, K, affine):
+    """mimo_predict against its canonical-level restatement: mixture / arg-max moments and nlpd."""
+    from oracle import mimo_oracle as O
+    rng = np.random.default_rng(N + dx + K)
+    Z, c, b, W = _random_problem(rng, N, dx, K)
+    dc = dx + (1 if affine else 0)
+    M = rng.standard_normal((K, dy, dc))
+    A = rng.standard_normal((K, dc, dc)); Q = A @ A.transpose(0, 2, 1) / dc + 0.1 * np.eye(dc)
+    A = rng.standard_normal((K, dy, dy)); P = A @ A.transpose(0, 2, 1) / dy + 0.5 * np.eye(dy)
+    Cc, ld = np.linalg.inv(P), np.linalg.slogdet(P)[1]
+    y = rng.standard_normal((N, dy)) * 3.
+    engine.upload(Z)
+    for mode in ("average", "mode"):
+        mu, covar, nlpd = engine.predict(c, b, W, M, Q, Cc, affine=affine, mode=mode, y=y, P=P, ld=ld)
+        rmu, rcov, rnl = O.predict_canonical(Z, c, b, W, M, Q, Cc, affine, mode, y, P, ld)
+        assert rel_err(mu, rmu) < 1e-11 and rel_err(covar, rcov) < 1e-10 and rel_err(nlpd, rnl) < 1e-11, mode
+        mu2, covar2, none = engine.predict(c, b, W, M, Q, Cc, affine=affine, mode=mode)
+        assert none is None and np.array_equal(mu2, mu) and np.array_equal(covar2, covar)
+
+
+def test_predict_rejects_bad_shapes(engine):
+    rng = np.random.default_rng(0)
+    Z, c, b, W = _random_problem(rng, 64, 2, 3)
+    engine.upload(Z)
+    M, Q = rng.standard_normal((3, 9, 3)), np.tile(np.eye(3), (3, 1, 1))
+    with pytest.raises(Exception):
+        engine.predict(c, b, W, M, Q, np.tile(np.eye(9), (3, 1, 1)))          # dy = 9 > 8: unsupported
+    with pytest.raises(ValueError):
+        engine.predict(c, b, W, M[:, :2], Q[:, :2, :2], np.tile(np.eye(2), (3, 1, 1)))   # dc mismatch
+
+
 def test_unsupported_shapes_fail_loudly(engine):
     from mimo_amd import _lib
     with pytest.raises(_lib.MimoHipError):

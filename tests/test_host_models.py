@@ -40,6 +40,15 @@ def test_ilr_scaled_gibbs_then_svi():
     mc.check_ilr_svi("ilr_svi_dx2_dy1_k8", OracleEngine())
 
 
+def test_tied_gmm_gibbs_vi_em():
+    mc.check_tied_gmm("tied_gmm_d3_k5", OracleEngine())
+
+
+@pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
+def test_tied_ilr_flow_and_prediction(name):
+    mc.check_tied_ilr_prediction(name, OracleEngine())
+
+
 def test_batched_samplers_match_the_reference_law():
     """The batched (Generator) Normal-Wishart / Matrix-Normal-Wishart samplers of the fast Gibbs path
     have the same first two moments as the reference-order samplers."""

@@ -171,3 +171,57 @@ def test_philox_known_answer():
     c = raw([5, 0, 3, 0], [1337, 0])
     u = ((c[0] >> 5) * 67108864.0 + (c[1] >> 6)) / 9007199254740992.0
     assert O.philox_uniforms(1337, np.array([5]), 3)[0] == u
+
+
+@pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
+def test_prediction_restatement(name):
+    """ilr.py:339-430 / bayesian.py:303-313,949-962 restated in the oracle vs the reference's outputs
+    (posterior taken from the fixture, inputs in model coordinates)."""
+    g = load_golden(name)
+    X, Xtr, Ytr = g["X"], g["Xtr"], g["Ytr"]
+    xx = (X - Xtr.mean(0)) / Xtr.std(0)
+    bpost, mpost = nw_of(g, "vi_bpost"), mnw_of(g, "vi_mpost")
+    gmean = O.stick_mean(g["vi_gpost_gammas"], g["vi_gpost_deltas"])
+    assert rel_err(O.stacked_mvn_logpdf(xx, *O.nw_posterior_predictive_gaussian(bpost)), g["basis_logpred_gaussian"]) < 1e-10
+    assert rel_err(O.ilr_predictive_weights(xx, bpost, gmean), g["pred_weights_gaussian"]) < 1e-10
+    mus, lmbdas = O.mnw_posterior_predictive_gaussian(xx, mpost)
+    assert rel_err(mus, g["pred_mus_gaussian"]) < 1e-10
+    assert rel_err(np.linalg.inv(lmbdas), g["pred_covars_gaussian"]) < 1e-10
+    sd = Ytr.std(0)
+    for pred in ("average", "mode"):
+        mu, covar, _ = O.ilr_meanfield_prediction(xx, bpost, mpost, gmean, prediction=pred)
+        assert rel_err(mu * sd + Ytr.mean(0), g[f"pred_{pred}_gaussian_mu"]) < 1e-10
+        var = np.einsum('ndd->nd', covar) * Ytr.var(0)
+        assert rel_err(var, g[f"pred_{pred}_gaussian_var"]) < 1e-9
+    # the canonical-level statement of mimo_predict equals the reference-shaped one
+    Ms, Ks, psis, nus = mpost
+    dy = Ms.shape[1]
+    P = (nus - dy + 1)[:, None, None] * psis
+    pm, lm = O.nw_posterior_predictive_gaussian(bpost)
+    b = np.einsum('kdl,kl->kd', lm, pm)
+    c = -0.5 * np.einsum('kd,kd->k', pm, b) - 0.5 * xx.shape[1] * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(lm)[1] + np.log(gmean)
+    yy = (g["Y"] - Ytr.mean(0)) / sd
+    for pred in ("average", "mode"):
+        a1 = O.ilr_meanfield_prediction(xx, bpost, mpost, gmean, prediction=pred, y=yy)
+        a2 = O.predict_canonical(xx, c, b, lm, Ms, np.linalg.inv(Ks), np.linalg.inv(P), True, pred, yy, P,
+                                 np.linalg.slogdet(P)[1])
+        for u, v in zip(a1, a2):
+            assert rel_err(u, v) < 1e-9
+
+
+def test_tied_posterior_restatement():
+    """composite.py:273-283 / 798-808: pooled Wishart block, from the fixture's own Gibbs posterior."""
+    g = load_golden("tied_gmm_d3_k5")
+    mus, kappas, psis, nus = nw_of(g, "gibbs_post")
+    D = mus.shape[1]
+    nat = (kappas[:, None] * mus, kappas, g["gibbs_nat2"], nus - D)
+    out = O.tied_nw_nat_to_std(*nat, D)
+    for a, b in zip(out, (mus, kappas, psis, nus)):
+        assert rel_err(a, b) < 1e-10
+    g = load_golden("tied_ilr_sine_k8")
+    Ms, Ks, psis, nus = mnw_of(g, "vi_mpost")
+    dy, dc = Ms.shape[1], Ms.shape[2]
+    nat = (Ms @ Ks, Ks, np.linalg.inv(psis) + Ms @ Ks @ np.swapaxes(Ms, 1, 2), nus - dy - 1 + dc)
+    out = O.tied_mnw_nat_to_std(*nat, dy, dc)
+    for a, b in zip(out, (Ms, Ks, psis, nus)):
+        assert rel_err(a, b) < 1e-9
