@@ -168,6 +168,36 @@ int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);
 int mimo_get_lse(mimo_ctx* ctx, double* lse_host /* N */);
 int mimo_get_labels(mimo_ctx* ctx, int32_t* labels_host /* N */);
 
+/* ---- host-side conjugate algebra of the variational sweep (no GPU calls) ------------------
+ * The consumer of the statistics block and producer of the next launch's parameters: K small dense
+ * problems per sweep, batched in one call (threads over k when K D^3 is large).  Inputs are the
+ * posterior NATURAL parameters (prior + statistics).  Return MIMO_E_INVALID if a block is not
+ * positive definite (the caller then takes the NumPy route, which raises like the reference). */
+
+/* Normal-Wishart blocks.  Replaces per sweep: NormalWishart.nat_to_std (composite.py:67-72),
+ * expected_statistics (composite.py:106-118, wishart.py:139-143) and the canonical form of
+ * StackedGaussiansWithNormalWisharts.expected_log_likelihood (bayesian.py:287-301).
+ *   in : a (K,D) = kappa m, b (K) = kappa, c (K,D,D) = psi^-1 + kappa m m', d (K) = nu - D
+ *   out: mus (K,D), psis (K,D,D), nus (K), half_logdet_psi (K) = sum log diag chol psi,
+ *        (cc, bb, W) = canonical expected log-density WITHOUT the gating term,
+ *        E2 (K) = E[-1/2 mu'Lambda mu], E4 (K) = E[1/2 logdet Lambda]   (E1 = bb, E3 = -W/2). */
+int mimo_host_nw_vi(int K, int D, const double* a, const double* b, const double* c, const double* d,
+                    double* mus, double* psis, double* nus, double* half_logdet_psi,
+                    double* cc, double* bb, double* W, double* E2, double* E4);
+
+/* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
+ * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
+ * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).
+ *   in : a (K,dy,dc) = M K, b (K,dc,dc) = K, c (K,dy,dy) = psi^-1 + M K M', d (K) = nu - dy - 1 + dc
+ *   out: Ms (K,dy,dc), psis (K,dy,dy), nus (K), half_logdet_psi (K), Kinv (K,dc,dc),
+ *        (cc, bb, W) over z = [x, y] (Dz = dc - affine + dy), E1 (K,dy,dc), E2 (K,dc,dc), E4 (K). */
+int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
+                     const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
+                     double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4);
+
+/* digamma used by the two routines above (recurrence + asymptotic series), for tests. */
+double mimo_host_digamma(double x);
+
 /* ---- introspection --------------------------------------------------------------------- */
 
 /* Uniform the in-kernel Philox stream gives datum `row` at `sweep` (host-side mirror, used by

@@ -22,6 +22,38 @@ def _outer(a, b):
     return np.einsum('kd,kl->kdl', a, b)
 
 
+# ---------------------------------------------------------------------------------------------
+# Native batched route for the per-sweep posterior update (mimo_amd/csrc/mimo_host.cpp): natural
+# parameters -> standard parameters, expected statistics and the canonical (c, b, W) in ONE call
+# instead of ~40 NumPy calls on the critical path between two kernel launches.  Same formulas as
+# the NumPy methods below (which stay the reference-order implementation and the route taken when
+# a block is not positive definite, so errors surface exactly as before).  MIMO_HOST_NATIVE=0
+# switches it off.
+# ---------------------------------------------------------------------------------------------
+import ctypes as _C
+import os as _os
+
+NATIVE_HOST = _os.environ.get("MIMO_HOST_NATIVE", "1") != "0"
+
+
+def _native():
+    if not NATIVE_HOST:
+        return None
+    try:
+        from mimo_amd import _lib
+        return _lib.load()
+    except Exception:
+        return None
+
+
+def _p(a):
+    return a.__array_interface__['data'][0]      # plain address: ctypes' data_as() costs ~7 us per array
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
 class StackedNormalWisharts:
     """K independent Normal-Wishart distributions over (mu_k, Lambda_k):
     Lambda ~ W(psi, nu), mu | Lambda ~ N(m, (kappa Lambda)^-1)."""
@@ -62,8 +94,29 @@ class StackedNormalWisharts:
 
     @nat_param.setter
     def nat_param(self, natparam):
-        self.params = self.nat_to_std(natparam)
+        if not self._assign_native(natparam):
+            self.params = self.nat_to_std(natparam)
         self._cached('nat', lambda: Stats(natparam))   # the exact natural parameters just assigned
+
+    def _assign_native(self, natparam):
+        """mimo_host_nw_vi: standard parameters + every derived quantity the sweep needs, in one call."""
+        lib = _native()
+        if lib is None or type(self).nat_to_std is not StackedNormalWisharts.nat_to_std:
+            return False
+        a, b, c, d = (_c64(v) for v in natparam)
+        K, D = self.size, self.dim
+        if a.shape != (K, D) or b.shape != (K,) or c.shape != (K, D, D) or d.shape != (K,):
+            return False
+        mus, psis, nus, hld = np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty(K)
+        cc, bb, W, E2, E4 = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty(K)
+        if lib.mimo_host_nw_vi(K, D, _p(a), _p(b), _p(c), _p(d), _p(mus), _p(psis), _p(nus), _p(hld),
+                               _p(cc), _p(bb), _p(W), _p(E2), _p(E4)) != 0:
+            return False
+        self.params = (mus, b.copy(), psis, nus)
+        self._cached('hld', lambda: hld)
+        self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
+        self._cached('canon', lambda: (cc, bb, W))
+        return True
 
     def std_to_nat(self, params):
         """eta = [kappa m, kappa, psi^-1 + kappa m m', nu - D]  (composite.py:50-65)."""
@@ -132,8 +185,10 @@ class StackedNormalWisharts:
 
     def canonical_expected(self):
         """(c, b, W) of <E_q[eta_k], t(x)> + log_base  (bayesian.py:287-301): the VI E-step form."""
-        E1, E2, E3, E4 = self.expected_statistics()
-        return self.log_base() + E2 + E4, E1, - 2. * E3
+        def numpy_route():
+            E1, E2, E3, E4 = self.expected_statistics()
+            return self.log_base() + E2 + E4, E1, - 2. * E3
+        return self._cached('canon', numpy_route)
 
     @staticmethod
     def _inner(nat, stats):
@@ -190,8 +245,31 @@ class StackedMatrixNormalWisharts:
 
     @nat_param.setter
     def nat_param(self, natparam):
-        self.params = self.nat_to_std(natparam)
+        if not self._assign_native(natparam):
+            self.params = self.nat_to_std(natparam)
         self._cached('nat', lambda: Stats(natparam))
+
+    def _assign_native(self, natparam):
+        """mimo_host_mnw_vi (affine and non-affine canonical forms are both kept)."""
+        lib = _native()
+        if lib is None or type(self).nat_to_std is not StackedMatrixNormalWisharts.nat_to_std:
+            return False
+        a, b, c, d = (_c64(v) for v in natparam)
+        K, dy, dc = self.size, self.row_dim, self.column_dim
+        if a.shape != (K, dy, dc) or b.shape != (K, dc, dc) or c.shape != (K, dy, dy) or d.shape != (K,) or dc < 2:
+            return False
+        Ms, psis, nus, hld, Kinv = np.empty((K, dy, dc)), np.empty((K, dy, dy)), np.empty(K), np.empty(K), np.empty((K, dc, dc))
+        E1, E2, E4 = np.empty((K, dy, dc)), np.empty((K, dc, dc)), np.empty(K)
+        Dz = dc - 1 + dy
+        cc, bb, W = np.empty(K), np.empty((K, Dz)), np.empty((K, Dz, Dz))
+        if lib.mimo_host_mnw_vi(K, dy, dc, 1, _p(a), _p(b), _p(c), _p(d), _p(Ms), _p(psis), _p(nus), _p(hld), _p(Kinv),
+                                _p(cc), _p(bb), _p(W), _p(E1), _p(E2), _p(E4)) != 0:
+            return False
+        self.params = (Ms, b.copy(), psis, nus)
+        self._cached('hld', lambda: hld)
+        self._cached('estats', lambda: (E1, E2, - 0.5 * nus[:, None, None] * psis, E4))
+        self._cached('canon_affine', lambda: (cc, bb, W))
+        return True
 
     def std_to_nat(self, params):
         """eta = [M K, K, psi^-1 + M K M', nu - d - 1 + l]  (composite.py:577-592)."""
@@ -264,6 +342,10 @@ class StackedMatrixNormalWisharts:
         """(c, b, W) over z = [x, y] of the expected log-density of y | x (bayesian.py:933-947):
         <E[Lambda A], y x~'> + <E[-1/2 A'Lambda A], x~ x~'> + <E[-1/2 Lambda], y y'> + E[1/2 logdet] + log_base
         with x~ = [x, 1] when affine."""
+        if affine:
+            hit = self.__dict__.get('_memo', {})
+            if hit.get('key') == tuple(id(p) for p in self.params) and 'canon_affine' in hit:
+                return hit['canon_affine']
         E1, E2, E3, E4 = self.expected_statistics()
         dy, dc = self.row_dim, self.column_dim
         dx = dc - 1 if affine else dc
