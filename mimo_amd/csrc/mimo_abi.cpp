@@ -204,6 +204,12 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
         put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
     }
   }
+  // padding components of the last row block: l = -1e300 for every datum, so the normalise phase needs no
+  // "does this component exist" test (exp -> 0, never the maximum, zero weight in the statistics)
+  for (int k = K; k < 16 * ((K + 15) / 16); ++k) {
+    const int f = feat_index(D, D, D);
+    img[((size_t)(k / 16) * NS + f / 4) * 64 + (f % 4) * 16 + k % 16] = kPadLogDensity;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MIMO_OK;
 }

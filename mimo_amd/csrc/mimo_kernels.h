@@ -87,6 +87,7 @@ struct PredictArgs {
   double* mu; double* covar; double* nlpd;
 };
 constexpr int kMaxPredictDy = 8;
+constexpr double kPadLogDensity = -1e300;   // c_k of the padding components k in [K, 16*K16)
 hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupported);
 
 }  // namespace mimo

@@ -120,7 +120,9 @@ __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
   q = fma(r, q, 1.0);
   const double e = tab[n & 63] * fma(r, q, 1.0);
   const double scaled = __hiloint2double(__double2hiint(e) + ((n >> 6) << 20), __double2loint(e));
-  return x < -700.0 ? 0.0 : scaled;
+  // x < -700 (also -inf) tested on the high word with an integer compare — not an f64 pipe slot:
+  // for x <= 0 the bit pattern grows with |x|; hi(-700.0) = 0xC085E000
+  return (unsigned)__double2hiint(x) > 0xC085E000u ? 0.0 : scaled;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -155,9 +157,37 @@ __device__ __forceinline__ void build_features_static(const double (&z)[D + 2], 
 }
 
 // ------------------------------------------------------------------------------------------
+// Short dependency chains.  The f64 VALU shares its pipe with the f64 MFMA, and the wave of the OTHER
+// workgroup on this SIMD is usually inside a matrix phase: every time this wave has no ready f64
+// instruction (it waits for the previous result), the pipe goes to an MFMA for 64 cycles.  A dependent
+// chain therefore costs ~70 cycles per link, an independent group ~6 per instruction (measured with
+// what-if builds at C3: the 32-link max / running-sum / compare chains were 45 % of the normalise phase).
+// All reductions below are trees, the cumulative sum is a Kogge-Stone scan.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double tree_max8(const double (&v)[8]) {
+  return fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
+}
+__device__ __forceinline__ double tree_sum8(const double (&v)[8]) {   // == scan8(v)[7], bit for bit
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+__device__ __forceinline__ void scan8(double (&x)[8]) {               // inclusive, 3 levels
+  double a[8], b[8];
+  a[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) a[i] = x[i - 1] + x[i];
+  b[0] = a[0]; b[1] = a[1];
+#pragma unroll
+  for (int i = 2; i < 8; ++i) b[i] = a[i - 2] + a[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = b[i];
+#pragma unroll
+  for (int i = 4; i < 8; ++i) x[i] = b[i - 4] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-datum normalisation over k of one 32-row tile held in LDS as Lt[row][component]:
-// 8 lanes per datum, 2*K16 consecutive components per lane, fully unrolled.  Softmax -> r written
-// back in place, or inverse-CDF categorical draw -> one-hot written back (+ label to HBM).
+// 8 lanes per datum, 2*K16 consecutive components per lane (<= 8 here: RBW = 1), fully unrolled.
+// Softmax -> r written back in place, or inverse-CDF categorical draw -> label (LDS + HBM).
 // ------------------------------------------------------------------------------------------
 template <int RBW, int MODE>
 __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __restrict__ Lt, const int LS,
@@ -166,79 +196,83 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
                                                const bool gibbs, double* const out_logp, double* const out_resp,
                                                double* const out_lse, double& sc_lse, double& sc_rl, double& sc_prod,
                                                int* __restrict__ labs) {
-        constexpr int CPM = 8 * RBW;  // most components a lane can own (Kpad <= 64 * RBW)
+        static_assert(RBW == 1, "register variant: at most 8 components per lane");
         const int pt = 8 * wave + (lane & 7), part = lane >> 3;
         const int CPP = 2 * K16, k0 = part * CPP;
         const int64_t n = n0 + pt;
         const bool valid = n < N;
         double* row = Lt + pt * LS + k0;
 
+        auto body = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        // Padding components (k >= K inside the last row block) carry l = kPadLogDensity from the operand
+        // image, so only the HBM table writes test k < K.  FULL: this lane owns all 8 slots (K16 = 4) and no
+        // slot test is compiled at all; otherwise slots c >= CPP belong to the next lane and are masked.
+        auto ok = [&](int c) { return FULL || c < CPP; };
         // x[] holds l, then exp(l - max), then the weight written back — one register array
-        double x[CPM];
+        double x[8], lsave[8];
 #pragma unroll
-        for (int c = 0; c < CPM; ++c) x[c] = (c < CPP && k0 + c < K) ? row[c] : -INFINITY;
+        for (int c = 0; c < 8; ++c) x[c] = ok(c) ? row[c] : -INFINITY;
         if (out_logp && valid) {
 #pragma unroll
-          for (int c = 0; c < CPM; ++c)
+          for (int c = 0; c < 8; ++c)
             if (c < CPP && k0 + c < K) out_logp[(int64_t)(k0 + c) * N + n] = x[c];
         }
-        double m = x[0];
-#pragma unroll
-        for (int c = 1; c < CPM; ++c) m = fmax(m, x[c]);
+        double m = tree_max8(x);
         m = fmax(m, __shfl_xor(m, 8));
         m = fmax(m, __shfl_xor(m, 16));
         m = fmax(m, __shfl_xor(m, 32));
 
-        double ssum = 0.0, sel = 0.0;
 #pragma unroll
-        for (int c = 0; c < CPM; ++c) {
-          const double lc = x[c];
-          x[c] = exp_nonpos(lc - m, etab);              // inactive slots: l = -inf -> 0
-          ssum += x[c];
-          if constexpr (MODE == kGeneric) sel = fma(x[c], (c < CPP && k0 + c < K) ? lc : 0.0, sel);
-          if (MIMO_EXP_CHAINS < 8 && (c & (MIMO_EXP_CHAINS - 1)) == MIMO_EXP_CHAINS - 1) __builtin_amdgcn_sched_barrier(0);   // bounded ILP
+        for (int c = 0; c < 8; ++c) {
+          if constexpr (MODE == kGeneric) lsave[c] = (c < CPP && k0 + c < K) ? x[c] : 0.0;
+          x[c] = exp_nonpos(x[c] - m, etab);              // masked / padding slots -> 0
         }
-        ssum += __shfl_xor(ssum, 8);
-        ssum += __shfl_xor(ssum, 16);
-        ssum += __shfl_xor(ssum, 32);
-        if constexpr (MODE == kGeneric) {   // sum_k r l only feeds the entropy split of the ELBO (scalars[1..2])
+        double sel = 0.0;
+        if constexpr (MODE == kGeneric) {   // sum_k e l only feeds the entropy split of the ELBO (scalars[1..2])
+          double t[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) t[c] = x[c] * lsave[c];
+          sel = tree_sum8(t);
           sel += __shfl_xor(sel, 8);
           sel += __shfl_xor(sel, 16);
           sel += __shfl_xor(sel, 32);
         }
-        // 1 / sum: v_rcp_f64 seed + two Newton steps (5 dependent f64 ops instead of the IEEE divide's
-        // ~12; every one of them waits for a matrix-pipe slot); relative error <= 1 ulp-ish (2^-52).
-        double inv = __builtin_amdgcn_rcp(ssum);
-        inv = fma(fma(-ssum, inv, 1.0), inv, inv);
-        inv = fma(fma(-ssum, inv, 1.0), inv, inv);
-
-        double lse = 0.0;
-        if constexpr (MODE == kGeneric) {
-          lse = m + log(ssum);
-          if (part == 0 && valid) {
-            sc_lse += lse;
-            sc_rl += sel * inv;
-            if (out_lse) out_lse[n] = lse;
-          }
-        } else {
-          // fast modes only need sum_n lse_n = sum_n m_n + log prod_n ssum_n: the product of the per-datum
-          // sums (each in [1, K]) is accumulated and its log taken once per 64 tiles by the caller.
-          if (part == 0 && valid) {
-            sc_lse += m;
-            sc_prod *= ssum;
-          }
-        }
 
         if (!gibbs) {
+          double ssum = tree_sum8(x);
+          ssum += __shfl_xor(ssum, 8);
+          ssum += __shfl_xor(ssum, 16);
+          ssum += __shfl_xor(ssum, 32);
+          // 1 / sum: v_rcp_f64 seed + two Newton steps (5 dependent f64 ops instead of the IEEE divide's
+          // ~12; every one of them waits for a matrix-pipe slot); relative error <= 1 ulp-ish (2^-52).
+          double inv = __builtin_amdgcn_rcp(ssum);
+          inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+          inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+          if constexpr (MODE == kGeneric) {
+            const double lse = m + log(ssum);
+            if (part == 0 && valid) {
+              sc_lse += lse;
+              sc_rl += sel * inv;
+              if (out_lse) out_lse[n] = lse;
+            }
+          } else {
+            // fast modes only need sum_n lse_n = sum_n m_n + log prod_n ssum_n: the product of the per-datum
+            // sums (each in [1, K]) is accumulated and its log taken once per 64 tiles by the caller.
+            if (part == 0 && valid) {
+              sc_lse += m;
+              sc_prod *= ssum;
+            }
+          }
           const double scale = valid ? inv : 0.0;
 #pragma unroll
-          for (int c = 0; c < CPM; ++c) {
+          for (int c = 0; c < 8; ++c) {
             x[c] *= scale;
-            if (c < CPP) row[c] = x[c];
+            if (ok(c)) row[c] = x[c];
           }
           if (out_resp && valid) {
 #pragma unroll
-            for (int c = 0; c < CPM; ++c)
+            for (int c = 0; c < 8; ++c)
               if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c];
           }
         } else {
@@ -246,12 +280,8 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           // cum = cumsum_k exp(l_k - lse).  The count is invariant to the common factor 1/sum e, so the
           // UNNORMALISED cumulative sums E_k = sum_{j<=k} e_j are compared with u * E_K (same labels up
           // to last-bit ties; no per-component scaling, no one-hot table: only the label is kept).
-          double cum = 0.0;
-#pragma unroll
-          for (int c = 0; c < CPM; ++c) {
-            cum += x[c];
-            x[c] = cum;  // local inclusive cumulative sum
-          }
+          scan8(x);                                  // local inclusive cumulative sums
+          const double cum = x[7];
           double incl = cum;  // inclusive scan over the 8 parts of this datum
           {
             double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
@@ -261,13 +291,26 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           double excl = __shfl_up(incl, 8);
           if (part == 0) excl = 0.0;
           const double ctot = __shfl(excl + cum, 56 + (lane & 7));  // == last cumulative value
+          if constexpr (MODE == kGeneric) {
+            const double lse = m + log(ctot);
+            if (part == 0 && valid) {
+              sc_lse += lse;
+              sc_rl += sel / ctot;
+              if (out_lse) out_lse[n] = lse;
+            }
+          } else {
+            if (part == 0 && valid) {
+              sc_lse += m;
+              sc_prod *= ctot;
+            }
+          }
           const double uu = a.u ? (valid ? a.u[n] : 0.0)
                                 : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
           const double tl = uu * ctot - excl;   // threshold in this lane's local cumulative scale
           int cnt = 0;
 #pragma unroll
-          for (int c = 0; c < CPM; ++c)
-            cnt += (c < CPP && k0 + c < K && tl > x[c]) ? 1 : 0;
+          for (int c = 0; c < 8; ++c)     // (padding slots can only be counted above the last real one: capped below)
+            cnt += (ok(c) && tl > x[c]) ? 1 : 0;
           cnt += __shfl_xor(cnt, 8);
           cnt += __shfl_xor(cnt, 16);
           cnt += __shfl_xor(cnt, 32);
@@ -277,11 +320,18 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
             if (valid && a.labels) a.labels[n] = label;
           }
         }
+        };
+        if (CPP == 8) body(std::true_type{});
+        else body(std::false_type{});
 }
 
-// Same contract as normalise_tile for lanes that own up to 8*RBW components (RBW > 1): the values are
-// processed in chunks of 8 that live in LDS between the passes (max / exp+sum / scale or cumulative),
-// so only 8 of them are in registers at a time.  Each lane re-reads only what it wrote itself.
+// Same contract for lanes that own up to 8*RBW components (RBW > 1), processed in chunks of 8.
+//   pass 1: max (8 independent chains across the chunks, then a tree)
+//   pass 2: e = exp(l - max), chunk totals T[ch] (trees); softmax: e written back, scaled in pass 3;
+//           Gibbs: nothing is written — l stays in LDS
+//   pass 3 (Gibbs): the chunk that holds the crossing is located from the chunk totals (registers), and
+//           only ITS eight e are recomputed from l (same function of the same inputs: bit-identical to
+//           pass 2), scanned and compared — 8 LDS reads and 12 compares instead of 32 + 32, no LDS writes.
 template <int RBW, int MODE>
 __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, double* __restrict__ Lt, const int LS,
                                                        const double* __restrict__ etab, const int K, const int K16,
@@ -295,81 +345,99 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
   const int64_t n = n0 + pt;
   const bool valid = n < N;
   double* row = Lt + pt * LS + k0;
-  auto active = [&](int c) { return c < CPP && k0 + c < K; };
+  // padding components carry l = kPadLogDensity (operand image): only HBM table writes test k < K.
+  // FULL: the lane owns all 8*RBW slots (K16 = 4*RBW) and no slot test is compiled.
+  auto body = [&](auto full_c) {
+  constexpr bool FULL = decltype(full_c)::value;
+  auto ok = [&](int c) { return FULL || c < CPP; };
+  auto active = [&](int c) { return ok(c) && k0 + c < K; };
 
-  double m = -INFINITY;
+  double mv[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) mv[cc] = -INFINITY;
 #pragma unroll
   for (int ch = 0; ch < RBW; ++ch) {
-    if (8 * ch < CPP) {
+    if (FULL || 8 * ch < CPP) {
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
         const int c = 8 * ch + cc;
-        const double l = active(c) ? row[c] : -INFINITY;
+        const double l = ok(c) ? row[c] : -INFINITY;
         if (out_logp && valid && active(c)) out_logp[(int64_t)(k0 + c) * N + n] = l;
-        m = fmax(m, l);
+        mv[cc] = fmax(mv[cc], l);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // one chunk of LDS reads in flight at a time (register pressure)
   }
+  double m = tree_max8(mv);
   m = fmax(m, __shfl_xor(m, 8));
   m = fmax(m, __shfl_xor(m, 16));
   m = fmax(m, __shfl_xor(m, 32));
 
-  double ssum = 0.0, sel = 0.0, cum = 0.0;
+  double T[RBW], selv[RBW];
 #pragma unroll
   for (int ch = 0; ch < RBW; ++ch) {
-    if (8 * ch < CPP) {
-      double x[8];
+    T[ch] = 0.0;
+    selv[ch] = 0.0;
+    if (FULL || 8 * ch < CPP) {
+      double x[8], lc[8];
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) x[cc] = active(8 * ch + cc) ? row[8 * ch + cc] : -INFINITY;
+      for (int cc = 0; cc < 8; ++cc) lc[cc] = ok(8 * ch + cc) ? row[8 * ch + cc] : -INFINITY;
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const double lc = x[cc];
-        x[cc] = exp_nonpos(lc - m, etab);
-        ssum += x[cc];
-        if constexpr (MODE == kGeneric) sel = fma(x[cc], active(8 * ch + cc) ? lc : 0.0, sel);
-        if ((cc & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int cc = 0; cc < 8; ++cc) x[cc] = exp_nonpos(lc[cc] - m, etab);
+      T[ch] = tree_sum8(x);
+      if constexpr (MODE == kGeneric) {
+        double t[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) t[cc] = x[cc] * (active(8 * ch + cc) ? lc[cc] : 0.0);
+        selv[ch] = tree_sum8(t);
       }
-      if (gibbs) {   // Gibbs keeps the running (unnormalised) cumulative sum instead of e itself
+      if (!gibbs) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) { cum += x[cc]; x[cc] = cum; }
+        for (int cc = 0; cc < 8; ++cc)
+          if (ok(8 * ch + cc)) row[8 * ch + cc] = x[cc];
       }
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc)
-        if (8 * ch + cc < CPP) row[8 * ch + cc] = x[cc];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);   // one chunk of exp chains in flight at a time (register pressure)
   }
-  ssum += __shfl_xor(ssum, 8);
-  ssum += __shfl_xor(ssum, 16);
-  ssum += __shfl_xor(ssum, 32);
+  // exclusive prefix of the chunk totals (base[ch] = sum of the chunks before ch) and the lane total
+  double base[RBW + 1];
+  base[0] = 0.0;
+#pragma unroll
+  for (int ch = 0; ch < RBW; ++ch) base[ch + 1] = base[ch] + T[ch];
+  const double cum = base[RBW];
+  double sel = 0.0;
   if constexpr (MODE == kGeneric) {
+#pragma unroll
+    for (int ch = 0; ch < RBW; ++ch) sel += selv[ch];
     sel += __shfl_xor(sel, 8);
     sel += __shfl_xor(sel, 16);
     sel += __shfl_xor(sel, 32);
   }
-  double inv = __builtin_amdgcn_rcp(ssum);
-  inv = fma(fma(-ssum, inv, 1.0), inv, inv);
-  inv = fma(fma(-ssum, inv, 1.0), inv, inv);
-  if constexpr (MODE == kGeneric) {
-    const double lse = m + log(ssum);
-    if (part == 0 && valid) {
-      sc_lse += lse;
-      sc_rl += sel * inv;
-      if (out_lse) out_lse[n] = lse;
-    }
-  } else {
-    if (part == 0 && valid) {
-      sc_lse += m;
-      sc_prod *= ssum;
-    }
-  }
 
   if (!gibbs) {
+    double ssum = cum;
+    ssum += __shfl_xor(ssum, 8);
+    ssum += __shfl_xor(ssum, 16);
+    ssum += __shfl_xor(ssum, 32);
+    double inv = __builtin_amdgcn_rcp(ssum);
+    inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+    inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+    if constexpr (MODE == kGeneric) {
+      const double lse = m + log(ssum);
+      if (part == 0 && valid) {
+        sc_lse += lse;
+        sc_rl += sel * inv;
+        if (out_lse) out_lse[n] = lse;
+      }
+    } else {
+      if (part == 0 && valid) {
+        sc_lse += m;
+        sc_prod *= ssum;
+      }
+    }
     const double scale = valid ? inv : 0.0;
 #pragma unroll
     for (int c = 0; c < 8 * RBW; ++c) {
-      if (c < CPP) {
+      if (ok(c)) {
         const double r = row[c] * scale;
         row[c] = r;
         if (out_resp && valid && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = r;
@@ -377,7 +445,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
       if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
-    // scale-invariant inverse CDF on the unnormalised cumulative sums written by the exp pass
+    // scale-invariant inverse CDF on the unnormalised cumulative sums (see normalise_tile)
     double incl = cum;
     {
       double v = __shfl_up(incl, 8);  if (part >= 1) incl += v;
@@ -387,13 +455,44 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
     double excl = __shfl_up(incl, 8);
     if (part == 0) excl = 0.0;
     const double ctot = __shfl(excl + cum, 56 + (lane & 7));
+    if constexpr (MODE == kGeneric) {
+      const double lse = m + log(ctot);
+      if (part == 0 && valid) {
+        sc_lse += lse;
+        sc_rl += sel / ctot;
+        if (out_lse) out_lse[n] = lse;
+      }
+    } else {
+      if (part == 0 && valid) {
+        sc_lse += m;
+        sc_prod *= ctot;
+      }
+    }
     const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
     const double tl = uu * ctot - excl;
-    int cnt = 0;
+    // chunk of the crossing: j = #{ch : tl > cumulative sum at the END of chunk ch}
+    int j = 0;
 #pragma unroll
-    for (int c = 0; c < 8 * RBW; ++c) {
-      if (c < CPP) cnt += (k0 + c < K && tl > row[c]) ? 1 : 0;
-      if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    for (int ch = 0; ch < RBW; ++ch) j += (tl > base[ch + 1]) ? 1 : 0;
+    // components of this lane that exist at all (the count if tl lies above every cumulative sum)
+    int cnt;
+    if ((!FULL && 8 * j >= CPP) || j >= RBW) {
+      cnt = CPP;      // above every cumulative sum of this lane (padding slots included: capped below)
+    } else {
+      double bj = base[0];
+#pragma unroll
+      for (int ch = 1; ch < RBW; ++ch) bj = (j == ch) ? base[ch] : bj;
+      const double* rj = row + 8 * j;
+      double x[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) x[cc] = (FULL || 8 * j + cc < CPP) ? rj[cc] : -INFINITY;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) x[cc] = exp_nonpos(x[cc] - m, etab);
+      scan8(x);
+      const double tj = tl - bj;
+      cnt = 8 * j;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) cnt += ((FULL || 8 * j + cc < CPP) && tj > x[cc]) ? 1 : 0;
     }
     cnt += __shfl_xor(cnt, 8);
     cnt += __shfl_xor(cnt, 16);
@@ -404,6 +503,9 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
       if (valid && a.labels) a.labels[n] = label;
     }
   }
+  };
+  if (CPP == 8 * RBW) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------

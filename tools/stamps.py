@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mimo_amd._lib as L
-L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmimo_hip_stamps.so")
+L.LIB_PATH = os.environ.get("STAMPS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmimo_hip_stamps.so")
 from mimo_amd.engine import HipEngine
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 16
