@@ -103,26 +103,29 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// exp(x) for x <= 0 in 10 float64 pipe operations (the f64 VALU shares its pipe with the f64 MFMA on
-// gfx950, so every f64 instruction of the softmax is paid in matrix issue slots):
-//   n = rint(x * 64/ln2) via the 1.5*2^52 trick, r = x - n ln2/64 (two-term Cody-Waite, |r| <= ln2/128),
+// exp(x) for x <= 0 in 9 float64 pipe operations + 6 integer ones (the f64 VALU shares its pipe with the
+// f64 MFMA on gfx950 and the normalise phase is bound by its instruction count, so every instruction of
+// the softmax is paid in matrix issue slots):
+//   n = rint(x * 64/ln2) via the 1.5*2^52 trick, r = x - n ln2/64 in ONE fma (|r| <= ln2/128),
 //   exp(x) = 2^(n>>6) * tab[n & 63] * (1 + r + ... + r^5/120),  tab[j] = 2^(j/64) in LDS.
-// Max relative error 4e-16 on [-700, 0]; x < -700 (exp < 1e-304) returns 0.
+// The single-constant reduction leaves an error of |n| * 1.2e-18 in r, i.e. a relative error of
+// 1.1e-16 * |x| in the result — an ABSOLUTE error below 4e-17 for every x <= 0 (max of |x| e^x), which is
+// what a sum of exponentials whose largest term is 1 sees.  x < -700 (exp < 1e-304) returns a denormal
+// below 1e-308 (only the high word is cleared) — zero for every purpose here.
 __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
   const double t = fma(x, 92.33248261689366, 6755399441055744.0);
   const int n = __double2loint(t);
   const double nf = t - 6755399441055744.0;
-  double r = fma(nf, -0x1.62e42fe000000p-7, x);
-  r = fma(nf, -0x1.f473de6af278fp-36, r);
+  const double r = fma(nf, -0x1.62e42fefa39efp-7, x);
   double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
   q = fma(r, q, 1.0 / 6.0);
   q = fma(r, q, 0.5);
   q = fma(r, q, 1.0);
   const double e = tab[n & 63] * fma(r, q, 1.0);
-  const double scaled = __hiloint2double(__double2hiint(e) + ((n >> 6) << 20), __double2loint(e));
-  // x < -700 (also -inf) tested on the high word with an integer compare — not an f64 pipe slot:
-  // for x <= 0 the bit pattern grows with |x|; hi(-700.0) = 0xC085E000
-  return (unsigned)__double2hiint(x) > 0xC085E000u ? 0.0 : scaled;
+  // x < -700 (also -inf and the -1e300 of padding components) tested on the high word with an integer
+  // compare — not an f64 pipe slot: for x <= 0 the bit pattern grows with |x|; hi(-700.0) = 0xC085E000
+  const int hi = (unsigned)__double2hiint(x) > 0xC085E000u ? 0 : __double2hiint(e) + ((n >> 6) << 20);
+  return __hiloint2double(hi, __double2loint(e));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -327,11 +330,10 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
 
 // Same contract for lanes that own up to 8*RBW components (RBW > 1), processed in chunks of 8.
 //   pass 1: max (8 independent chains across the chunks, then a tree)
-//   pass 2: e = exp(l - max), chunk totals T[ch] (trees); softmax: e written back, scaled in pass 3;
-//           Gibbs: nothing is written — l stays in LDS
-//   pass 3 (Gibbs): the chunk that holds the crossing is located from the chunk totals (registers), and
-//           only ITS eight e are recomputed from l (same function of the same inputs: bit-identical to
-//           pass 2), scanned and compared — 8 LDS reads and 12 compares instead of 32 + 32, no LDS writes.
+//   pass 2: e = exp(l - max) written back in place, chunk totals T[ch] (trees) kept in registers
+//   pass 3: softmax: e scaled by 1/sum.  Gibbs: the chunk that holds the crossing is located from the
+//           chunk totals, and only ITS eight e are read back, scanned and compared — 8 LDS reads and 12
+//           compares instead of 32 + 32.
 template <int RBW, int MODE>
 __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, double* __restrict__ Lt, const int LS,
                                                        const double* __restrict__ etab, const int K, const int K16,
@@ -390,11 +392,9 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
         for (int cc = 0; cc < 8; ++cc) t[cc] = x[cc] * (active(8 * ch + cc) ? lc[cc] : 0.0);
         selv[ch] = tree_sum8(t);
       }
-      if (!gibbs) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-          if (ok(8 * ch + cc)) row[8 * ch + cc] = x[cc];
-      }
+      for (int cc = 0; cc < 8; ++cc)        // e replaces l in place (softmax: scaled in pass 3; Gibbs: the
+        if (ok(8 * ch + cc)) row[8 * ch + cc] = x[cc];   // crossing chunk is read back in pass 3)
     }
     __builtin_amdgcn_sched_barrier(0);   // one chunk of exp chains in flight at a time (register pressure)
   }
@@ -485,9 +485,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
       const double* rj = row + 8 * j;
       double x[8];
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) x[cc] = (FULL || 8 * j + cc < CPP) ? rj[cc] : -INFINITY;
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) x[cc] = exp_nonpos(x[cc] - m, etab);
+      for (int cc = 0; cc < 8; ++cc) x[cc] = (FULL || 8 * j + cc < CPP) ? rj[cc] : 0.0;
       scan8(x);
       const double tj = tl - bj;
       cnt = 8 * j;
@@ -838,8 +836,45 @@ void fused_kernel(const KernelArgs a) {
           else stats_body(std::integral_constant<int, 1>{}, lab_c);
         }
       };
-      if constexpr (MODE == kFastGibbs || MODE == kModeLabels) stats_nact(std::true_type{});
-      else if constexpr (MODE == kGeneric) { if (gibbs) stats_nact(std::true_type{}); else stats_nact(std::false_type{}); }
+      // Hard labels, K > 16: the weight tile is one-hot, so row block rb only receives the rows whose label
+      // falls into it — on average 32/K16 of the 32.  Instead of contracting all 8 steps against a mostly
+      // zero A operand, the members of each row block are compacted (wave ballot -> scalar bit scan) and
+      // contracted 4 at a time: ~1 step per row block instead of 8 (K = 256: 12 MFMAs per wave-tile
+      // instead of 96).  Every row is a member of exactly one row block, so the sums are the same sums.
+      auto stats_sparse = [&]() {
+        const int rbl = labs[lane & 31] >> 4;          // row block of row (lane & 31); -1 for rows beyond N
+        const int shift = 8 * q;
+#pragma unroll
+        for (int i = 0; i < RBW; ++i) {
+          const int rb = wave + 4 * i;
+          if (rb < K16) {
+            uint32_t m = (uint32_t)__ballot(rbl == rb);   // lanes 32..63 repeat lanes 0..31: low half only
+            while (m) {
+              uint32_t packed = 0;                         // row indices of the next (up to) 4 members, 0xFF = none
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t d = m ? (uint32_t)__builtin_ctz(m) : 0xFFu;
+                m &= m - 1;
+                packed |= d << (8 * e);
+              }
+              const uint32_t mine = (packed >> shift) & 0xFFu;   // lane (kk = q) contracts member q
+              const bool have = mine != 0xFFu;
+              const int row_d = have ? (int)mine : 0;
+              const double av = (have && (labs[row_d] & 15) == j) ? 1.0 : 0.0;
+              const double* pb = Ph + row_d * RS + j;
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb)
+                sacc[i][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * cb], sacc[i][cb], 0, 0, 0);
+            }
+          }
+        }
+      };
+      auto stats_labels = [&]() {
+        if (K16 >= 2) stats_sparse();
+        else stats_nact(std::true_type{});
+      };
+      if constexpr (MODE == kFastGibbs || MODE == kModeLabels) stats_labels();
+      else if constexpr (MODE == kGeneric) { if (gibbs) stats_labels(); else stats_nact(std::false_type{}); }
       else stats_nact(std::false_type{});
     }
 
