@@ -1,9 +1,11 @@
 from .gating import Categorical, Dirichlet, TruncatedStickBreaking
 from .wishart import Wishart
-from .gaussian import StackedGaussiansWithPrecision, TiedGaussiansWithPrecision
+from .gaussian import (StackedGaussiansWithPrecision, TiedGaussiansWithPrecision,
+                       StackedGaussiansWithDiagonalPrecision, TiedGaussiansWithDiagonalPrecision)
 from .lingauss import StackedLinearGaussiansWithPrecision, TiedLinearGaussiansWithPrecision
 from .composite import (StackedNormalWisharts, StackedMatrixNormalWisharts, TiedNormalWisharts,
-                        TiedMatrixNormalWisharts)
+                        TiedMatrixNormalWisharts, StackedNormalGammas, TiedNormalGammas)
 from .bayesian import (CategoricalWithDirichlet, CategoricalWithStickBreaking,
                        StackedGaussiansWithNormalWisharts, StackedLinearGaussiansWithMatrixNormalWisharts,
-                       TiedGaussiansWithNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts)
+                       TiedGaussiansWithNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts,
+                       StackedGaussiansWithNormalGammas, TiedGaussiansWithNormalGammas)

@@ -14,7 +14,9 @@ import copy
 import numpy as np
 
 from mimo_amd.distributions.gating import Categorical
-from mimo_amd.distributions.gaussian import StackedGaussiansWithPrecision, TiedGaussiansWithPrecision
+from mimo_amd.distributions.gaussian import (StackedGaussiansWithPrecision, TiedGaussiansWithPrecision,
+                                             StackedGaussiansWithDiagonalPrecision,
+                                             TiedGaussiansWithDiagonalPrecision)
 from mimo_amd.distributions.lingauss import StackedLinearGaussiansWithPrecision, TiedLinearGaussiansWithPrecision
 
 
@@ -216,6 +218,48 @@ class TiedGaussiansWithNormalWisharts(StackedGaussiansWithNormalWisharts):
             mus, lmbdas = prior.rvs()
             likelihood = TiedGaussiansWithPrecision(size=size, dim=dim, mus=mus, lmbdas=lmbdas, engine=engine)
         super().__init__(size, dim, prior, likelihood, engine=engine)
+
+
+class StackedGaussiansWithNormalGammas(StackedGaussiansWithNormalWisharts):
+    """Diagonal-precision Gaussians under Normal-Gamma priors / posteriors (bayesian.py:343-481).
+    Same update skeleton as the Normal-Wishart block; the engine evaluates the same canonical form with a
+    diagonal W and the statistic block is reduced to [sum r x, n_d, n_d, sum r x^2] (K, D) on the way in.
+    The posterior keeps the reference's observable update rule by default — see StackedNormalGammas."""
+
+    def __init__(self, size, dim, prior, likelihood=None, engine=None):
+        self.size = size
+        self.dim = dim
+        self.prior = prior
+        self.posterior = copy.deepcopy(prior)
+        if likelihood is None:
+            mus, lmbdas_diags = prior.rvs()
+            likelihood = self._likelihood_class(size=size, dim=dim, mus=mus, lmbdas_diags=lmbdas_diags,
+                                                engine=engine)
+        self.likelihood = likelihood
+
+    _likelihood_class = StackedGaussiansWithDiagonalPrecision
+
+    def posterior_predictive_gaussian(self):
+        """bayesian.py:457-461: N(m_k, diag((alpha/beta) / (1 + 1/kappa))^-1)."""
+        mus, kappas, alphas, betas = self.posterior.params
+        return mus, (alphas / betas) / (1. + 1. / kappas)
+
+    def predictive_canonical(self):
+        mus, lmbda_diags = self.posterior_predictive_gaussian()
+        b = lmbda_diags * mus
+        c = - 0.5 * np.sum(mus * b, axis=1) - 0.5 * self.dim * np.log(2. * np.pi)\
+            + 0.5 * np.sum(np.log(lmbda_diags), axis=1)
+        return c, b, np.eye(self.dim) * lmbda_diags[:, None, :]
+
+    def posterior_predictive_studentt(self):
+        mus, lmbda_diags = self.posterior_predictive_gaussian()
+        return mus, lmbda_diags, 2. * self.posterior.alphas
+
+
+class TiedGaussiansWithNormalGammas(StackedGaussiansWithNormalGammas):
+    """One diagonal precision shared by all K under a TiedNormalGammas prior / posterior (bayesian.py:484-500)."""
+
+    _likelihood_class = TiedGaussiansWithDiagonalPrecision
 
 
 class StackedLinearGaussiansWithMatrixNormalWisharts(_ConjugateBlock):

@@ -12,6 +12,7 @@ These classes produce the per-component parameter block the kernels consume (exp
 import numpy as np
 import numpy.random as npr
 import scipy.linalg as sla
+from scipy.special import gammaln, digamma
 
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs,
@@ -411,3 +412,138 @@ class TiedMatrixNormalWisharts(_TiedNatParam, StackedMatrixNormalWisharts):
         psi = np.linalg.inv(np.mean(c - Ms @ b @ np.swapaxes(Ms, 1, 2), axis=0))
         nu = np.mean(d + self.row_dim + 1. - self.column_dim)
         return Ms, b, np.array(self.size * [psi]), np.array(self.size * [nu])
+
+
+# ---------------------------------------------------------------------------------------------
+# Diagonal-precision blocks: Normal-Gamma priors / posteriors
+# ---------------------------------------------------------------------------------------------
+class StackedNormalGammas:
+    """K independent Normal-Gamma distributions over (mu_k, diag Lambda_k), every array (K, D):
+    lambda_kd ~ Gamma(alpha_kd, beta_kd), mu_kd | lambda_kd ~ N(m_kd, (kappa_kd lambda_kd)^-1)
+    (mimo/distributions/composite.py:286-404 per block, :407-519 stacked).
+
+    `reference_setters` (default True) keeps the reference's observable update rule: its stacked
+    setters for `alphas` / `betas` write attributes nothing reads (composite.py:472-484), so assigning
+    natural or standard parameters moves (mus, kappas) only and the Gamma factors stay where the
+    constructor put them — the posterior of every stacked diagonal model keeps the PRIOR's (alpha, beta)
+    for the whole run.  Parity is against that behaviour; `reference_setters=False` applies the
+    conjugate update to all four parameters."""
+
+    def __init__(self, size, dim, mus=None, kappas=None, alphas=None, betas=None, reference_setters=True):
+        self.size = size
+        self.dim = dim
+        self.reference_setters = reference_setters
+        f = lambda v: None if v is None else np.array(v, dtype=float)
+        self.mus, self.kappas, self.alphas, self.betas = f(mus), f(kappas), f(alphas), f(betas)
+
+    @property
+    def params(self):
+        return self.mus, self.kappas, self.alphas, self.betas
+
+    @params.setter
+    def params(self, values):
+        mus, kappas, alphas, betas = (np.asarray(v, dtype=float) for v in values)
+        self.mus, self.kappas = mus, kappas
+        if not self.reference_setters:
+            self.alphas, self.betas = alphas, betas
+
+    @property
+    def nat_param(self):
+        return self.std_to_nat(self.params)
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        self.params = self.nat_to_std(natparam)
+
+    def std_to_nat(self, params):
+        """eta = [kappa m, kappa, 2 alpha - 1, 2 beta + kappa m^2]  (composite.py:314-329)."""
+        mus, kappas, alphas, betas = params
+        return Stats([kappas * mus, kappas, 2. * alphas - 1., 2. * betas + kappas * mus**2])
+
+    def nat_to_std(self, natparam):
+        """composite.py:331-337."""
+        a, b, c, d = natparam
+        mus = a / b
+        return mus, b, 0.5 * (c + 1.), 0.5 * (d - b * mus**2)
+
+    def mean(self):
+        return self.mus, self.alphas / self.betas
+
+    def mode(self):
+        """composite.py:342-345: lambda = (alpha - 1/2) / beta."""
+        return self.mus, (self.alphas - 0.5) / self.betas
+
+    def rvs(self, rng=None):
+        """Per block in the reference's RNG order (composite.py:347-351, gamma.py:53-55,
+        gaussian.py:646-648): D gamma draws, then mu = m + normal(D) / sqrt(kappa lambda).
+        With `rng` (a numpy Generator) all K blocks are drawn at once (same law, different stream)."""
+        if rng is not None:
+            lmbdas = rng.gamma(self.alphas, 1. / self.betas)
+            return self.mus + rng.standard_normal(self.mus.shape) / np.sqrt(self.kappas * lmbdas), lmbdas
+        mus, lmbdas = [], []
+        for k in range(self.size):
+            lmbda = npr.gamma(self.alphas[k], 1. / self.betas[k])
+            chol_inv = np.diag(1. / np.sqrt(self.kappas[k] * lmbda))
+            mus.append(self.mus[k] + npr.normal(size=self.dim).dot(chol_inv.T))
+            lmbdas.append(lmbda)
+        return np.stack(mus, axis=0), np.stack(lmbdas, axis=0)
+
+    @property
+    def base(self):
+        return np.power(2. * np.pi, - self.dim / 2.) * np.ones(self.size)
+
+    def log_base(self):
+        return np.log(self.base)
+
+    def log_partition(self):
+        """composite.py:360-363, gamma.py:91-92."""
+        return - 0.5 * np.sum(np.log(self.kappas), axis=1)\
+            + np.sum(gammaln(self.alphas) - self.alphas * np.log(self.betas), axis=1)
+
+    def expected_statistics(self):
+        """E[lambda mu], E[-1/2 lambda mu^2], E[1/2 log lambda], E[-1/2 lambda] (composite.py:371-382)."""
+        E_lmbdas = self.alphas / self.betas
+        E_lmbdas_mu = E_lmbdas * self.mus
+        return (E_lmbdas_mu, - 0.5 * (1. / self.kappas + self.mus * E_lmbdas_mu),
+                0.5 * (digamma(self.alphas) - np.log(self.betas)), - 0.5 * E_lmbdas)
+
+    def canonical_expected(self):
+        """(c, b, W) of <E_q[eta_k], t(x)> + log_base with the (K, N, D) statistics [x, 1, 1, x^2] of
+        gaussian.py:784-800 (bayesian.py:441-455): a diagonal W."""
+        E1, E2, E3, E4 = self.expected_statistics()
+        W = np.zeros((self.size, self.dim, self.dim))
+        idx = np.arange(self.dim)
+        W[:, idx, idx] = - 2. * E4
+        return self.log_base() + np.sum(E2 + E3, axis=1), E1, W
+
+    @staticmethod
+    def _inner(nat, stats):
+        return sum(np.einsum('kd,kd->k', n, s) for n, s in zip(nat, stats))
+
+    def entropy(self):
+        return self.log_partition() - self.log_base() - self._inner(self.nat_param, self.expected_statistics())
+
+    def cross_entropy(self, other):
+        return other.log_partition() - other.log_base() - self._inner(other.nat_param, self.expected_statistics())
+
+    def log_likelihood(self, x):
+        """sum_k log NG(mu_k, lambda_k) (composite.py:365-369, :507-509); x = (mus, lmbdas_diags)."""
+        mus, lmbdas = x
+        kl = self.kappas * lmbdas
+        gauss = - 0.5 * np.sum(kl * (mus - self.mus)**2, axis=1) + 0.5 * np.sum(np.log(kl), axis=1)\
+            - 0.5 * self.dim * np.log(2. * np.pi)
+        gam = np.sum((self.alphas - 1.) * np.log(lmbdas) - self.betas * lmbdas, axis=1)\
+            - np.sum(gammaln(self.alphas) - self.alphas * np.log(self.betas), axis=1)
+        return np.sum(gauss + gam)
+
+
+class TiedNormalGammas(StackedNormalGammas):
+    """K Normal-Gammas whose Gamma factor is shared: alpha, beta = mean over k (composite.py:522-547).
+    With `reference_setters` the pooled values are, like the stacked ones, never stored."""
+
+    def nat_to_std(self, natparam):
+        a, b, c, d = natparam
+        mus = a / b
+        alphas = np.mean(0.5 * (c + 1.), axis=0)
+        betas = np.mean(0.5 * (d - b * mus**2), axis=0)
+        return mus, b, np.array(self.size * [alphas]), np.array(self.size * [betas])

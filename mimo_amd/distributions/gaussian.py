@@ -28,6 +28,13 @@ def upper_chol(mats):
 
 class StackedGaussiansWithPrecision:
 
+    diagonal = False
+
+    @staticmethod
+    def block_stats(S):
+        """engine block -> Stats([sum r x, n, sum r xx', n]) (gaussian.py:502)."""
+        return Stats([S.sx, S.n, S.sxx, S.n])
+
     def __init__(self, size, dim, mus=None, lmbdas=None, engine=None):
         self.size = size
         self.dim = dim
@@ -141,8 +148,7 @@ class StackedGaussiansWithPrecision:
                 out = out + s
             return out
         eng = self._bind(data)
-        S = eng.weighted_stats(np.asarray(weights, dtype=float))
-        return Stats([S.sx, S.n, S.sxx, S.n])
+        return self.block_stats(eng.weighted_stats(np.asarray(weights, dtype=float)))
 
     def statistics(self, data, fold=True):
         """gaussian.py:466-489.  fold=True: the data totals replicated for every component.
@@ -178,3 +184,103 @@ class TiedGaussiansWithPrecision(StackedGaussiansWithPrecision):
         sigma = symmetrize(sigma) + 1e-16 * np.eye(self.dim)
         assert np.all(np.linalg.eigvalsh(sigma) > 0.)
         self.mus, self.lmbdas = mus, np.array(self.size * [np.linalg.inv(sigma)])
+
+
+class StackedGaussiansWithDiagonalPrecision(StackedGaussiansWithPrecision):
+    """K Gaussians with diagonal precisions, parameters (mus (K,D), lmbdas_diags (K,D))
+    (mimo/distributions/gaussian.py:697-852).  The engine sees the same canonical form with
+    W_k = diag(lambda_k); the statistic block it returns is reduced to its diagonal here."""
+
+    diagonal = True
+
+    def __init__(self, size, dim, mus=None, lmbdas_diags=None, engine=None):
+        self.size = size
+        self.dim = dim
+        self.mus = None if mus is None else np.array(mus, dtype=float)
+        self.lmbdas_diags = None if lmbdas_diags is None else np.array(lmbdas_diags, dtype=float)
+        self._engine = engine
+
+    @property
+    def params(self):
+        return self.mus, self.lmbdas_diags
+
+    @params.setter
+    def params(self, values):
+        self.mus, self.lmbdas_diags = (np.asarray(v, dtype=float) for v in values)
+
+    def std_to_nat(self, params):
+        mus, lmbdas_diags = params
+        return Stats([lmbdas_diags * mus, - 0.5 * lmbdas_diags])
+
+    def nat_to_std(self, natparam):
+        return - 0.5 * natparam[0] / natparam[1], - 2. * natparam[1]
+
+    @property
+    def lmbdas(self):
+        return np.eye(self.dim) * self.lmbdas_diags[:, None, :]
+
+    @property
+    def lmbdas_chol(self):
+        return np.eye(self.dim) * np.sqrt(self.lmbdas_diags)[:, None, :]
+
+    @property
+    def lmbdas_chol_inv(self):
+        return np.eye(self.dim) / np.sqrt(self.lmbdas_diags)[:, None, :]
+
+    @property
+    def sigmas_diags(self):
+        return 1. / self.lmbdas_diags
+
+    @property
+    def sigmas(self):
+        return np.eye(self.dim) * self.sigmas_diags[:, None, :]
+
+    def log_partition(self):
+        """gaussian.py:678-680 per component."""
+        return 0.5 * np.sum(self.lmbdas_diags * self.mus**2, axis=1) - 0.5 * np.sum(np.log(self.lmbdas_diags), axis=1)
+
+    def canonical(self):
+        return - self.log_partition() + self.log_base(), self.lmbdas_diags * self.mus, self.lmbdas
+
+    @staticmethod
+    def block_stats(S):
+        """engine block -> Stats([sum r x, n_d, n_d, sum r x^2]) with (K, D) entries (gaussian.py:802-815)."""
+        nd = np.repeat(S.n[:, None], S.sx.shape[1], axis=1)
+        return Stats([S.sx, nd, nd, np.diagonal(S.sxx, axis1=1, axis2=2).copy()])
+
+    def weighted_statistics(self, data, weights):
+        if not isinstance(data, np.ndarray):
+            stats = list(map(self.weighted_statistics, data, weights))
+            out = stats[0]
+            for s in stats[1:]:
+                out = out + s
+            return out
+        eng = self._bind(data)
+        return self.block_stats(eng.weighted_stats(np.asarray(weights, dtype=float)))
+
+    def statistics(self, data, fold=True):
+        """gaussian.py:777-800, fold=True (see StackedGaussiansWithPrecision.statistics for fold=False)."""
+        if not fold:
+            raise NotImplementedError("statistics(fold=False) materialises (K,N,D); use "
+                                      "expected_log_likelihood / the fused E-step instead")
+        eng = self._bind(data)
+        x, nd, _, xx = self.block_stats(eng.weighted_stats(np.ones((1, eng.N))))
+        rep = lambda a: np.repeat(a, self.size, axis=0)
+        return Stats([rep(x), rep(nd), rep(nd), rep(xx)])
+
+    def max_likelihood(self, data, weights=None, stats=None):
+        """gaussian.py:841-852."""
+        xk, ndk, _, xxk = stats if stats is not None else self.weighted_statistics(data, weights)
+        mus = xk / ndk
+        self.mus, self.lmbdas_diags = mus, 1. / (xxk / ndk - mus**2 + 1e-16)
+
+
+class TiedGaussiansWithDiagonalPrecision(StackedGaussiansWithDiagonalPrecision):
+    """One diagonal precision shared by all K (gaussian.py:855-878): pooled variance in the M-step."""
+
+    def max_likelihood(self, data, weights=None, stats=None):
+        xk, ndk, _, xxk = stats if stats is not None else self.weighted_statistics(data, weights)
+        mus = xk / ndk
+        sigma_diag = (np.sum(xxk, axis=0) - np.sum(ndk * mus**2, axis=0)) / np.sum(ndk, axis=0)
+        self.mus = mus
+        self.lmbdas_diags = np.array(self.size * [1. / (sigma_diag + 1e-16)])

@@ -24,8 +24,12 @@ from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
 
 
-def _component_stats(S):
-    """engine block -> Stats([sum r x, n, sum r xx', n]) (gaussian.py:502)."""
+def _component_stats(S, components=None):
+    """engine block -> the Stats tuple of the component family: Stats([sum r x, n, sum r xx', n])
+    (gaussian.py:502) or, for diagonal precisions, Stats([sum r x, n_d, n_d, sum r x^2]) (gaussian.py:815)."""
+    lik = getattr(components, 'likelihood', components)
+    if lik is not None and hasattr(lik, 'block_stats'):
+        return lik.block_stats(S)
     return Stats([S.sx, S.n, S.sxx, S.n])
 
 
@@ -113,7 +117,7 @@ class MixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'EM #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
-                self.components.max_likelihood(None, stats=_component_stats(S))
+                self.components.max_likelihood(None, stats=_component_stats(S, self.components))
                 self.gating.max_likelihood(None, S.n)
                 S, sc = eng.estep(*self.canonical())
                 log_lik.append(sc[0])
@@ -133,7 +137,7 @@ class MixtureOfGaussians:
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
                 S = eng.weighted_stats(resp * weights)
-                self.components.max_likelihood(None, stats=_component_stats(S))
+                self.components.max_likelihood(None, stats=_component_stats(S, self.components))
                 self.gating.max_likelihood(None, S.n)
                 _, sc = eng.estep(*self.canonical(), stats=False, keep_resp=True)
                 resp = eng.get_resp(self.size)
@@ -193,7 +197,7 @@ class BayesianMixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'MAP #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
-                self.components.max_aposteriori(None, stats=_component_stats(S))
+                self.components.max_aposteriori(None, stats=_component_stats(S, self.components))
                 self.gating.max_aposteriori(None, S.n)
                 S, sc = eng.estep(*self.likelihood.canonical())
                 log_prior = self.gating.prior.log_likelihood(self.gating.likelihood.params)\
@@ -230,7 +234,7 @@ class BayesianMixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'Init #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for it in range(maxiter):
-                self.components.resample(None, stats=_component_stats(S), rng=param_rng)
+                self.components.resample(None, stats=_component_stats(S, self.components), rng=param_rng)
                 self.gating.resample(None, counts=S.n)
                 last = it == maxiter - 1
                 labels, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last,
@@ -262,7 +266,7 @@ class BayesianMixtureOfGaussians:
     def resample_components(self, obs, labels):
         """gmm.py:235-237 without the dense one_hot table."""
         eng = self._bind(obs)
-        self.components.resample(None, stats=_component_stats(eng.label_stats(labels, self.size)))
+        self.components.resample(None, stats=_component_stats(eng.label_stats(labels, self.size), self.components))
 
     # ---- mean field ----------------------------------------------------------------------------
     def expected_log_complete_likelihood(self, obs):
@@ -310,7 +314,7 @@ class BayesianMixtureOfGaussians:
         return vlb
 
     def _update_from_stats(self, S, sample=True):
-        self.components.meanfield_update(None, stats=_component_stats(S), sample=sample)
+        self.components.meanfield_update(None, stats=_component_stats(S, self.components), sample=sample)
         self.gating.meanfield_update(None, S.n, sample=sample)
 
     def _vlb_prior_terms(self):
@@ -325,7 +329,7 @@ class BayesianMixtureOfGaussians:
 
     def meanfield_update_components(self, obs, resp):
         eng = self._bind(obs)
-        self.components.meanfield_update(None, stats=_component_stats(eng.weighted_stats(resp)))
+        self.components.meanfield_update(None, stats=_component_stats(eng.weighted_stats(resp), self.components))
 
     # ---- SVI -----------------------------------------------------------------------------------
     def meanfield_stochastic_descent(self, obs, randomize=True, maxiter=500, step_size=1e-2, batch_size=128,
@@ -350,7 +354,7 @@ class BayesianMixtureOfGaussians:
                         Sb = beng.weighted_stats(resp)
                     else:
                         Sb, _ = beng.estep(*self.canonical_expected())
-                    self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb),
+                    self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb, self.components),
                                                   sample=sample_likelihood)
                     self.gating.meanfield_sgd(None, Sb.n, scale, step_size, sample=sample_likelihood)
                 _, sc = eng.estep(*self.canonical_expected(), stats=False)
@@ -361,7 +365,7 @@ class BayesianMixtureOfGaussians:
     def meanfield_sgd_parameters(self, obs, resp, scale, step_size):
         eng = _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
         S = eng.weighted_stats(resp)
-        self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(S))
+        self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(S, self.components))
         self.gating.meanfield_sgd(None, S.n, scale, step_size)
 
     # ---- ELBO with explicit responsibilities (reference-shaped) ----------------------------------

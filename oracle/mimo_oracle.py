@@ -215,6 +215,95 @@ def gauss_statistics_unfolded(data, K):
 
 
 # ==========================================================================================
+# diagonal-precision Gaussians / Normal-Gamma blocks — mimo/distributions/gaussian.py:697-878,
+# composite.py:286-547, bayesian.py:343-500
+# ==========================================================================================
+def diag_gauss_log_likelihood(x, mus, lmbdas_diags):
+    """StackedGaussiansWithDiagonalPrecision.log_likelihood (gaussian.py:817-832) with
+    log_partition (gaussian.py:678-680) and log_base (gaussian.py:69-74) per component."""
+    K, D = mus.shape
+    lmbdas = np.array([np.diag(l) for l in lmbdas_diags])
+    log_lik = np.einsum('kd,kdl,nl->kn', mus, lmbdas, x, optimize=True)\
+        - 0.5 * np.einsum('nd,kdl,nl->kn', x, lmbdas, x, optimize=True)
+    log_partition = np.array([0.5 * np.einsum('d,dl,l->', mus[k], lmbdas[k], mus[k])
+                              - np.sum(np.log(np.sqrt(lmbdas_diags[k]))) for k in range(K)])
+    return log_lik - log_partition[:, None] - 0.5 * D * LOG2PI
+
+
+def diag_gauss_weighted_statistics(data, weights):
+    """gaussian.py:802-815 -> (xk (K,D), ndk (K,D), ndk, xxk (K,D))."""
+    K, D = weights.shape[0], data.shape[1]
+    xk = np.einsum('kn,nd->kd', weights, data)
+    xxk = np.einsum('nd,kn,nd->kd', data, weights, data)
+    ndk = np.broadcast_to(np.sum(weights, axis=1, keepdims=True), (K, D))
+    return xk, ndk, ndk, xxk
+
+
+def ng_std_to_nat(mus, kappas, alphas, betas):
+    """composite.py:314-329."""
+    return kappas * mus, kappas, 2. * alphas - 1., 2. * betas + kappas * mus**2
+
+
+def ng_nat_to_std(a, b, c, d):
+    """composite.py:331-337."""
+    mus = a / b
+    return mus, b, 0.5 * (c + 1.), 0.5 * (d - b * mus**2)
+
+
+def tied_ng_nat_to_std(a, b, c, d):
+    """composite.py:536-547: Gamma factor pooled (mean over k)."""
+    K = a.shape[0]
+    mus = a / b
+    alphas = np.mean(0.5 * (c + 1.), axis=0)
+    betas = np.mean(0.5 * (d - b * mus**2), axis=0)
+    return mus, b, np.array(K * [alphas]), np.array(K * [betas])
+
+
+def ng_expected_statistics(mus, kappas, alphas, betas):
+    """composite.py:371-382."""
+    E_lmbdas_mu = alphas / betas * mus
+    return (E_lmbdas_mu, - 0.5 * (1. / kappas + mus * E_lmbdas_mu),
+            0.5 * (digamma(alphas) - np.log(betas)), - 0.5 * (alphas / betas))
+
+
+def ng_log_partition(mus, kappas, alphas, betas):
+    """composite.py:360-363 + gamma.py:91-92, per block."""
+    return - 0.5 * np.sum(np.log(kappas), axis=1) + np.sum(gammaln(alphas) - alphas * np.log(betas), axis=1)
+
+
+def ng_vlb(post, prior):
+    """entropy - cross_entropy (bayesian.py:401-404, composite.py:384-404), per block."""
+    D = post[0].shape[1]
+    E = ng_expected_statistics(*post)
+    inner = lambda nat: sum(np.einsum('kd,kd->k', n, e) for n, e in zip(nat, E))
+    log_base = - 0.5 * D * LOG2PI
+    ent = ng_log_partition(*post) - log_base - inner(ng_std_to_nat(*post))
+    cross = ng_log_partition(*prior) - log_base - inner(ng_std_to_nat(*prior))
+    return ent - cross
+
+
+def stacked_ng_update(prior, stats, post_gamma, tied=False):
+    """posterior.nat_param = prior.nat_param + stats as the reference OBSERVABLY performs it
+    (bayesian.py:385-392): nat_to_std yields four arrays, but the stacked setters of alphas / betas store
+    them in attributes nothing reads (composite.py:472-484), so (alphas, betas) stay `post_gamma`."""
+    nat = [p + s for p, s in zip(ng_std_to_nat(*prior), stats)]
+    mus, kappas, _, _ = (tied_ng_nat_to_std if tied else ng_nat_to_std)(*nat)
+    return mus, kappas, post_gamma[0], post_gamma[1]
+
+
+def diag_gauss_ng_expected_log_likelihood(x, post):
+    """StackedGaussiansWithNormalGammas.expected_log_likelihood (bayesian.py:441-455) with the unfolded
+    statistics [x, 1, 1, x^2] of gaussian.py:784-800."""
+    K, D = post[0].shape
+    E = ng_expected_statistics(*post)
+    xk = np.array([x for _ in range(K)])
+    xxk = np.array([x * x for _ in range(K)])
+    ndk = np.ones((K, x.shape[0], D))
+    return - 0.5 * D * LOG2PI + np.einsum('kd,knd->kn', E[0], xk) + np.einsum('kd,knd->kn', E[1], ndk)\
+        + np.einsum('kd,knd->kn', E[2], ndk) + np.einsum('kd,knd->kn', E[3], xxk)
+
+
+# ==========================================================================================
 # Wishart / Normal-Wishart — mimo/distributions/wishart.py, composite.py:19-256
 # ==========================================================================================
 def wishart_log_partition(psi, nu):

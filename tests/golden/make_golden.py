@@ -462,7 +462,70 @@ def tied_ilr_prediction_case(name, N, K, seed, gibbs_iters=4, svi_iters=5, vi_it
     print(name, "ok")
 
 
+def ng_params(p):
+    return dict(mus=p.mus, kappas=p.kappas, alphas=p.alphas, betas=p.betas)
+
+
+def diag_gmm_case(name, N, D, K, seed, tied, iters=6):
+    """Diagonal-precision GMM under (Tied)NormalGammas (composite.py:286-547, bayesian.py:343-500,
+    gaussian.py:697-878; examples/dgmm, examples/tdgmm): seeded Gibbs sweeps, VI / SVI / MAP / EM traces and the
+    E-step tables.  The reference's stacked alpha / beta setters write unused attributes (composite.py:472-484),
+    so what is pinned here is its OBSERVABLE behaviour: the posterior keeps the prior's Gamma factors."""
+    from mimo.distributions import (StackedNormalGammas, TiedNormalGammas, StackedGaussiansWithNormalGammas,
+                                    TiedGaussiansWithNormalGammas, StackedGaussiansWithDiagonalPrecision,
+                                    TiedGaussiansWithDiagonalPrecision, Categorical)
+    from mimo.mixtures import MixtureOfGaussians
+    Prior = TiedNormalGammas if tied else StackedNormalGammas
+    Comp = TiedGaussiansWithNormalGammas if tied else StackedGaussiansWithNormalGammas
+    Lik = TiedGaussiansWithDiagonalPrecision if tied else StackedGaussiansWithDiagonalPrecision
+    npr.seed(seed)
+    X = make_data(N, D)
+    out = dict(X=X, K=np.array(K), D=np.array(D), seed=np.array(seed), iters=np.array(iters), tied=np.array(tied),
+               gating_kind=np.array('dirichlet'))
+    gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=2. * np.ones((K,))))   # MAP needs alpha > 1
+    prior = Prior(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K, D)),
+                  alphas=(D + 1. + 1e-8) / 2. * np.ones((K, D)), betas=0.5 * np.ones((K, D)))
+    npr.seed(seed + 1)
+    comps = Comp(size=K, dim=D, prior=prior)
+    m = BayesianMixtureOfGaussians(gating=gating, components=comps)
+    put(out, "prior", ng_params(prior)); put(out, "gprior", gating_params(gating.prior, 'dirichlet'))
+    out["init_mus"], out["init_lmbdas_diags"] = comps.likelihood.mus, comps.likelihood.lmbdas_diags
+    out["loglik_table"] = comps.likelihood.log_likelihood(X.copy())
+    npr.seed(seed + 2)
+    m.resample(X.copy(), init_labels='random', maxiter=3, progress_bar=False)
+    out["gibbs_mus"], out["gibbs_lmbdas_diags"] = m.components.likelihood.mus, m.components.likelihood.lmbdas_diags
+    out["gibbs_probs"] = m.gating.likelihood.probs
+    put(out, "gibbs_post", ng_params(m.components.posterior))
+    npr.seed(seed + 3)
+    vlb = m.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=iters, tol=0., progress_bar=False)
+    out["vi_vlb"] = np.array(vlb)
+    put(out, "vi_post", ng_params(m.components.posterior))
+    out["vi_ell_table"] = m.components.expected_log_likelihood(X.copy())
+    out["vi_resp"] = m.expected_responsibilities(X.copy())
+    out["vi_nat"] = np.stack(m.components.posterior.nat_param)
+    st = m.components.likelihood.weighted_statistics(X.copy(), out["vi_resp"])
+    out["vi_stats_x"], out["vi_stats_nd"], out["vi_stats_xx"] = st[0], st[1], st[3]
+    import random
+    npr.seed(seed + 4); random.seed(seed + 14)
+    out["svi_vlb"] = np.array(m.meanfield_stochastic_descent(X.copy(), randomize=False, maxiter=iters, step_size=5e-1,
+                                                             batch_size=64, progress_bar=False))
+    put(out, "svi_post", ng_params(m.components.posterior))
+    npr.seed(seed + 5)
+    out["map_logprob"] = np.array(m.max_aposteriori(X.copy(), randomize=True, maxiter=iters, progress_bar=False))
+    out["map_mus"], out["map_lmbdas_diags"] = m.components.likelihood.mus, m.components.likelihood.lmbdas_diags
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=Lik(size=K, dim=D))
+    npr.seed(seed + 6)
+    out["em_loglik"] = np.array(lik.max_likelihood(X.copy(), randomize=True, maxiter=iters, progress_bar=False))
+    out["em_mus"], out["em_lmbdas_diags"] = lik.components.mus, lik.components.lmbdas_diags
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "diag":
+        diag_gmm_case("diag_gmm_d3_k5", N=500, D=3, K=5, seed=1352, tied=False)
+        diag_gmm_case("tied_diag_gmm_d4_k6", N=400, D=4, K=6, seed=1353, tied=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tied":
         tied_gmm_case("tied_gmm_d3_k5", N=500, D=3, K=5, seed=1349)
         tied_ilr_prediction_case("tied_ilr_sine_k8", N=400, K=8, seed=1350)
@@ -488,3 +551,5 @@ if __name__ == "__main__":
     tied_gmm_case("tied_gmm_d3_k5", N=500, D=3, K=5, seed=1349)
     tied_ilr_prediction_case("tied_ilr_sine_k8", N=400, K=8, seed=1350)
     tied_ilr_prediction_case("tied_ilr_dx3_dy2_k6", N=300, K=6, seed=1351, dx=3, dy=2)
+    diag_gmm_case("diag_gmm_d3_k5", N=500, D=3, K=5, seed=1352, tied=False)
+    diag_gmm_case("tied_diag_gmm_d4_k6", N=400, D=4, K=6, seed=1353, tied=True)

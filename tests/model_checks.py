@@ -10,7 +10,10 @@ from mimo_amd.distributions import (Dirichlet, TruncatedStickBreaking, Categoric
                                     StackedGaussiansWithNormalWisharts, StackedMatrixNormalWisharts,
                                     StackedLinearGaussiansWithMatrixNormalWisharts, TiedNormalWisharts,
                                     TiedGaussiansWithNormalWisharts, TiedGaussiansWithPrecision,
-                                    TiedMatrixNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts)
+                                    TiedMatrixNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts,
+                                    StackedNormalGammas, TiedNormalGammas, StackedGaussiansWithNormalGammas,
+                                    TiedGaussiansWithNormalGammas, StackedGaussiansWithDiagonalPrecision,
+                                    TiedGaussiansWithDiagonalPrecision)
 from mimo_amd.mixtures import BayesianMixtureOfGaussians, BayesianMixtureOfLinearGaussians
 
 
@@ -292,6 +295,67 @@ def check_tied_gmm(name, engine, tol=1e-8):
     ll = lik.max_likelihood(X, randomize=True, maxiter=iters, progress_bar=False)
     assert rel_err(np.array(ll), g["em_loglik"]) < tol
     assert rel_err(lik.components.mus, g["em_mus"]) < 1e-6 and rel_err(lik.components.lmbdas, g["em_lmbdas"]) < 1e-6
+
+
+def check_diag_gmm(name, engine, tol=1e-8):
+    """Diagonal-precision GMM under (Tied)NormalGammas (examples/dgmm, examples/tdgmm):
+    tables, seeded Gibbs sweeps, VI / SVI / MAP / EM traces against the reference's observable behaviour."""
+    from mimo_amd.distributions import Categorical
+    from mimo_amd.mixtures import MixtureOfGaussians
+    g = load_golden(name)
+    X, K, D, seed, iters, tied = g["X"], int(g["K"]), int(g["D"]), int(g["seed"]), int(g["iters"]), bool(g["tied"])
+    Prior = TiedNormalGammas if tied else StackedNormalGammas
+    Comp = TiedGaussiansWithNormalGammas if tied else StackedGaussiansWithNormalGammas
+    Lik = TiedGaussiansWithDiagonalPrecision if tied else StackedGaussiansWithDiagonalPrecision
+    ng = lambda pre: tuple(g[f"{pre}_{k}"] for k in ("mus", "kappas", "alphas", "betas"))
+    kind, gating = make_gating(g, K)
+    prior = Prior(size=K, dim=D, **{k: g["prior_" + k] for k in ("mus", "kappas", "alphas", "betas")})
+    npr.seed(seed + 1)
+    comps = Comp(size=K, dim=D, prior=prior, engine=engine)
+    m = BayesianMixtureOfGaussians(gating=gating, components=comps, engine=engine)
+    assert rel_err(comps.likelihood.mus, g["init_mus"]) < 1e-12
+    assert rel_err(comps.likelihood.lmbdas_diags, g["init_lmbdas_diags"]) < 1e-12
+    assert rel_err(comps.likelihood.log_likelihood(X), g["loglik_table"]) < tol
+    npr.seed(seed + 2)
+    m.resample(X, init_labels='random', maxiter=3, progress_bar=False, label_rng='host')
+    assert rel_err(m.components.likelihood.mus, g["gibbs_mus"]) < tol
+    assert rel_err(m.components.likelihood.lmbdas_diags, g["gibbs_lmbdas_diags"]) < tol
+    assert rel_err(m.gating.likelihood.probs, g["gibbs_probs"]) < tol
+    for a, b in zip(m.components.posterior.params, ng("gibbs_post")):
+        assert rel_err(a, b) < tol
+    npr.seed(seed + 3)
+    vlb = m.meanfield_coordinate_descent(X, randomize=False, maxiter=iters, tol=0., progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    for a, b in zip(m.components.posterior.params, ng("vi_post")):
+        assert rel_err(a, b) < 1e-6
+    assert rel_err(m.components.expected_log_likelihood(X), g["vi_ell_table"]) < 1e-6
+    assert rel_err(m.expected_responsibilities(X), g["vi_resp"]) < 1e-6
+    st = m.components.likelihood.weighted_statistics(X, g["vi_resp"])
+    assert rel_err(st[0], g["vi_stats_x"]) < tol and rel_err(st[1], g["vi_stats_nd"]) < tol
+    assert rel_err(st[3], g["vi_stats_xx"]) < tol and st[1].shape == (K, D)
+    import random
+    npr.seed(seed + 4)
+    random.seed(seed + 14)
+    vlb = m.meanfield_stochastic_descent(X, randomize=False, maxiter=iters, step_size=5e-1, batch_size=64,
+                                         progress_bar=False)
+    assert rel_err(np.array(vlb), g["svi_vlb"]) < tol
+    for a, b in zip(m.components.posterior.params, ng("svi_post")):
+        assert rel_err(a, b) < 1e-6
+    npr.seed(seed + 5)
+    lp = m.max_aposteriori(X, randomize=True, maxiter=iters, progress_bar=False)
+    assert rel_err(np.array(lp), g["map_logprob"]) < tol
+    assert rel_err(m.components.likelihood.mus, g["map_mus"]) < 1e-6
+    assert rel_err(m.components.likelihood.lmbdas_diags, g["map_lmbdas_diags"]) < 1e-6
+    lik = MixtureOfGaussians(gating=Categorical(dim=K), components=Lik(K, D, engine=engine), engine=engine)
+    npr.seed(seed + 6)
+    ll = lik.max_likelihood(X, randomize=True, maxiter=iters, progress_bar=False)
+    assert rel_err(np.array(ll), g["em_loglik"]) < tol
+    assert rel_err(lik.components.mus, g["em_mus"]) < 1e-6
+    assert rel_err(lik.components.lmbdas_diags, g["em_lmbdas_diags"]) < 1e-6
+    # the conjugate update with the setter defect switched off moves the Gamma factors too
+    fixed = Prior(size=K, dim=D, reference_setters=False, **{k: g["prior_" + k] for k in ("mus", "kappas", "alphas", "betas")})
+    fixed.nat_param = prior.nat_param + st
+    assert np.all(fixed.alphas >= prior.alphas) and np.any(fixed.alphas > prior.alphas + 1.) and np.all(fixed.betas > 0.)
 
 
 def check_tied_ilr_prediction(name, engine, tol=1e-7):

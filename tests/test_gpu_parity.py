@@ -49,6 +49,11 @@ def test_tied_gmm_gibbs_vi_em(engine):
     mc.check_tied_gmm("tied_gmm_d3_k5", engine)
 
 
+@pytest.mark.parametrize("name", ["diag_gmm_d3_k5", "tied_diag_gmm_d4_k6"])
+def test_diag_gmm_all_drivers(engine, name):
+    mc.check_diag_gmm(name, engine)
+
+
 @pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
 def test_tied_ilr_flow_and_prediction(name, engine):
     mc.check_tied_ilr_prediction(name, engine)

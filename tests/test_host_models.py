@@ -44,6 +44,11 @@ def test_tied_gmm_gibbs_vi_em():
     mc.check_tied_gmm("tied_gmm_d3_k5", OracleEngine())
 
 
+@pytest.mark.parametrize("name", ["diag_gmm_d3_k5", "tied_diag_gmm_d4_k6"])
+def test_diag_gmm_all_drivers(name):
+    mc.check_diag_gmm(name, OracleEngine())
+
+
 @pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
 def test_tied_ilr_flow_and_prediction(name):
     mc.check_tied_ilr_prediction(name, OracleEngine())

