@@ -167,6 +167,10 @@ __device__ __forceinline__ void build_features_static(const double (&z)[D + 2], 
 // what-if builds at C3: the 32-link max / running-sum / compare chains were 45 % of the normalise phase).
 // All reductions below are trees, the cumulative sum is a Kogge-Stone scan.
 // ------------------------------------------------------------------------------------------
+// (mimo_kernels.hip is compiled with -fno-honor-nans: without it LLVM puts a canonicalising self-max in front
+// of every fmax whose operands may be signalling NaNs — anything that came out of memory or a lane exchange —
+// which doubled the f64 instructions of the max tree: 21 -> 10 v_max_f64 per lane at K = 64.  No kernel here
+// computes with NaNs: the host rejects NaN input.)
 __device__ __forceinline__ double tree_max8(const double (&v)[8]) {
   return fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
 }
@@ -1258,8 +1262,11 @@ __global__ void unpack_stats(const double* __restrict__ red, const uint8_t* __re
     const double slse = red[(int64_t)Kpad * F16 + 0], srl = red[(int64_t)Kpad * F16 + 1];
     const bool split = red[(int64_t)Kpad * F16 + 2] > 0.0;
     scalars[0] = slse;                       // sum_n logsumexp_k l
-    scalars[1] = split ? srl : NAN;          // sum_n sum_k r l
-    scalars[2] = split ? slse - srl : NAN;   // -sum r log r  (log r = l - lse, sum_k r = 1)
+    // (integer selects: the file is built with -fno-honor-nans, under which a floating-point select may
+    // fold a NaN arm away)
+    const long long nan_bits = 0x7ff8000000000000LL;
+    scalars[1] = __longlong_as_double(split ? __double_as_longlong(srl) : nan_bits);          // sum_n sum_k r l
+    scalars[2] = __longlong_as_double(split ? __double_as_longlong(slse - srl) : nan_bits);   // -sum r log r  (log r = l - lse, sum_k r = 1)
   }
 }
 

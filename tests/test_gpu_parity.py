@@ -176,6 +176,34 @@ def test_many_tiles_per_workgroup(engine, D, K):
     assert np.array_equal(lab, ref) and np.array_equal(S3.n, np.bincount(ref, minlength=K))
 
 
+@pytest.mark.parametrize("D,K", [(15, 64), (8, 256), (3, 256), (16, 64)])
+def test_repeated_launches_are_bit_identical(engine, D, K):
+    """Every launch of every mode returns the SAME bits (fixed summation order, no float atomics) with all
+    workgroups co-resident and several tiles per workgroup.  Regression for a lane-layout experiment whose
+    kernels were right on the first tile of a workgroup and sporadically wrong on later ones when two workgroups
+    shared a CU (tools/stress_generic.py is the long form of this test)."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    N = 32 * 512 * 3 + 77
+    rng = np.random.default_rng(100 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    _, _, sxx = O.packed_stats(Z, np.exp(L - logsumexp(L, axis=0)))
+    ref = O.sample_discrete_from_log(L, O.philox_uniforms(5, np.arange(N), 1))
+    for kw in ({}, dict(keep_lse=True), dict(entropy_split=True)):
+        first = None
+        for _ in range(6):
+            S, sc = engine.estep(c, b, W, **kw)
+            if first is None:
+                first = (S.sxx.copy(), sc[0])
+                assert rel_err(S.sxx, sxx) < 1e-11
+            assert np.array_equal(S.sxx, first[0]) and sc[0] == first[1]
+    for _ in range(6):
+        lab, S = engine.gibbs_labels(c, b, W, seed=5, sweep=1)
+        assert np.array_equal(lab, ref) and np.array_equal(S.n, np.bincount(ref, minlength=K))
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the
