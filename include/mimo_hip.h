@@ -105,6 +105,17 @@ int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0);
 int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                int flags, double* S, double* scalars);
 
+/* The same pass with a weight per data row: the statistics are those of r_kn * row_weights[n], the tables
+ * and the ELBO scalars those of the unweighted r_kn.
+ * Replaces: the `weights` argument of the hierarchical drivers — resp * weights feeds the update while the
+ *   bound uses resp (mimo/mixtures/hgmm.py:199-207), and an outer mixture hands its responsibilities
+ *   resp[m, :] to inner mixture m as such weights (hgmm.py:407-414, 457-465).
+ * row_weights: N doubles (host, or device with MIMO_F_DEVICE_IN).  Shapes on the two-stage path
+ * (Dz > 16, or K > 64 with Dz > 9) return MIMO_E_UNSUPPORTED: there the weights go in as a table
+ * (mimo_estep with MIMO_F_KEEP_RESP, then mimo_weighted_stats). */
+int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                        const double* row_weights, int flags, double* S, double* scalars);
+
 /* Completes a call issued with MIMO_F_ASYNC: waits for the context's stream and copies the packed
  * statistics / scalars of that call to the host pointers (either may be NULL).  Lets the host overlap
  * its own O(K D^3) work (the ELBO's prior terms, gmm.py:360-361) with the pass over the data. */

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mimo_attach": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mimo_set_row_offset": (C.c_int, [_vp, C.c_int64]),
     "mimo_estep": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "mimo_estep_weighted": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "mimo_wait": (C.c_int, [_vp, _vp, _vp]),
     "mimo_gibbs_labels": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _vp,
                                     C.c_int, _vp, _vp]),

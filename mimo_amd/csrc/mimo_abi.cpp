@@ -452,6 +452,34 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   return run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
 }
 
+int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                        const double* row_weights, int flags, double* S, double* scalars) {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!c || !b || !W || !row_weights) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: c, b, W, row_weights must be non-NULL");
+  if (flags & MIMO_F_NO_STATS) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: the weights only enter the statistics");
+  if (!S && !(flags & MIMO_F_ASYNC)) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: S is NULL");
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  if (!fused_covers(a.K16, a.F16 / 16, kSrcEstep))
+    return fail(ctx, MIMO_E_UNSUPPORTED, "mimo_estep_weighted: K=%d, Dz=%d runs on the two-stage path, which takes "
+                "its weights as a table (mimo_estep + mimo_weighted_stats)", K, ctx->D);
+  a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
+  if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
+  if (flags & MIMO_F_DEVICE_IN) {
+    a.u = row_weights;
+  } else {
+    const size_t n1 = (size_t)(ctx->N > 0 ? ctx->N : 1);
+    if ((rc = ensure_dev(ctx, &ctx->u_d, &ctx->u_cap, n1))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, row_weights, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // pageable host memory
+    a.u = ctx->u_d;
+  }
+  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  a.theta = ctx->theta_d;
+  return run_fused(ctx, a, kSrcEstep, flags, S, scalars);
+}
+
 int mimo_wait(mimo_ctx* ctx, double* S, double* scalars) {
   int rc = bind(ctx); if (rc) return rc;
   if (!ctx->pending_async) return fail(ctx, MIMO_E_STATE, "mimo_wait: no asynchronous call is pending");

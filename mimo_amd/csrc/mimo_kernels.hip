@@ -272,15 +272,21 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
             }
           }
           const double scale = valid ? inv : 0.0;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            x[c] *= scale;
-            if (ok(c)) row[c] = x[c];
-          }
+          // per-row weights (generic mode only; a.u doubles as the weight vector of a mean-field pass): the
+          // statistics are those of r_kn w_n, the tables and the ELBO scalars those of r_kn
+          // (mimo/mixtures/hgmm.py:199-207: resp * weights feeds the update, the unweighted resp the bound)
+          double wrow = 1.0;
+          if constexpr (MODE == kGeneric) wrow = (a.u && valid) ? a.u[n] : 1.0;
           if (out_resp && valid) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-              if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c];
+              if (c < CPP && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = x[c] * scale;
+          }
+          const double wscale = MODE == kGeneric ? scale * wrow : scale;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            x[c] *= wscale;
+            if (ok(c)) row[c] = x[c];
           }
         } else {
           // inverse-CDF draw (mimo/utils/stats.py:10-17): label = #{k : u * cum[K-1] > cum[k]} with
@@ -439,11 +445,13 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
       }
     }
     const double scale = valid ? inv : 0.0;
+    double wrow = 1.0;   // per-row weights: see normalise_tile
+    if constexpr (MODE == kGeneric) wrow = (a.u && valid) ? a.u[n] : 1.0;
 #pragma unroll
     for (int c = 0; c < 8 * RBW; ++c) {
       if (ok(c)) {
         const double r = row[c] * scale;
-        row[c] = r;
+        row[c] = MODE == kGeneric ? r * wrow : r;
         if (out_resp && valid && k0 + c < K) out_resp[(int64_t)(k0 + c) * N + n] = r;
       }
       if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -1351,7 +1359,8 @@ static fused_fn pick_stats(int ncb, int mode) {
 static fused_fn resolve_fused(const KernelArgs& a, int src) {
   const int ncb = a.F16 / 16;
   int mode = src == kSrcWeights ? kModeWeights : src == kSrcLabels ? kModeLabels : kGeneric;
-  if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse) mode = a.gibbs ? kFastGibbs : kFastVI;
+  if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse && (a.gibbs || !a.u))
+    mode = a.gibbs ? kFastGibbs : kFastVI;   // (per-row weights of a mean-field pass live in the generic kernels)
   if (!fused_covers(a.K16, ncb, src)) return nullptr;
   if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
   return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)

@@ -9,3 +9,5 @@ from .bayesian import (CategoricalWithDirichlet, CategoricalWithStickBreaking,
                        StackedGaussiansWithNormalWisharts, StackedLinearGaussiansWithMatrixNormalWisharts,
                        TiedGaussiansWithNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts,
                        StackedGaussiansWithNormalGammas, TiedGaussiansWithNormalGammas)
+from .hierarchical import (NormalWishart, TiedGaussiansWithScaledPrecision,
+                           TiedGaussiansWithHierarchicalNormalWisharts)

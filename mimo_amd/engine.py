@@ -115,17 +115,31 @@ class HipEngine:
             raise ValueError(f"parameter shapes {c.shape}, {b.shape}, {W.shape} do not match K={K}, Dz={self.D}")
         return c, b, W, K
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
+              row_weights=None):
         """Fused E-step.  Returns (SuffStats | None, scalars[3]); scalars[1:] are NaN unless
-        entropy_split (or a keep_* flag) is set."""
+        entropy_split (or a keep_* flag) is set.  `row_weights` (N,): the statistics are those of
+        r_kn * w_n, tables and scalars stay unweighted (hgmm.py:199-207)."""
         c, b, W, K = self._params(c, b, W)
         flags = ((_lib.F_KEEP_RESP if keep_resp else 0) | (_lib.F_KEEP_LOGP if keep_logp else 0)
                  | (_lib.F_KEEP_LSE if keep_lse else 0) | (0 if stats else _lib.F_NO_STATS)
                  | (_lib.F_ENTROPY_SPLIT if entropy_split else 0))
         S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
         sc = np.empty(3)
-        self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, flags,
-                                         _ptr(S) if stats else None, _ptr(sc)))
+        if row_weights is not None and stats:
+            w = _f64(row_weights).reshape(-1)
+            if w.shape[0] != self.N:
+                raise ValueError(f"row_weights has {w.shape[0]} entries, data has {self.N} rows")
+            rc = self._lib.mimo_estep_weighted(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(w), flags, _ptr(S), _ptr(sc))
+            if rc == _lib.E_UNSUPPORTED:      # two-stage shapes take their weights as a table
+                self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K,
+                                                 flags | _lib.F_KEEP_RESP | _lib.F_NO_STATS, None, _ptr(sc)))
+                self._K = K
+                return self.weighted_stats(self.get_resp(K) * w[None, :]), sc
+            self._check(rc)
+        else:
+            self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, flags,
+                                             _ptr(S) if stats else None, _ptr(sc)))
         self._K = K
         return (SuffStats.from_packed(S, K, self.D) if stats else None), sc
 

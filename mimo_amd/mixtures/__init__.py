@@ -1,2 +1,4 @@
 from .gmm import MixtureOfGaussians, BayesianMixtureOfGaussians
 from .ilr import MixtureOfLinearGaussians, BayesianMixtureOfLinearGaussians
+from .hgmm import (BayesianMixtureOfGaussiansWithHierarchicalPrior, MixtureOfMixtureOfGaussians,
+                   BayesianMixtureOfMixtureOfGaussians)

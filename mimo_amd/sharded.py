@@ -94,7 +94,13 @@ class ShardedEngine:
             self._host = torch.empty(n, dtype=torch.float64).pin_memory()
         return self._buf, n - 4
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
+              row_weights=None):
+        """`row_weights` are the weights of THIS rank's rows (hierarchical drivers)."""
+        if row_weights is not None:
+            S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
+                                     entropy_split=entropy_split, row_weights=row_weights)
+            return self._allreduce_host(S, sc) if stats else (None, self._allreduce_scalars(sc))
         if self._device_path and stats and not (keep_resp or keep_logp or keep_lse or entropy_split):
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)

@@ -521,7 +521,100 @@ def diag_gmm_case(name, N, D, K, seed, tied, iters=6):
     print(name, "ok")
 
 
+def hier_gmm_case(name, N, D, K, M, seed, iters=4, sub=3):
+    """Hierarchical mixtures (hgmm.py:118-504, bayesian.py:592-793; examples/hgmm): K Gaussians with one precision
+    under a Normal-Wishart hyper-prior — seeded Gibbs sweeps, VI traces without and with per-datum weights, the
+    full-data natural-gradient driver and the E-step tables — and mixtures of M such mixtures (Gibbs, VI, SVI, EM)."""
+    import random
+    from mimo.distributions import (NormalWishart, TiedGaussiansWithScaledPrecision, TiedGaussiansWithPrecision,
+                                    TiedGaussiansWithHierarchicalNormalWisharts, Categorical)
+    from mimo.mixtures import (BayesianMixtureOfGaussiansWithHierarchicalPrior, BayesianMixtureOfMixtureOfGaussians,
+                               MixtureOfGaussians)
+    from mimo.mixtures.hgmm import MixtureOfMixtureOfGaussians
+    npr.seed(seed)
+    X = make_data(N, D, n_clusters=K)
+    w = np.linspace(0.25, 1., N)
+    out = dict(X=X, w=w, K=np.array(K), M=np.array(M), D=np.array(D), seed=np.array(seed), iters=np.array(iters),
+               sub=np.array(sub))
+
+    def inner(k):
+        gating = CategoricalWithDirichlet(dim=k, prior=Dirichlet(dim=k, alphas=np.ones((k,))))
+        hyper = NormalWishart(dim=D, mu=np.zeros((D,)), kappa=1e-2, psi=np.eye(D), nu=D + 1. + 1e-8)
+        prior = TiedGaussiansWithScaledPrecision(size=k, dim=D, kappas=1e-2 * np.ones((k,)))
+        comps = TiedGaussiansWithHierarchicalNormalWisharts(size=k, dim=D, hyper_prior=hyper, prior=prior)
+        return BayesianMixtureOfGaussiansWithHierarchicalPrior(size=k, dim=D, gating=gating, components=comps)
+
+    def state(m, pre):
+        c = m.components
+        out[pre + "_post_mus"], out[pre + "_post_kappas"] = c.posterior.mus, c.posterior.kappas
+        out[pre + "_post_lmbdas"] = c.posterior.lmbdas
+        for nm, v in zip(("mu", "kappa", "psi", "nu"), c.hyper_posterior.params):
+            out[pre + "_hyper_" + nm] = np.asarray(v)
+        out[pre + "_lik_mus"], out[pre + "_lik_lmbdas"] = c.likelihood.mus, c.likelihood.lmbdas
+        out[pre + "_galphas"] = m.gating.posterior.alphas
+
+    npr.seed(seed + 1); m = inner(K)
+    out["init_lik_mus"], out["init_lik_lmbdas"] = m.components.likelihood.mus, m.components.likelihood.lmbdas
+    npr.seed(seed + 2)
+    m.resample(X.copy(), maxiter=iters, maxsubiter=sub, progress_bar=False)
+    state(m, "gibbs")
+    npr.seed(seed + 3)
+    out["vi_vlb"] = np.array(m.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=iters, maxsubiter=sub, tol=0.,
+                                                            progress_bar=False))
+    state(m, "vi")
+    out["vi_ell_table"] = m.components.expected_log_likelihood(X.copy())
+    out["vi_resp"] = m.expected_responsibilities(X.copy())
+    out["vi_comp_vlb"] = np.array(m.components.variational_lowerbound())
+    out["vi_logpred"] = m.components.log_posterior_predictive_gaussian(X.copy())
+    npr.seed(seed + 4)
+    out["viw_vlb"] = np.array(m.meanfield_coordinate_descent(X.copy(), randomize=True, weights=w, maxiter=iters,
+                                                             maxsubiter=sub, tol=0., progress_bar=False))
+    state(m, "viw")
+    npr.seed(seed + 5)
+    m.meanfield_stochastic_descent(X.copy(), randomize=False, weights=w, maxiter=iters, maxsubiter=sub, step_size=5e-1,
+                                   progress_bar=False)
+    state(m, "svi")
+
+    def outer():
+        gating = CategoricalWithDirichlet(dim=M, prior=Dirichlet(dim=M, alphas=np.ones((M,))))
+        return BayesianMixtureOfMixtureOfGaussians(cluster_size=M, mixture_size=K, dim=D, gating=gating,
+                                                   components=[inner(K) for _ in range(M)])
+
+    def mom_state(mm, pre):
+        out[pre + "_galphas"] = mm.gating.posterior.alphas
+        out[pre + "_post_mus"] = np.stack([c.components.posterior.mus for c in mm.components])
+        out[pre + "_hyper_psi"] = np.stack([c.components.hyper_posterior.wishart.psi for c in mm.components])
+        out[pre + "_inner_galphas"] = np.stack([c.gating.posterior.alphas for c in mm.components])
+
+    npr.seed(seed + 6); mm = outer()
+    npr.seed(seed + 7)
+    mm.meanfield_coordinate_descent(X.copy(), randomize=True, maxiter=3, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    mom_state(mm, "mom_vi")
+    out["mom_vi_resp"] = mm.expected_responsibilities(X.copy())
+    npr.seed(seed + 8); random.seed(seed + 18)
+    mm.meanfield_stochastic_descent(X.copy(), randomize=False, maxiter=3, maxsubiter=2, maxsubsubiter=2, step_size=5e-1,
+                                    batch_size=64, progress_bar=False)
+    mom_state(mm, "mom_svi")
+    npr.seed(seed + 9)
+    mm.resample(X.copy(), init_labels='random', maxiter=2, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    mom_state(mm, "mom_gibbs")
+    out["mom_gibbs_lik_mus"] = np.stack([c.components.likelihood.mus for c in mm.components])
+    npr.seed(seed + 10)
+    comps = [MixtureOfGaussians(gating=Categorical(dim=K), components=TiedGaussiansWithPrecision(size=K, dim=D))
+             for _ in range(M)]
+    em = MixtureOfMixtureOfGaussians(cluster_size=M, mixture_size=K, dim=D, gating=Categorical(dim=M), components=comps)
+    out["mom_em_loglik"] = np.array(em.max_likelihood(X.copy(), randomize=True, maxiter=3, maxsubiter=2, progress_bar=False))
+    out["mom_em_mus"] = np.stack([c.components.mus for c in em.components])
+    out["mom_em_probs"] = em.gating.probs
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hier":
+        hier_gmm_case("hier_gmm_d2_k4_m2", N=400, D=2, K=4, M=2, seed=1354)
+        hier_gmm_case("hier_gmm_d3_k3_m3", N=300, D=3, K=3, M=3, seed=1355)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "diag":
         diag_gmm_case("diag_gmm_d3_k5", N=500, D=3, K=5, seed=1352, tied=False)
         diag_gmm_case("tied_diag_gmm_d4_k6", N=400, D=4, K=6, seed=1353, tied=True)
@@ -553,3 +646,5 @@ if __name__ == "__main__":
     tied_ilr_prediction_case("tied_ilr_dx3_dy2_k6", N=300, K=6, seed=1351, dx=3, dy=2)
     diag_gmm_case("diag_gmm_d3_k5", N=500, D=3, K=5, seed=1352, tied=False)
     diag_gmm_case("tied_diag_gmm_d4_k6", N=400, D=4, K=6, seed=1353, tied=True)
+    hier_gmm_case("hier_gmm_d2_k4_m2", N=400, D=2, K=4, M=2, seed=1354)
+    hier_gmm_case("hier_gmm_d3_k3_m3", N=300, D=3, K=3, M=3, seed=1355)

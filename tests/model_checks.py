@@ -358,6 +358,99 @@ def check_diag_gmm(name, engine, tol=1e-8):
     assert np.all(fixed.alphas >= prior.alphas) and np.any(fixed.alphas > prior.alphas + 1.) and np.all(fixed.betas > 0.)
 
 
+def check_hier_gmm(name, engine, tol=1e-8):
+    """Hierarchical mixtures (examples/hgmm): seeded Gibbs sweeps, VI traces without and
+    with per-row weights, the natural-gradient driver, tables, and mixtures of mixtures (VI, SVI, Gibbs, EM)."""
+    import random
+    from mimo_amd.distributions import (NormalWishart, TiedGaussiansWithScaledPrecision,
+                                        TiedGaussiansWithHierarchicalNormalWisharts, Categorical)
+    from mimo_amd.mixtures import (BayesianMixtureOfGaussiansWithHierarchicalPrior, MixtureOfMixtureOfGaussians,
+                                   BayesianMixtureOfMixtureOfGaussians, MixtureOfGaussians)
+    g = load_golden(name)
+    X, w = g["X"], g["w"]
+    K, M, D, seed, iters, sub = (int(g[k]) for k in ("K", "M", "D", "seed", "iters", "sub"))
+
+    def inner(k):
+        gating = CategoricalWithDirichlet(dim=k, prior=Dirichlet(dim=k, alphas=np.ones((k,))))
+        hyper = NormalWishart(dim=D, mu=np.zeros((D,)), kappa=1e-2, psi=np.eye(D), nu=D + 1. + 1e-8)
+        prior = TiedGaussiansWithScaledPrecision(size=k, dim=D, kappas=1e-2 * np.ones((k,)))
+        comps = TiedGaussiansWithHierarchicalNormalWisharts(size=k, dim=D, hyper_prior=hyper, prior=prior, engine=engine)
+        return BayesianMixtureOfGaussiansWithHierarchicalPrior(size=k, dim=D, gating=gating, components=comps, engine=engine)
+
+    def check_state(m, pre, t):
+        c = m.components
+        assert rel_err(c.posterior.mus, g[pre + "_post_mus"]) < t, pre
+        assert rel_err(c.posterior.kappas, g[pre + "_post_kappas"]) < t, pre
+        assert rel_err(c.posterior.lmbdas, g[pre + "_post_lmbdas"]) < t, pre
+        for nm, v in zip(("mu", "kappa", "psi", "nu"), c.hyper_posterior.params):
+            assert rel_err(np.asarray(v), g[pre + "_hyper_" + nm]) < t, (pre, nm)
+        assert rel_err(c.likelihood.mus, g[pre + "_lik_mus"]) < t and rel_err(c.likelihood.lmbdas, g[pre + "_lik_lmbdas"]) < t
+        assert rel_err(m.gating.posterior.alphas, g[pre + "_galphas"]) < t, pre
+
+    npr.seed(seed + 1)
+    m = inner(K)
+    assert rel_err(m.components.likelihood.mus, g["init_lik_mus"]) < 1e-12
+    assert rel_err(m.components.likelihood.lmbdas, g["init_lik_lmbdas"]) < 1e-12
+    npr.seed(seed + 2)
+    m.resample(X, maxiter=iters, maxsubiter=sub, progress_bar=False)
+    check_state(m, "gibbs", tol)
+    npr.seed(seed + 3)
+    vlb = m.meanfield_coordinate_descent(X, randomize=False, maxiter=iters, maxsubiter=sub, tol=0., progress_bar=False)
+    assert rel_err(np.array(vlb), g["vi_vlb"]) < tol
+    check_state(m, "vi", 1e-7)
+    assert rel_err(m.components.expected_log_likelihood(X), g["vi_ell_table"]) < 1e-7
+    assert rel_err(m.expected_responsibilities(X), g["vi_resp"]) < 1e-7
+    assert rel_err(np.sum(m.components.variational_lowerbound()), np.sum(g["vi_comp_vlb"])) < 1e-7
+    assert rel_err(m.components.log_posterior_predictive_gaussian(X), g["vi_logpred"]) < 1e-7
+    # explicit-responsibility bound = the fused one (hgmm.py:301-306)
+    assert abs(m.variational_lowerbound(X, g["vi_resp"]) - g["vi_vlb"][-1]) < 1e-7 * abs(g["vi_vlb"][-1])
+    npr.seed(seed + 4)
+    vlb = m.meanfield_coordinate_descent(X, randomize=True, weights=w, maxiter=iters, maxsubiter=sub, tol=0.,
+                                         progress_bar=False)
+    assert rel_err(np.array(vlb), g["viw_vlb"]) < tol
+    check_state(m, "viw", 1e-7)
+    npr.seed(seed + 5)
+    assert m.meanfield_stochastic_descent(X, randomize=False, weights=w, maxiter=iters, maxsubiter=sub, step_size=5e-1,
+                                          progress_bar=False) == []
+    check_state(m, "svi", 1e-7)
+
+    def outer():
+        gating = CategoricalWithDirichlet(dim=M, prior=Dirichlet(dim=M, alphas=np.ones((M,))))
+        return BayesianMixtureOfMixtureOfGaussians(cluster_size=M, mixture_size=K, dim=D, gating=gating,
+                                                   components=[inner(K) for _ in range(M)])
+
+    def check_mom(mm, pre, t):
+        assert rel_err(mm.gating.posterior.alphas, g[pre + "_galphas"]) < t, pre
+        assert rel_err(np.stack([c.components.posterior.mus for c in mm.components]), g[pre + "_post_mus"]) < t, pre
+        assert rel_err(np.stack([c.components.hyper_posterior.wishart.psi for c in mm.components]),
+                       g[pre + "_hyper_psi"]) < t, pre
+        assert rel_err(np.stack([c.gating.posterior.alphas for c in mm.components]), g[pre + "_inner_galphas"]) < t, pre
+
+    npr.seed(seed + 6)
+    mm = outer()
+    npr.seed(seed + 7)
+    mm.meanfield_coordinate_descent(X, randomize=True, maxiter=3, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    check_mom(mm, "mom_vi", 1e-7)
+    assert rel_err(mm.expected_responsibilities(X), g["mom_vi_resp"]) < 1e-7
+    npr.seed(seed + 8)
+    random.seed(seed + 18)
+    mm.meanfield_stochastic_descent(X, randomize=False, maxiter=3, maxsubiter=2, maxsubsubiter=2, step_size=5e-1,
+                                    batch_size=64, progress_bar=False)
+    check_mom(mm, "mom_svi", 1e-7)
+    npr.seed(seed + 9)
+    mm.resample(X, init_labels='random', maxiter=2, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    check_mom(mm, "mom_gibbs", 1e-7)
+    assert rel_err(np.stack([c.components.likelihood.mus for c in mm.components]), g["mom_gibbs_lik_mus"]) < 1e-7
+    npr.seed(seed + 10)
+    comps = [MixtureOfGaussians(gating=Categorical(dim=K), components=TiedGaussiansWithPrecision(K, D, engine=engine),
+                                engine=engine) for _ in range(M)]
+    em = MixtureOfMixtureOfGaussians(cluster_size=M, mixture_size=K, dim=D, gating=Categorical(dim=M), components=comps)
+    ll = em.max_likelihood(X, randomize=True, maxiter=3, maxsubiter=2, progress_bar=False)
+    assert rel_err(np.array(ll), g["mom_em_loglik"]) < tol
+    assert rel_err(np.stack([c.components.mus for c in em.components]), g["mom_em_mus"]) < 1e-7
+    assert rel_err(em.gating.probs, g["mom_em_probs"]) < 1e-7
+
+
 def check_tied_ilr_prediction(name, engine, tol=1e-7):
     """examples/ilr/evaluate_sine.py at fixture size: tied MNW experts, Gibbs -> SVI -> VI -> prediction."""
     import random

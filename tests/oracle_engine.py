@@ -38,7 +38,8 @@ class OracleEngine:
         n, sx, sxx = O.packed_stats(self.Z, R)
         return SuffStats(n, sx, sxx)
 
-    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False):
+    def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
+              row_weights=None):
         L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))
         lse = logsumexp(L, axis=0) if self.N else np.zeros(0)
         R = np.exp(L - lse)
@@ -51,7 +52,8 @@ class OracleEngine:
             self._lse = lse
         srl = float(np.sum(R * L))
         sc = np.array([float(np.sum(lse)), srl, float(np.sum(lse)) - srl])
-        return (self._stats(R) if stats else None), sc
+        Rw = R if row_weights is None else R * np.asarray(row_weights, float).reshape(1, -1)
+        return (self._stats(Rw) if stats else None), sc
 
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
         L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))

@@ -54,6 +54,11 @@ def test_diag_gmm_all_drivers(engine, name):
     mc.check_diag_gmm(name, engine)
 
 
+@pytest.mark.parametrize("name", ["hier_gmm_d2_k4_m2", "hier_gmm_d3_k3_m3"])
+def test_hierarchical_gmm_all_drivers(engine, name):
+    mc.check_hier_gmm(name, engine)
+
+
 @pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
 def test_tied_ilr_flow_and_prediction(name, engine):
     mc.check_tied_ilr_prediction(name, engine)
@@ -202,6 +207,32 @@ def test_repeated_launches_are_bit_identical(engine, D, K):
     for _ in range(6):
         lab, S = engine.gibbs_labels(c, b, W, seed=5, sweep=1)
         assert np.array_equal(lab, ref) and np.array_equal(S.n, np.bincount(ref, minlength=K))
+
+
+@pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (8, 200, 33000), (5, 7, 0), (20, 16, 5000)])
+def test_row_weighted_estep(engine, D, K, N):
+    """mimo_estep_weighted: statistics of r_kn w_n, scalars / tables of the unweighted r_kn (hgmm.py:199-207) —
+    single-pass shapes in-kernel, two-stage shapes (Dz = 20) through the table route."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(1000 * D + K)
+    Z, c, b, W = _random_problem(rng, max(N, 1), D, K)
+    Z = Z[:N]
+    w = rng.uniform(0.0, 2.0, size=N)
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0) if N else np.zeros(0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R * w[None, :])
+    S, sc = engine.estep(c, b, W, row_weights=w, keep_resp=True)
+    scale = max(np.abs(sxx).max(), 1e-300) if N else 1.0
+    assert np.abs(S.n - n).max() <= 1e-11 * max(n.max(), 1.0) and np.abs(S.sxx - sxx).max() <= 1e-11 * scale
+    assert abs(sc[0] - lse.sum()) <= 1e-12 * max(abs(lse.sum()), 1.0)
+    if N:
+        assert rel_err(engine.get_resp(K), R) < 1e-11        # the table stays unweighted
+        S1, _ = engine.estep(c, b, W, row_weights=np.ones(N))
+        S0, _ = engine.estep(c, b, W)
+        assert rel_err(S1.sxx, S0.sxx) < 1e-13
 
 
 def test_full_size_properties(engine):

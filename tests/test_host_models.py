@@ -49,6 +49,11 @@ def test_diag_gmm_all_drivers(name):
     mc.check_diag_gmm(name, OracleEngine())
 
 
+@pytest.mark.parametrize("name", ["hier_gmm_d2_k4_m2", "hier_gmm_d3_k3_m3"])
+def test_hierarchical_gmm_all_drivers(name):
+    mc.check_hier_gmm(name, OracleEngine())
+
+
 @pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
 def test_tied_ilr_flow_and_prediction(name):
     mc.check_tied_ilr_prediction(name, OracleEngine())
