@@ -411,6 +411,6 @@ class BayesianMixtureOfLinearGaussians:
             covar = np.einsum('kh,...hj,ji->...ki', mat, covar, mat.T)
         if incremental:
             mu += x[:, :self.output_dim]
-        var = np.vstack(list(map(np.diag, covar))) if len(covar) else np.zeros((0, self.output_dim))
+        var = np.diagonal(covar, axis1=1, axis2=2).copy()     # (the reference stacks N np.diag calls, ilr.py:417)
         out = (mu, var if variance == 'diagonal' else covar, np.sqrt(var))
         return out + (nlpd,) if y is not None else out
