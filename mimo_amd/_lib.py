@@ -28,6 +28,7 @@ SIGNATURES = {
     "mimo_upload": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mimo_attach": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
     "mimo_set_row_offset": (C.c_int, [_vp, C.c_int64]),
+    "mimo_set_structure": (C.c_int, [_vp, C.c_int]),
     "mimo_estep": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "mimo_estep_weighted": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "mimo_wait": (C.c_int, [_vp, _vp, _vp]),

@@ -29,7 +29,9 @@ struct mimo_ctx {
   int D = 0;
   int64_t row0 = 0;
 
-  // feature map for the current D
+  // feature map for the current D and structure (0: full symmetric W, 1: diagonal W)
+  int structure = 0;
+  int feat_structure = -1;
   int feat_D = -1;
   int F = 0, F16 = 0;
   std::vector<uint8_t> feat_h;
@@ -130,14 +132,20 @@ static int bind(mimo_ctx* ctx) {
 }
 
 // feature table for dimension D: pairs (a,b), a <= b <= D over z~ = [z, 1]; padding -> (D+1,D+1)
+static int fidx(const mimo_ctx* ctx, int a, int b) {
+  return ctx->structure ? diag_feat_index(ctx->D, a, b) : feat_index(ctx->D, a, b);
+}
+
 static int prepare_features(mimo_ctx* ctx, int D) {
-  if (ctx->feat_D == D) return MIMO_OK;
-  ctx->F = feat_count(D);
-  ctx->F16 = feat_pad16(D);
+  if (ctx->feat_D == D && ctx->feat_structure == ctx->structure) return MIMO_OK;
+  const bool diag = ctx->structure != 0;
+  ctx->F = diag ? diag_feat_count(D) : feat_count(D);
+  ctx->F16 = diag ? diag_feat_pad16(D) : feat_pad16(D);
   ctx->feat_h.assign((size_t)ctx->F16 * 2, (uint8_t)(D + 1));
   for (int a = 0; a <= D; ++a)
     for (int b = a; b <= D; ++b) {
-      const int f = feat_index(D, a, b);
+      if (diag && a != b && b != D) continue;
+      const int f = diag ? diag_feat_index(D, a, b) : feat_index(D, a, b);
       ctx->feat_h[2 * f] = (uint8_t)a;
       ctx->feat_h[2 * f + 1] = (uint8_t)b;
     }
@@ -145,6 +153,7 @@ static int prepare_features(mimo_ctx* ctx, int D) {
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->feat_d), ctx->feat_h.size()));
   HIP_TRY(ctx, hipMemcpy(ctx->feat_d, ctx->feat_h.data(), ctx->feat_h.size(), hipMemcpyHostToDevice));
   ctx->feat_D = D;
+  ctx->feat_structure = ctx->structure;
   return MIMO_OK;
 }
 
@@ -170,6 +179,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->feat = ctx->feat_d;
   a->row0 = ctx->row0;
   a->do_stats = 1;
+  a->diag = ctx->structure != 0;
   a->ntiles = (ctx->N + kTile - 1) / kTile;
 }
 
@@ -196,18 +206,22 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
       const int s = f / 4, kk = f % 4;
       img[((size_t)rb * NS + s) * 64 + kk * 16 + i] = v;
     };
-    put(feat_index(D, D, D), c[k]);
+    put(fidx(ctx, D, D), c[k]);
     for (int a = 0; a < D; ++a) {
-      put(feat_index(D, a, D), bk[a]);
-      put(feat_index(D, a, a), -0.5 * Wk[a * D + a]);
-      for (int bb = a + 1; bb < D; ++bb)
-        put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+      put(fidx(ctx, a, D), bk[a]);
+      put(fidx(ctx, a, a), -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) {
+        if (!ctx->structure) put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+        else if (Wk[a * D + bb] != 0.0 || Wk[bb * D + a] != 0.0)
+          return fail(ctx, MIMO_E_INVALID, "diagonal structure is set (mimo_set_structure) but W[%d] has the "
+                      "off-diagonal entry (%d,%d)", k, a, bb);
+      }
     }
   }
   // padding components of the last row block: l = -1e300 for every datum, so the normalise phase needs no
   // "does this component exist" test (exp -> 0, never the maximum, zero weight in the statistics)
   for (int k = K; k < 16 * ((K + 15) / 16); ++k) {
-    const int f = feat_index(D, D, D);
+    const int f = fidx(ctx, D, D);
     img[((size_t)(k / 16) * NS + f / 4) * 64 + (f % 4) * 16 + k % 16] = kPadLogDensity;
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -307,12 +321,12 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   HIP_TRY(ctx, launch_reduce(ctx->partials, grid, (int64_t)pstride, ctx->reduced, ctx->stream));
   const size_t slen = (size_t)K * (1 + D + (size_t)D * D);
   if (device_out) {
-    HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, a.F16, want_stats ? S : nullptr, scalars, ctx->stream));
+    HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, ctx->F, a.F16, want_stats ? S : nullptr, scalars, ctx->stream));
     return MIMO_OK;
   }
   if ((rc = ensure_dev(ctx, &ctx->S_d, &ctx->S_cap, slen + 4))) return rc;
   if ((rc = ensure_pinned(ctx, &ctx->S_h, &ctx->S_hcap, slen + 4))) return rc;
-  HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, a.F16, want_stats ? ctx->S_d : nullptr,
+  HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, ctx->F, a.F16, want_stats ? ctx->S_d : nullptr,
                              ctx->S_d + slen, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (flags & MIMO_F_ASYNC) {
@@ -408,6 +422,17 @@ int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
   if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
   ctx->Z = Z_dev;
   return MIMO_OK;
+}
+
+int mimo_set_structure(mimo_ctx* ctx, int structure) {
+  int rc = bind(ctx); if (rc) return rc;
+  if (structure != MIMO_STRUCT_FULL && structure != MIMO_STRUCT_DIAG)
+    return fail(ctx, MIMO_E_INVALID, "mimo_set_structure: unknown structure %d", structure);
+  if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
+  if (ctx->structure == structure) return MIMO_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the feature table may be in use
+  ctx->structure = structure;
+  return ctx->D > 0 ? prepare_features(ctx, ctx->D) : MIMO_OK;
 }
 
 int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0) {

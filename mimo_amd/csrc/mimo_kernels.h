@@ -44,6 +44,7 @@ struct KernelArgs {
   int cb0;                // statistics modes: first 16-wide feature column block of this launch
   int F16_total;          // padded feature count of the whole problem (partials row stride)
   int write_scalars;      // write the 4 scalar slots of the partial block (0: another launch owns them)
+  int diag;               // feature table is the diagonal one (2 Dz + 1 features): table-driven E-step kernels
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
 };
 
@@ -53,6 +54,11 @@ inline int feat_pad16(int D) { return (feat_count(D) + 15) / 16 * 16; }
 inline int feat_index(int D, int a, int b) {  // a <= b <= D
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }
+// diagonal structure (W_k diagonal): only the 2D+1 features z_a^2, z_a, 1 exist —
+//   f = a for (a,a), D + a for (a,D), 2D for (D,D)
+inline int diag_feat_count(int D) { return 2 * D + 1; }
+inline int diag_feat_pad16(int D) { return (diag_feat_count(D) + 15) / 16 * 16; }
+inline int diag_feat_index(int D, int a, int b) { return a == D ? 2 * D : (b == D ? D + a : a); }
 
 size_t fused_lds_bytes(const KernelArgs& a);
 int fused_grid(const KernelArgs& a, int num_cu, int src);
@@ -65,7 +71,7 @@ hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t strea
 bool fused_covers(int K16, int ncb, int src);
 int stats_group_ncb(int K16);   // feature column blocks one statistics launch can accumulate for this K
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
-hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
+hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream);
 
 hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,

@@ -599,7 +599,7 @@ void fused_kernel(const KernelArgs a) {
   // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
   // critical path (T*D <= 512 for the fused E-step modes, Dz <= 16; <= 1024 for the statistics modes).
-  constexpr int ZPT = SRC == kSrcEstep ? 2 : 4;
+  constexpr int ZPT = (SRC == kSrcEstep && DS > 0) ? 2 : 4;   // DS = 0: table-driven features, Dz up to 32
   int zoff[ZPT];
 #pragma unroll
   for (int i = 0; i < ZPT; ++i) {
@@ -1252,9 +1252,8 @@ __global__ void table_entropy_partials(const double* __restrict__ t, int64_t cou
 
 // feature-space block [Kpad][F16] (+4 scalars) -> packed S[K][1 + D + D*D] and scalars[3]
 __global__ void unpack_stats(const double* __restrict__ red, const uint8_t* __restrict__ feat,
-                             int K, int D, int F16, double* __restrict__ S,
+                             int K, int D, int F, int F16, double* __restrict__ S,
                              double* __restrict__ scalars) {
-  const int F = (D + 1) * (D + 2) / 2;
   const int Kpad = (K + 15) / 16 * 16;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (S && e < (int64_t)K * F) {
@@ -1344,6 +1343,19 @@ static fused_fn pick_estep(int D, int mode) {
   return nullptr;
 }
 
+// E-step modes over a table-driven feature set (diagonal structure: 2 Dz + 1 features, at most 5 column blocks)
+template <int RBW>
+static fused_fn pick_estep_table(int ncb, int mode) {
+#define MIMO_ESTEP_TABLE_CASE(n) case n: return mode == kFastVI ? fused_kernel<n, RBW, kFastVI, 0> \
+    : mode == kFastGibbs ? fused_kernel<n, RBW, kFastGibbs, 0> : fused_kernel<n, RBW, kGeneric, 0>;
+  switch (ncb) {
+    MIMO_ESTEP_TABLE_CASE(1) MIMO_ESTEP_TABLE_CASE(2) MIMO_ESTEP_TABLE_CASE(3) MIMO_ESTEP_TABLE_CASE(4)
+    MIMO_ESTEP_TABLE_CASE(5)
+  }
+#undef MIMO_ESTEP_TABLE_CASE
+  return nullptr;
+}
+
 // statistics modes: table-driven feature build, one instantiation per column-block count
 template <int RBW>
 static fused_fn pick_stats(int ncb, int mode) {
@@ -1362,6 +1374,8 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
   if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse && (a.gibbs || !a.u))
     mode = a.gibbs ? kFastGibbs : kFastVI;   // (per-row weights of a mean-field pass live in the generic kernels)
   if (!fused_covers(a.K16, ncb, src)) return nullptr;
+  if (src == kSrcEstep && a.diag)
+    return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : pick_estep_table<4>(ncb, mode);
   if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
   return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
          : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
@@ -1454,12 +1468,16 @@ hipError_t launch_table_entropy(const double* table, int64_t count, double* part
   return launch_reduce(partials, nblocks, 1, out, stream);
 }
 
-hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F16,
+hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream) {
   const int bs = 256;
-  const int64_t total = (int64_t)K * feat_count(D);
+  const int64_t total = (int64_t)K * F;
+  if (S_packed && F < feat_count(D)) {   // diagonal structure: the off-diagonal second moments are not computed
+    hipError_t e = hipMemsetAsync(S_packed, 0, sizeof(double) * (size_t)K * (1 + D + (size_t)D * D), stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(unpack_stats, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, stream,
-                     reduced, feat, K, D, F16, S_packed, scalars3);
+                     reduced, feat, K, D, F, F16, S_packed, scalars3);
   return hipGetLastError();
 }
 

@@ -128,7 +128,7 @@ class StackedGaussiansWithPrecision:
         if np.isnan(data).any():
             raise ValueError("NaN rows are not supported by the HIP engine (reference drops them: "
                              "gaussian.py:493-494); filter them before calling")
-        return _engine.bind(self.engine, data.reshape(-1, self.dim))
+        return _engine.bind(self.engine, data.reshape(-1, self.dim), 'diag' if self.diagonal else 'full')
 
     def log_likelihood(self, x):
         """(K, N) table of component log-densities (gaussian.py:510-521)."""

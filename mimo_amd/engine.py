@@ -81,6 +81,13 @@ class HipEngine:
     def set_row_offset(self, row0):
         self._check(self._lib.mimo_set_row_offset(self._ctx, int(row0)))
 
+    def set_structure(self, structure):
+        """'full' (symmetric W) or 'diag' (diagonal W: the 2 Dz + 1 feature kernels, mimo_set_structure)."""
+        code = {'full': 0, 'diag': 1}[structure]
+        if getattr(self, '_structure', 0) != code:
+            self._check(self._lib.mimo_set_structure(self._ctx, code))
+            self._structure = code
+
     def profile(self, enable=True):
         self._check(self._lib.mimo_profile(self._ctx, 1 if enable else 0))
 
@@ -290,9 +297,12 @@ def _bind_key(Z):
     return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str)
 
 
-def bind(engine, Z):
+def bind(engine, Z, structure='full'):
     """Make `Z` ((N,Dz) float64 host array) the engine's resident data set, uploading it only if it
-    is not the array bound last (identity = address + shape; in-place edits need engine.unbind())."""
+    is not the array bound last (identity = address + shape; in-place edits need engine.unbind()), and
+    select the structure of the precision blocks the caller is going to pass."""
+    if hasattr(engine, 'set_structure'):
+        engine.set_structure(structure)
     Z = np.asarray(Z)
     if Z.ndim == 1:
         Z = Z.reshape(-1, 1)

@@ -82,7 +82,8 @@ class MixtureOfGaussians:
             return c + np.log(self.gating.probs), b, W
 
     def _bind(self, obs):
-        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim),
+                            'diag' if getattr(self.components, 'diagonal', False) else 'full')
 
     # ---- reference-shaped table methods --------------------------------------------------------
     def log_complete_likelihood(self, obs):
@@ -170,8 +171,11 @@ class BayesianMixtureOfGaussians:
     def dim(self):
         return self.likelihood.dim
 
+    def _structure(self):
+        return 'diag' if getattr(self.components.likelihood, 'diagonal', False) else 'full'
+
     def _bind(self, obs):
-        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim), self._structure())
 
     def used_labels(self, obs):
         labels = np.argmax(self.expected_responsibilities(obs), axis=0)
@@ -347,6 +351,8 @@ class BayesianMixtureOfGaussians:
                   disable=not progress_bar) as pbar:
             for i in range(maxiter):
                 for batch in batches(batch_size, len(obs)):
+                    if hasattr(beng, 'set_structure'):
+                        beng.set_structure(self._structure())
                     beng.upload(obs[batch, :])
                     if i == 0 and randomize is True:
                         resp = npr.rand(self.size, len(batch))
@@ -363,7 +369,7 @@ class BayesianMixtureOfGaussians:
         return vlb
 
     def meanfield_sgd_parameters(self, obs, resp, scale, step_size):
-        eng = _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+        eng = self._bind(obs)
         S = eng.weighted_stats(resp)
         self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(S, self.components))
         self.gating.meanfield_sgd(None, S.n, scale, step_size)

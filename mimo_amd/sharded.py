@@ -94,6 +94,10 @@ class ShardedEngine:
             self._host = torch.empty(n, dtype=torch.float64).pin_memory()
         return self._buf, n - 4
 
+    def set_structure(self, structure):
+        if hasattr(self.inner, 'set_structure'):
+            self.inner.set_structure(structure)
+
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):
         """`row_weights` are the weights of THIS rank's rows (hierarchical drivers)."""

@@ -34,6 +34,9 @@ class OracleEngine:
     def set_stream(self, s):
         pass
 
+    def set_structure(self, structure):
+        self.structure = structure      # (the double always computes the full block; diagonal callers read its diagonal)
+
     def _stats(self, R):
         n, sx, sxx = O.packed_stats(self.Z, R)
         return SuffStats(n, sx, sxx)

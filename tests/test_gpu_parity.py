@@ -235,6 +235,48 @@ def test_row_weighted_estep(engine, D, K, N):
         assert rel_err(S1.sxx, S0.sxx) < 1e-13
 
 
+@pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (32, 64, 20000), (8, 256, 33000), (32, 128, 9000),
+                                   (5, 7, 0), (24, 200, 5000)])
+def test_diagonal_structure(engine, D, K, N):
+    """mimo_set_structure(MIMO_STRUCT_DIAG): the 2 Dz + 1 feature kernels against the oracle with W = diag —
+    tables, statistics (zero off-diagonal second moments), bound, labels; full W is rejected; switching back."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(77 * D + K)
+    Z, c, b, Wf = _random_problem(rng, max(N, 1), D, K)
+    Z = Z[:N]
+    W = Wf * np.eye(D)[None, :, :]
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0) if N else np.zeros(0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    dsxx = sxx * np.eye(D)[None, :, :]
+    try:
+        engine.set_structure('diag')
+        engine.upload(Z)
+        S, sc = engine.estep(c, b, W)
+        scale = max(np.abs(sxx).max(), 1e-300) if N else 1.0
+        assert np.abs(S.n - n).max() <= 1e-11 * max(n.max(), 1.0) and np.abs(S.sx - sx).max() <= 1e-11 * scale
+        assert np.abs(S.sxx - dsxx).max() <= 1e-11 * scale
+        assert abs(sc[0] - lse.sum()) <= 1e-12 * max(abs(lse.sum()), 1.0)
+        if N:
+            S2, _ = engine.estep(c, b, W, keep_logp=True, keep_resp=True)
+            assert rel_err(engine.get_logp(K), L) < 1e-12 and rel_err(engine.get_resp(K), R) < 1e-10
+            assert np.abs(S2.sxx - dsxx).max() <= 1e-11 * scale
+            lab, S3 = engine.gibbs_labels(c, b, W, seed=3, sweep=9)
+            ref = O.sample_discrete_from_log(L, O.philox_uniforms(3, np.arange(N), 9))
+            assert np.array_equal(lab, ref) and np.array_equal(S3.n, np.bincount(ref, minlength=K))
+            Sw = engine.weighted_stats(R)
+            assert np.abs(Sw.sxx - dsxx).max() <= 1e-11 * scale
+            with pytest.raises((RuntimeError, ValueError)):
+                engine.estep(c, b, Wf)                       # off-diagonal entries under the diagonal structure
+    finally:
+        engine.set_structure('full')
+    if N:
+        S4, _ = engine.estep(c, b, W)                        # same W through the full feature map
+        assert np.abs(S4.sxx - sxx).max() <= 1e-11 * scale
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the

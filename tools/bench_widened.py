@@ -73,10 +73,12 @@ report("tied-covariance GMM, mean-field VI", t, N * K, N * K * (FE + FS))
 prior = StackedNormalGammas(K, D, np.zeros((K, D)), 1e-2 * np.ones((K, D)), (D + 1.) / 2. * np.ones((K, D)), 0.5 * np.ones((K, D)))
 diag = BayesianMixtureOfGaussians(gd(), StackedGaussiansWithNormalGammas(K, D, prior, engine=eng), engine=eng)
 t = per_iter(lambda it: diag.meanfield_coordinate_descent(X, randomize=False, maxiter=it, tol=0., progress_bar=False))
-report("diagonal-precision GMM, mean-field VI (runs the full-W kernels with W = diag)", t, N * K, N * K * (FE + FS),
-       "flops counted as for a full W: a diagonal feature map would need 4D+3 per evaluation")
+FEd, FSd = 2 * (2 * D + 1) + 8, 2 * (2 * D + 1) + 1      # both products over the 2D+1 features z_a^2, z_a, 1
+report("diagonal-precision GMM, mean-field VI (MIMO_STRUCT_DIAG: 2D+1 feature kernels; reference-shaped driver)", t,
+       N * K, N * K * (FEd + FSd), "flops of the diagonal form: 2(2D+1)+8 and 2(2D+1)+1 per evaluation; the iteration "
+       "includes ~1 ms of host posterior.rvs()")
 t = per_iter(lambda it: diag.resample(X, maxiter=it, progress_bar=False, label_rng='philox', seed=1))
-report("diagonal-precision GMM, Gibbs sweep (Philox labels)", t, N * K, N * K * FE + N * FS)
+report("diagonal-precision GMM, Gibbs sweep (Philox labels)", t, N * K, N * K * FEd + N * FSd)
 
 hyper = NormalWishart(D, np.zeros(D), 1e-2, np.eye(D), D + 2.)
 hp = TiedGaussiansWithScaledPrecision(K, D, kappas=1e-2 * np.ones(K))
