@@ -132,20 +132,23 @@ static int bind(mimo_ctx* ctx) {
 }
 
 // feature table for dimension D: pairs (a,b), a <= b <= D over z~ = [z, 1]; padding -> (D+1,D+1)
-static int fidx(const mimo_ctx* ctx, int a, int b) {
-  return ctx->structure ? diag_feat_index(ctx->D, a, b) : feat_index(ctx->D, a, b);
+static int fidx(const mimo_ctx* ctx, int a, int b) {   // feature of the pair (a, b), a <= b <= D; -1: not in the map
+  const int D = ctx->D;
+  if (ctx->structure == MIMO_STRUCT_DIAG) return (a == b || b == D) ? diag_feat_index(D, a, b) : -1;
+  if (ctx->structure == MIMO_STRUCT_LINEAR) return b == D ? a : -1;
+  return feat_index(D, a, b);
 }
 
 static int prepare_features(mimo_ctx* ctx, int D) {
   if (ctx->feat_D == D && ctx->feat_structure == ctx->structure) return MIMO_OK;
-  const bool diag = ctx->structure != 0;
-  ctx->F = diag ? diag_feat_count(D) : feat_count(D);
-  ctx->F16 = diag ? diag_feat_pad16(D) : feat_pad16(D);
+  const int st = ctx->structure;
+  ctx->F = st == MIMO_STRUCT_DIAG ? diag_feat_count(D) : st == MIMO_STRUCT_LINEAR ? lin_feat_count(D) : feat_count(D);
+  ctx->F16 = (ctx->F + 15) / 16 * 16;
   ctx->feat_h.assign((size_t)ctx->F16 * 2, (uint8_t)(D + 1));
   for (int a = 0; a <= D; ++a)
     for (int b = a; b <= D; ++b) {
-      if (diag && a != b && b != D) continue;
-      const int f = diag ? diag_feat_index(D, a, b) : feat_index(D, a, b);
+      const int f = fidx(ctx, a, b);
+      if (f < 0) continue;
       ctx->feat_h[2 * f] = (uint8_t)a;
       ctx->feat_h[2 * f + 1] = (uint8_t)b;
     }
@@ -207,11 +210,17 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
       img[((size_t)rb * NS + s) * 64 + kk * 16 + i] = v;
     };
     put(fidx(ctx, D, D), c[k]);
+    for (int a = 0; a < D; ++a) put(fidx(ctx, a, D), bk[a]);
+    if (ctx->structure == MIMO_STRUCT_LINEAR) {
+      // the common quadratic term stays with the caller (see mimo_set_structure); all W[k] must be one matrix
+      if (k > 0 && memcmp(Wk, W, sizeof(double) * D * D) != 0)
+        return fail(ctx, MIMO_E_INVALID, "linear structure is set (mimo_set_structure) but W[%d] differs from W[0]", k);
+      continue;
+    }
     for (int a = 0; a < D; ++a) {
-      put(fidx(ctx, a, D), bk[a]);
       put(fidx(ctx, a, a), -0.5 * Wk[a * D + a]);
       for (int bb = a + 1; bb < D; ++bb) {
-        if (!ctx->structure) put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+        if (ctx->structure == MIMO_STRUCT_FULL) put(feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
         else if (Wk[a * D + bb] != 0.0 || Wk[bb * D + a] != 0.0)
           return fail(ctx, MIMO_E_INVALID, "diagonal structure is set (mimo_set_structure) but W[%d] has the "
                       "off-diagonal entry (%d,%d)", k, a, bb);
@@ -426,7 +435,7 @@ int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
 
 int mimo_set_structure(mimo_ctx* ctx, int structure) {
   int rc = bind(ctx); if (rc) return rc;
-  if (structure != MIMO_STRUCT_FULL && structure != MIMO_STRUCT_DIAG)
+  if (structure != MIMO_STRUCT_FULL && structure != MIMO_STRUCT_DIAG && structure != MIMO_STRUCT_LINEAR)
     return fail(ctx, MIMO_E_INVALID, "mimo_set_structure: unknown structure %d", structure);
   if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
   if (ctx->structure == structure) return MIMO_OK;

@@ -44,7 +44,7 @@ struct KernelArgs {
   int cb0;                // statistics modes: first 16-wide feature column block of this launch
   int F16_total;          // padded feature count of the whole problem (partials row stride)
   int write_scalars;      // write the 4 scalar slots of the partial block (0: another launch owns them)
-  int diag;               // feature table is the diagonal one (2 Dz + 1 features): table-driven E-step kernels
+  int diag;               // feature table is a reduced one (diagonal: 2 Dz + 1, linear: Dz + 1 features): table-driven E-step kernels
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
 };
 
@@ -59,6 +59,10 @@ inline int feat_index(int D, int a, int b) {  // a <= b <= D
 inline int diag_feat_count(int D) { return 2 * D + 1; }
 inline int diag_feat_pad16(int D) { return (diag_feat_count(D) + 15) / 16 * 16; }
 inline int diag_feat_index(int D, int a, int b) { return a == D ? 2 * D : (b == D ? D + a : a); }
+// linear structure (all W_k equal: the quadratic term is common to every component and leaves the softmax):
+// only the D+1 features z_a, 1 exist — f = a for (a,D), D for (D,D)
+inline int lin_feat_count(int D) { return D + 1; }
+inline int lin_feat_pad16(int D) { return (lin_feat_count(D) + 15) / 16 * 16; }
 
 size_t fused_lds_bytes(const KernelArgs& a);
 int fused_grid(const KernelArgs& a, int num_cu, int src);

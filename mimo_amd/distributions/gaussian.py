@@ -29,6 +29,7 @@ def upper_chol(mats):
 class StackedGaussiansWithPrecision:
 
     diagonal = False
+    tied = False
 
     @staticmethod
     def block_stats(S):
@@ -123,12 +124,17 @@ class StackedGaussiansWithPrecision:
         return - self.log_partition() + self.log_base(), b, self.lmbdas
 
     # ---- O(N) methods: on the engine ----------------------------------------------------------
+    @property
+    def structure(self):
+        """Feature map the engine runs for this family (mimo_set_structure)."""
+        return 'diag' if self.diagonal else 'linear' if self.tied else 'full'
+
     def _bind(self, data):
         data = np.asarray(data, dtype=float)
         if np.isnan(data).any():
             raise ValueError("NaN rows are not supported by the HIP engine (reference drops them: "
                              "gaussian.py:493-494); filter them before calling")
-        return _engine.bind(self.engine, data.reshape(-1, self.dim), 'diag' if self.diagonal else 'full')
+        return _engine.bind(self.engine, data.reshape(-1, self.dim), self.structure)
 
     def log_likelihood(self, x):
         """(K, N) table of component log-densities (gaussian.py:510-521)."""
@@ -174,8 +180,19 @@ class StackedGaussiansWithPrecision:
 
 
 class TiedGaussiansWithPrecision(StackedGaussiansWithPrecision):
-    """K Gaussians sharing one precision matrix (gaussian.py:545-572): same E-step form (W_k all equal),
-    pooled covariance in the M-step."""
+    """K Gaussians sharing one precision matrix (gaussian.py:545-572): pooled covariance in the M-step.
+    With all W_k equal the quadratic term leaves the softmax, and every update of a tied block only uses
+    sum_k of the second-moment blocks — a constant of the data (or of the row weights).  The engine therefore
+    runs the Dz + 1 feature kernels ('linear' structure) and hands over that pooled matrix."""
+
+    tied = True
+
+    @staticmethod
+    def block_stats(S):
+        if S.sxx is None:       # 'linear' structure: K equal shares of the pooled second moment (only their sum is used)
+            K = S.n.shape[0]
+            return Stats([S.sx, S.n, np.broadcast_to(S.sxx_total / K, (K,) + S.sxx_total.shape), S.n])
+        return Stats([S.sx, S.n, S.sxx, S.n])
 
     def max_likelihood(self, data, weights=None, stats=None):
         xk, nk, xxTk, _ = stats if stats is not None else self.weighted_statistics(data, weights)

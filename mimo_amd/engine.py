@@ -19,10 +19,12 @@ from . import _lib
 class SuffStats:
     """Packed per-component statistics  n_k, sum_n r z, sum_n r z z'  (float64)."""
 
-    __slots__ = ("n", "sx", "sxx")
+    __slots__ = ("n", "sx", "sxx", "sxx_total")
 
-    def __init__(self, n, sx, sxx):
-        self.n, self.sx, self.sxx = n, sx, sxx
+    def __init__(self, n, sx, sxx, sxx_total=None):
+        # sxx is None under the 'linear' structure (one precision shared by all components): only
+        # sxx_total = sum_k sum_n r_kn z z' (= sum_n w_n z_n z_n') exists, which is all a tied update uses
+        self.n, self.sx, self.sxx, self.sxx_total = n, sx, sxx, sxx_total
 
     @staticmethod
     def from_packed(S, K, D):
@@ -82,11 +84,51 @@ class HipEngine:
         self._check(self._lib.mimo_set_row_offset(self._ctx, int(row0)))
 
     def set_structure(self, structure):
-        """'full' (symmetric W) or 'diag' (diagonal W: the 2 Dz + 1 feature kernels, mimo_set_structure)."""
-        code = {'full': 0, 'diag': 1}[structure]
+        """'full' (symmetric W), 'diag' (diagonal W: the 2 Dz + 1 feature kernels) or 'linear' (all W_k equal:
+        the Dz + 1 feature kernels; this class adds the data constants the shared quadratic term contributes,
+        see mimo_set_structure in include/mimo_hip.h)."""
+        code = {'full': 0, 'diag': 1, 'linear': 2}[structure]
         if getattr(self, '_structure', 0) != code:
             self._check(self._lib.mimo_set_structure(self._ctx, code))
             self._structure = code
+
+    # -- 'linear' structure: what the shared quadratic term -1/2 z'W z adds back -------------------
+    class _AsFull:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            self.prev = {0: 'full', 1: 'diag', 2: 'linear'}[getattr(self.eng, '_structure', 0)]
+            self.eng.set_structure('full')
+
+        def __exit__(self, *a):
+            self.eng.set_structure(self.prev)
+
+    def _xx(self, weights=None):
+        """sum_n w_n z_n z_n' (D, D): one pass with a single unit-responsibility component, full structure."""
+        with HipEngine._AsFull(self):
+            w = np.ones((1, self.N)) if weights is None else _f64(weights).reshape(1, -1)
+            return self.weighted_stats(w).sxx[0]
+
+    def _xx_total(self):
+        if getattr(self, '_xx_cache', None) is None:
+            self._xx_cache = self._xx()
+        return self._xx_cache
+
+    def _linear(self):
+        return getattr(self, '_structure', 0) == 2
+
+    def _linear_stats(self, S, total):
+        if S is not None:
+            S.sxx, S.sxx_total = None, total
+        return S
+
+    def _linear_scalars(self, sc, W0):
+        corr = - 0.5 * float(np.sum(W0 * self._xx_total()))     # sum_n -1/2 z_n'W z_n = -1/2 tr(W XX)
+        sc = np.array(sc, dtype=float)
+        sc[0] += corr
+        sc[1] += corr          # sum r l gains the same constant (sum_k r = 1); NaN stays NaN
+        return sc
 
     def profile(self, enable=True):
         self._check(self._lib.mimo_profile(self._ctx, 1 if enable else 0))
@@ -99,6 +141,7 @@ class HipEngine:
     # -- data -----------------------------------------------------------------------------
     def upload(self, Z):
         """Z: (N, Dz) float64 host array (copied once) or a CUDA/HIP torch tensor (borrowed)."""
+        self._xx_cache = None
         if hasattr(Z, "data_ptr") and getattr(Z, "is_cuda", False):
             import torch
             if Z.dtype != torch.float64 or not Z.is_contiguous() or Z.dim() != 2:
@@ -127,6 +170,19 @@ class HipEngine:
         """Fused E-step.  Returns (SuffStats | None, scalars[3]); scalars[1:] are NaN unless
         entropy_split (or a keep_* flag) is set.  `row_weights` (N,): the statistics are those of
         r_kn * w_n, tables and scalars stay unweighted (hgmm.py:199-207)."""
+        if self._linear():
+            Wa = _f64(W)
+            if keep_logp or keep_lse or not np.array_equal(Wa, np.broadcast_to(Wa[:1], Wa.shape)):
+                with HipEngine._AsFull(self):      # per-datum tables carry the quadratic term itself
+                    return self._estep(c, b, W, stats, keep_resp, keep_logp, keep_lse, entropy_split, row_weights)
+            S, sc = self._estep(c, b, W, stats, keep_resp, False, False, entropy_split, row_weights)
+            total = None
+            if stats:
+                total = self._xx_total() if row_weights is None else self._xx(row_weights)
+            return self._linear_stats(S, total), self._linear_scalars(sc, Wa[0])
+        return self._estep(c, b, W, stats, keep_resp, keep_logp, keep_lse, entropy_split, row_weights)
+
+    def _estep(self, c, b, W, stats, keep_resp, keep_logp, keep_lse, entropy_split, row_weights):
         c, b, W, K = self._params(c, b, W)
         flags = ((_lib.F_KEEP_RESP if keep_resp else 0) | (_lib.F_KEEP_LOGP if keep_logp else 0)
                  | (_lib.F_KEEP_LSE if keep_lse else 0) | (0 if stats else _lib.F_NO_STATS)
@@ -154,6 +210,13 @@ class HipEngine:
         """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
         The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs."""
         c, b, W, K = self._params(c, b, W)
+        self._async_W0 = None
+        if self._linear():
+            if not np.array_equal(W, np.broadcast_to(W[:1], W.shape)):
+                self.set_structure('full')      # not a tied block after all: stays full until the caller re-binds
+            else:
+                self._xx_total()                # (a first call runs its own pass: before the asynchronous one)
+                self._async_W0 = W[0].copy()
         self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
         self._K = K
         self._async_K = K
@@ -163,7 +226,10 @@ class HipEngine:
         S = np.empty((K, 1 + self.D + self.D * self.D))
         sc = np.empty(3)
         self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
-        return SuffStats.from_packed(S, K, self.D), sc
+        S = SuffStats.from_packed(S, K, self.D)
+        if getattr(self, '_async_W0', None) is not None:
+            return self._linear_stats(S, self._xx_total()), self._linear_scalars(sc, self._async_W0)
+        return S, sc
 
     def estep_device(self, c, b, W, S_dev_ptr, scalars_dev_ptr):
         """Asynchronous fused E-step writing packed S / scalars to device pointers."""
@@ -176,6 +242,9 @@ class HipEngine:
                      keep_logp=False):
         """Fused Gibbs label step.  Returns (labels int32 | None, SuffStats | None)."""
         c, b, W, K = self._params(c, b, W)
+        if self._linear() and (keep_logp or not np.array_equal(W, np.broadcast_to(W[:1], W.shape))):
+            with HipEngine._AsFull(self):
+                return self.gibbs_labels(c, b, W, seed, sweep, u, stats, return_labels, keep_logp)
         flags = (0 if stats else _lib.F_NO_STATS) | (_lib.F_KEEP_LOGP if keep_logp else 0)
         S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
         labels = np.empty(self.N, dtype=np.int32) if return_labels else None
@@ -188,7 +257,10 @@ class HipEngine:
             _ptr(u) if u is not None else None, flags,
             _ptr(labels) if return_labels else None, _ptr(S) if stats else None))
         self._K = K
-        return labels, (SuffStats.from_packed(S, K, self.D) if stats else None)
+        S = SuffStats.from_packed(S, K, self.D) if stats else None
+        if self._linear() and stats:      # every row carries exactly one label: the second moments add up to XX
+            S = self._linear_stats(S, self._xx_total())
+        return labels, S
 
     def gibbs_labels_device(self, c, b, W, seed, sweep, S_dev_ptr):
         c, b, W, K = self._params(c, b, W)
@@ -210,7 +282,10 @@ class HipEngine:
             p = _ptr(resp)
         S = np.empty((K, 1 + self.D + self.D * self.D))
         self._check(self._lib.mimo_weighted_stats(self._ctx, p, K, 0, _ptr(S)))
-        return SuffStats.from_packed(S, K, self.D)
+        S = SuffStats.from_packed(S, K, self.D)
+        if self._linear():     # sum_k r_kn is the weight of row n in the pooled second moment (1 for responsibilities)
+            S = self._linear_stats(S, self._xx_total() if resp is None else self._xx(np.sum(resp, axis=0)))
+        return S
 
     def label_stats(self, labels, K):
         """Statistics of hard labels (no one-hot table); labels=None reuses the resident draw."""
@@ -226,7 +301,8 @@ class HipEngine:
             p = _ptr(labels)
         S = np.empty((K, 1 + self.D + self.D * self.D))
         self._check(self._lib.mimo_label_stats(self._ctx, p, K, 0, _ptr(S)))
-        return SuffStats.from_packed(S, K, self.D)
+        S = SuffStats.from_packed(S, K, self.D)
+        return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
     def table_entropy(self, table=None):
         """-sum t log t of a (K,N) host table (None: the resident responsibilities)."""

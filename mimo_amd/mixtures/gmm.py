@@ -35,6 +35,8 @@ def _component_stats(S, components=None):
 
 def canonical_inner(c, b, W, S):
     """sum_kn r_kn l_kn = <Theta, S(r)>  for l = c + b.x - 1/2 x'Wx  and S the statistics of r."""
+    if S.sxx is None:      # 'linear' structure: one W for all components, pooled second moment
+        return float(np.sum(c * S.n) + np.sum(b * S.sx) - 0.5 * np.sum(W[0] * S.sxx_total))
     return float(np.sum(c * S.n) + np.sum(b * S.sx) - 0.5 * np.sum(W * S.sxx))
 
 
@@ -83,7 +85,7 @@ class MixtureOfGaussians:
 
     def _bind(self, obs):
         return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim),
-                            'diag' if getattr(self.components, 'diagonal', False) else 'full')
+                            getattr(self.components, 'structure', 'full'))
 
     # ---- reference-shaped table methods --------------------------------------------------------
     def log_complete_likelihood(self, obs):
@@ -172,7 +174,7 @@ class BayesianMixtureOfGaussians:
         return self.likelihood.dim
 
     def _structure(self):
-        return 'diag' if getattr(self.components.likelihood, 'diagonal', False) else 'full'
+        return getattr(self.components.likelihood, 'structure', 'full')
 
     def _bind(self, obs):
         return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim), self._structure())

@@ -44,7 +44,8 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
         return self._engine if self._engine is not None else self.components.likelihood.engine
 
     def _bind(self, obs):
-        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim))
+        return _engine.bind(self.engine, np.asarray(obs, dtype=float).reshape(-1, self.dim),
+                            self.components.likelihood.structure)
 
     def canonical_expected(self):
         c, b, W = self.components.canonical_expected()
@@ -59,7 +60,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
                 u = npr.random(size=(1, eng.N))                      # stats.py:14
                 labels, S = eng.gibbs_labels(*self.likelihood.canonical(), u=u)
                 self.gating.resample(None, counts=S.n)
-                self.components.resample(None, None, maxsubiter, stats=_component_stats(S))
+                self.components.resample(None, None, maxsubiter, stats=_component_stats(S, self.components))
                 self.labels_ = labels
                 pbar.update(1)
 
@@ -74,7 +75,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
 
     def resample_components(self, obs, labels, maxsubiter):
         eng = self._bind(obs)
-        self.components.resample(None, None, maxsubiter, stats=_component_stats(eng.label_stats(labels, self.size)))
+        self.components.resample(None, None, maxsubiter, stats=_component_stats(eng.label_stats(labels, self.size), self.components))
 
     # ---- tables ---------------------------------------------------------------------------------------
     def expected_log_complete_likelihood(self, obs):
@@ -120,7 +121,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
         return vlb
 
     def _update_from_stats(self, S, maxsubiter):
-        self.components.meanfield_update(None, None, maxsubiter, stats=_component_stats(S))
+        self.components.meanfield_update(None, None, maxsubiter, stats=_component_stats(S, self.components))
         self.gating.meanfield_update(None, S.n)
 
     def _vlb_prior_terms(self):
@@ -134,7 +135,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
 
     def meanfield_update_components(self, obs, resp, maxsubiter):
         self.components.meanfield_update(None, None, maxsubiter,
-                                         stats=_component_stats(self._bind(obs).weighted_stats(resp)))
+                                         stats=_component_stats(self._bind(obs).weighted_stats(resp), self.components))
 
     # ---- SVI (hgmm.py:231-270: full-data natural-gradient steps, no bound is recorded) ------------------
     def meanfield_stochastic_descent(self, obs, randomize=True, weights=None, maxiter=250, maxsubiter=5, scale=1,
@@ -152,7 +153,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
         return vlb
 
     def _sgd_from_stats(self, S, maxsubiter, scale, step_size):
-        self.components.meanfield_sgd(None, None, maxsubiter, scale, step_size, stats=_component_stats(S))
+        self.components.meanfield_sgd(None, None, maxsubiter, scale, step_size, stats=_component_stats(S, self.components))
         self.gating.meanfield_sgd(None, S.n, scale, step_size)
 
     def meanfield_sgd_parameters(self, obs, resp, maxsubiter, scale, step_size):

@@ -95,8 +95,10 @@ class ShardedEngine:
         return self._buf, n - 4
 
     def set_structure(self, structure):
+        """'linear' needs the pooled second moment of ALL shards: the sharded path keeps such blocks on the
+        full feature map (same results; the tied fast path is single-GPU for now)."""
         if hasattr(self.inner, 'set_structure'):
-            self.inner.set_structure(structure)
+            self.inner.set_structure('full' if structure == 'linear' else structure)
 
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):

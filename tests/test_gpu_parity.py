@@ -277,6 +277,52 @@ def test_diagonal_structure(engine, D, K, N):
         assert np.abs(S4.sxx - sxx).max() <= 1e-11 * scale
 
 
+@pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (15, 64, 20000), (8, 256, 33000), (32, 128, 9000),
+                                   (5, 7, 0)])
+def test_linear_structure_for_tied_blocks(engine, D, K, N):
+    """mimo_set_structure(MIMO_STRUCT_LINEAR): one W for all components — the Dz + 1 feature kernels plus the data
+    constants of the shared quadratic term reproduce the full-structure results: n_k, sum r z, the POOLED second
+    moment, the bound, responsibilities and labels; tables with the quadratic term fall back to the full map."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(31 * D + K)
+    Z, c, b, Wf = _random_problem(rng, max(N, 1), D, K)
+    Z = Z[:N]
+    W = np.ascontiguousarray(np.broadcast_to(Wf[:1], Wf.shape))
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0) if N else np.zeros(0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    XX = Z.T @ Z
+    w = rng.uniform(0., 2., size=N)
+    try:
+        engine.set_structure('linear')
+        engine.upload(Z)
+        S, sc = engine.estep(c, b, W)
+        scale = max(np.abs(XX).max(), 1e-300) if N else 1.0
+        assert S.sxx is None and np.abs(S.sxx_total - XX).max() <= 1e-11 * scale
+        assert np.abs(S.n - n).max() <= 1e-11 * max(n.max(), 1.0) and np.abs(S.sx - sx).max() <= 1e-11 * scale
+        assert abs(sc[0] - lse.sum()) <= 1e-11 * max(abs(lse.sum()), 1.0)
+        if N:
+            engine.estep_async(c, b, W)
+            Sa, sca = engine.estep_wait()
+            assert np.array_equal(Sa.sx, S.sx) and sca[0] == sc[0]
+            Sw, scw = engine.estep(c, b, W, row_weights=w, keep_resp=True)
+            assert rel_err(Sw.sxx_total, (Z * w[:, None]).T @ Z) < 1e-11 and abs(scw[0] - sc[0]) <= 1e-12 * abs(sc[0])
+            assert rel_err(Sw.sx, O.packed_stats(Z, R * w[None, :])[1]) < 1e-10
+            assert rel_err(engine.get_resp(K), R) < 1e-9
+            engine.estep(c, b, W, stats=False, keep_logp=True, keep_lse=True)          # full map behind the scenes
+            assert rel_err(engine.get_logp(K), L) < 1e-12 and rel_err(engine.get_lse(), lse) < 1e-12
+            lab, S3 = engine.gibbs_labels(c, b, W, seed=3, sweep=9)
+            ref = O.sample_discrete_from_log(L, O.philox_uniforms(3, np.arange(N), 9))
+            assert np.mean(lab != ref) < 1e-4                  # the common term only moves last-bit ties
+            assert np.array_equal(S3.n, np.bincount(lab, minlength=K)) and rel_err(S3.sxx_total, XX) < 1e-11
+            S4, sc4 = engine.estep(c, b, Wf)                   # not a tied block: silently the full map
+            assert S4.sxx is not None
+    finally:
+        engine.set_structure('full')
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the
