@@ -1,0 +1,49 @@
+#include "mimo_hip.h"
+#include <vector>
+#include <random>
+#include <cstdio>
+#include <cmath>
+int main() {
+  std::mt19937_64 g(1);
+  std::normal_distribution<double> nd;
+  for (int K : {1, 3, 4, 5, 64, 130}) for (int D : {1, 2, 5, 16, 32}) {
+    std::vector<double> a(K * D), b(K), c((size_t)K * D * D), d(K), mus(K * D), psis((size_t)K * D * D), nus(K), hld(K),
+        cc(K), bb(K * D), W((size_t)K * D * D), E2(K), E4(K);
+    for (int k = 0; k < K; ++k) {
+      b[k] = 1.0 + k; d[k] = 3.0 + k;
+      std::vector<double> A(D * D);
+      for (auto& v : A) v = nd(g);
+      for (int i = 0; i < D; ++i) a[k * D + i] = nd(g);
+      for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) {
+        double s = (i == j) ? D + 1.0 : 0.0;
+        for (int l = 0; l < D; ++l) s += A[i * D + l] * A[j * D + l];
+        c[((size_t)k * D + i) * D + j] = s + a[k * D + i] * a[k * D + j] / b[k];
+      }
+    }
+    int rc = mimo_host_nw_vi(K, D, a.data(), b.data(), c.data(), d.data(), mus.data(), psis.data(), nus.data(), hld.data(),
+                             cc.data(), bb.data(), W.data(), E2.data(), E4.data());
+    if (rc != 0 || !std::isfinite(cc[K - 1])) { printf("nw K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    // matrix-normal-Wishart: dy x dc blocks
+    int dy = D > 8 ? 8 : D, dc = (D > 9 ? 9 : D) + 1;
+    for (int affine : {0, 1}) {
+      std::vector<double> ma((size_t)K * dy * dc), mb((size_t)K * dc * dc), mc((size_t)K * dy * dy), md(K), Ms((size_t)K * dy * dc),
+          mp((size_t)K * dy * dy), mn(K), mh(K), Kinv((size_t)K * dc * dc), e1((size_t)K * dy * dc), e2((size_t)K * dc * dc), e4(K);
+      int Dz = dc - affine + dy;
+      std::vector<double> mcc(K), mbb((size_t)K * Dz), mW((size_t)K * Dz * Dz);
+      for (int k = 0; k < K; ++k) {
+        md[k] = 2.0 + k;
+        for (int i = 0; i < dc; ++i) for (int j = 0; j < dc; ++j) mb[((size_t)k * dc + i) * dc + j] = (i == j) ? 2.0 + i : 0.1;
+        for (int i = 0; i < dy * dc; ++i) ma[(size_t)k * dy * dc + i] = 0.01 * nd(g);
+        for (int i = 0; i < dy; ++i) for (int j = 0; j < dy; ++j) mc[((size_t)k * dy + i) * dy + j] = (i == j) ? 3.0 + i : 0.2;
+      }
+      rc = mimo_host_mnw_vi(K, dy, dc, affine, ma.data(), mb.data(), mc.data(), md.data(), Ms.data(), mp.data(), mn.data(),
+                            mh.data(), Kinv.data(), mcc.data(), mbb.data(), mW.data(), e1.data(), e2.data(), e4.data());
+      if (rc != 0 && dc >= 2) { printf("mnw K=%d dy=%d dc=%d affine=%d rc=%d\n", K, dy, dc, affine, rc); return 1; }
+    }
+  }
+  // a block that is not positive definite must come back as an error, not as a crash
+  double a1[2] = {0, 0}, b1[1] = {1}, c1[4] = {1, 2, 2, 1}, d1[1] = {3}, o[64];
+  int rc = mimo_host_nw_vi(1, 2, a1, b1, c1, d1, o, o + 2, o + 6, o + 7, o + 8, o + 9, o + 11, o + 15, o + 16);
+  printf("non-SPD rc=%d (expected negative)\nsanitizer run ok\n", rc);
+  return rc < 0 ? 0 : 1;
+}
