@@ -10,4 +10,6 @@ from .bayesian import (CategoricalWithDirichlet, CategoricalWithStickBreaking,
                        TiedGaussiansWithNormalWisharts, TiedLinearGaussiansWithMatrixNormalWisharts,
                        StackedGaussiansWithNormalGammas, TiedGaussiansWithNormalGammas)
 from .hierarchical import (NormalWishart, TiedGaussiansWithScaledPrecision,
-                           TiedGaussiansWithHierarchicalNormalWisharts)
+                           TiedGaussiansWithHierarchicalNormalWisharts, MatrixNormalWithPrecision,
+                           StackedAffineLinearGaussiansWithPrecision,
+                           TiedAffineLinearGaussiansWithMatrixNormalWisharts)

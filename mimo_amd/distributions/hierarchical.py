@@ -312,3 +312,243 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
         eng = self.likelihood._bind(np.reshape(x, (-1, self.dim)))
         eng.estep(*self.predictive_canonical(), stats=False, keep_logp=True)
         return eng.get_logp(self.size)
+
+
+# ---------------------------------------------------------------------------------------------
+# Hierarchical linear-Gaussian experts: one slope matrix and one output precision shared by all K
+# experts, a separate offset per expert (mimo/distributions/bayesian.py:1222-1522)
+# ---------------------------------------------------------------------------------------------
+class MatrixNormalWithPrecision:
+    """vec(A) ~ N(vec(M), (K (x) V)^-1), A of shape (row_dim, column_dim) (matrix.py:10-175)."""
+
+    def __init__(self, column_dim, row_dim, M=None, V=None, K=None):
+        self.column_dim = column_dim
+        self.row_dim = row_dim
+        f = lambda v: None if v is None else np.array(v, dtype=float)
+        self.M, self.V, self.K = f(M), f(V), f(K)
+
+    @property
+    def params(self):
+        return self.M, self.V, self.K
+
+    @params.setter
+    def params(self, values):
+        self.M, self.V, self.K = values
+
+    def mean(self):
+        return self.M
+
+    def mode(self):
+        return self.M
+
+    def rvs(self):
+        """matrix.py:122-124: one normal(row_dim * column_dim) call, Fortran-order reshape."""
+        chol_inv = sla.inv(sla.cholesky(np.kron(self.K, self.V), lower=False))
+        aux = npr.normal(size=self.row_dim * self.column_dim).dot(chol_inv.T)
+        return self.M + np.reshape(aux, (self.row_dim, self.column_dim), order='F')
+
+
+class StackedAffineLinearGaussiansWithPrecision:
+    """K experts y | x ~ N(A_k x + c_k, Lambda_k^-1) with slope and offset kept apart
+    (lingauss.py:576-744).  The engine sees the joint row z = [x, y] and the same quadratic form as the
+    affine experts of lingauss.py with A~ = [A | c]."""
+
+    affine = True
+
+    def __init__(self, size, column_dim, row_dim, As=None, cs=None, lmbdas=None, engine=None):
+        self.size = size
+        self.column_dim = column_dim
+        self.row_dim = row_dim
+        f = lambda v: None if v is None else np.array(v, dtype=float)
+        self.As, self.cs, self.lmbdas = f(As), f(cs), f(lmbdas)
+        self._engine = engine
+
+    @property
+    def engine(self):
+        from mimo_amd import engine as _engine
+        return self._engine if self._engine is not None else _engine.default_engine()
+
+    @property
+    def params(self):
+        return self.As, self.cs, self.lmbdas
+
+    @params.setter
+    def params(self, values):
+        self.As, self.cs, self.lmbdas = (np.asarray(v, dtype=float) for v in values)
+
+    @property
+    def input_dim(self):
+        return self.column_dim
+
+    @property
+    def output_dim(self):
+        return self.row_dim
+
+    @property
+    def lmbdas_chol(self):
+        return np.swapaxes(np.linalg.cholesky(self.lmbdas), -1, -2)
+
+    @property
+    def lmbdas_chol_inv(self):
+        return np.stack([sla.inv(c) for c in self.lmbdas_chol])
+
+    def predict(self, x):
+        """lingauss.py:647-649."""
+        return np.einsum('kdl,...l->k...d', self.As, x) + self.cs[:, None, :]
+
+    def log_base(self):
+        return - 0.5 * self.row_dim * np.log(2. * np.pi) * np.ones(self.size)
+
+    def canonical(self):
+        from mimo_amd.distributions.lingauss import residual_quadratic
+        aug = np.concatenate([self.As, self.cs[:, :, None]], axis=2)
+        c0, b, W = residual_quadratic(aug, self.lmbdas, True, self.column_dim)
+        logdet_half = np.sum(np.log(np.diagonal(self.lmbdas_chol, axis1=1, axis2=2)), axis=1)
+        return c0 + logdet_half + self.log_base(), b, W
+
+    def _bind(self, x, y):
+        from mimo_amd import engine as _engine
+        from mimo_amd.distributions.lingauss import joint_rows
+        x = np.asarray(x, dtype=float).reshape(-1, self.column_dim)
+        y = np.asarray(y, dtype=float).reshape(-1, self.row_dim)
+        return _engine.bind(self.engine, joint_rows(x, y))
+
+    def log_likelihood(self, x, y):
+        eng = self._bind(x, y)
+        eng.estep(*self.canonical(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    @staticmethod
+    def block_stats(S, dx):
+        """engine block over z = [x, y] -> Stats([ymk, xmk, yxTk, xxTk, yyTk, nk]) (lingauss.py:700-715)."""
+        return Stats([S.sx[:, dx:], S.sx[:, :dx], S.sxx[:, dx:, :dx], S.sxx[:, :dx, :dx], S.sxx[:, dx:, dx:], S.n])
+
+    def weighted_statistics(self, x, y, weights):
+        eng = self._bind(x, y)
+        return self.block_stats(eng.weighted_stats(np.asarray(weights, dtype=float)), self.column_dim)
+
+
+class TiedAffineLinearGaussiansWithMatrixNormalWisharts:
+    """reference: bayesian.py:1222-1522.  The reference re-contracts the data in every sub-iteration
+    (nine einsums over N, :1263-1273, :1325-1335); here the joint statistics block of the fused pass
+    (`stats=`) is read once and the sub-iterations are O(K d^3) host algebra: with c_k the current offsets,
+    sum r c c' = n_k c c',  sum r y c' = ymk c',  sum r c x' = c xmk',
+    sum r (y - c)(y - c)' = yyTk - ymk c' - c ymk' + n_k c c'."""
+
+    def __init__(self, size, column_dim, row_dim, slope_prior, offset_prior, precision_prior, likelihood=None,
+                 engine=None):
+        self.size = size
+        self.column_dim = column_dim
+        self.row_dim = row_dim
+        As = np.zeros((size, row_dim, column_dim))
+        lmbdas = np.zeros((size, row_dim, row_dim))
+        for k in range(size):
+            lmbdas[k] = precision_prior.rvs()
+            slope_prior.V = lmbdas[k]
+            As[k] = slope_prior.rvs()
+        offset_prior.lmbdas = lmbdas
+        cs = offset_prior.rvs(sizes=size * [1])
+        self.slope_prior, self.offset_prior, self.precision_prior = slope_prior, offset_prior, precision_prior
+        self.likelihood = likelihood if likelihood is not None else\
+            StackedAffineLinearGaussiansWithPrecision(size, column_dim, row_dim, As, cs, lmbdas, engine=engine)
+        self.slope_posterior = copy.deepcopy(slope_prior)
+        self.offset_posterior = copy.deepcopy(offset_prior)
+        self.precision_posterior = copy.deepcopy(precision_prior)
+
+    def _stats(self, x, y, weights, stats):
+        return stats if stats is not None else self.likelihood.weighted_statistics(x, y, weights)
+
+    def _slope_and_precision(self, cs, ymk, xmk, yxTk, xxTk, yyTk, nk):
+        """Pooled posterior of the shared slope (M, K) and precision (psi, nu) given the offsets `cs`
+        (bayesian.py:1275-1298, identical at :1337-1360)."""
+        Kn = self.size
+        M0, K0 = self.slope_prior.M, self.slope_prior.K
+        psi0, nu0 = self.precision_prior.psi, self.precision_prior.nu
+        cxTk = np.einsum('kd,kl->kdl', cs, xmk)
+        B = (M0 @ K0)[None, :, :] + yxTk - cxTk
+        Kk_inv = np.linalg.inv(K0[None, :, :] + xxTk)
+        M = np.sum(B @ Kk_inv, axis=0) / Kn
+        K = np.sum(K0[None, :, :] + xxTk, axis=0) / Kn
+        resid = yyTk - np.einsum('kd,kl->kdl', ymk, cs) - np.einsum('kd,kl->kdl', cs, ymk)\
+            + nk[:, None, None] * np.einsum('kd,kl->kdl', cs, cs)
+        dc = cs - self.offset_prior.mus
+        psi = np.linalg.inv(np.linalg.inv(psi0) + M0 @ K @ M0.T + np.sum(resid, axis=0) / Kn
+                            + np.sum(self.offset_prior.kappas[:, None, None] * np.einsum('kd,kl->kdl', dc, dc), axis=0) / Kn
+                            - np.sum(B @ Kk_inv @ np.swapaxes(B, 1, 2), axis=0) / Kn)
+        nu = np.sum(nu0 + nk + 1) / Kn
+        return M, K, psi, nu
+
+    def _offsets(self, A_k, ymk, xmk, nk):
+        kap = self.offset_prior.kappas
+        rhos = (kap[:, None] * self.offset_prior.mus + (ymk - np.einsum('kdl,kl->kd', A_k, xmk))) / (kap + nk)[:, None]
+        return rhos, kap + nk
+
+    # ---- Gibbs sampling (bayesian.py:1258-1318) ------------------------------------------------------
+    def resample(self, x, y, z=None, nb_iter=25, stats=None):
+        ymk, xmk, yxTk, xxTk, yyTk, nk = self._stats(x, y, z, stats)
+        As = cs = lmbdas = None
+        for _ in range(nb_iter):
+            cs = self.offset_posterior.rvs(sizes=self.size * [1])
+            M, K, psi, nu = self._slope_and_precision(cs, ymk, xmk, yxTk, xxTk, yyTk, nk)
+            self.slope_posterior.M, self.slope_posterior.K = M, K
+            self.precision_posterior.psi, self.precision_posterior.nu = psi, nu
+            As = np.zeros((self.size, self.row_dim, self.column_dim))
+            lmbdas = np.zeros((self.size, self.row_dim, self.row_dim))
+            for k in range(self.size):
+                lmbdas[k] = self.precision_posterior.rvs()
+                self.slope_posterior.V = lmbdas[k]
+                As[k] = self.slope_posterior.rvs()
+            self.offset_posterior.mus, self.offset_posterior.kappas = self._offsets(As, ymk, xmk, nk)
+            self.offset_posterior.lmbdas = lmbdas
+        self.likelihood.As, self.likelihood.cs, self.likelihood.lmbdas = As, cs, lmbdas
+
+    # ---- mean field (bayesian.py:1320-1385) -------------------------------------------------------------
+    def meanfield_update(self, x, y, weights=None, nb_iter=25, stats=None):
+        ymk, xmk, yxTk, xxTk, yyTk, nk = self._stats(x, y, weights, stats)
+        for _ in range(nb_iter):
+            cs = self.offset_posterior.mean()
+            M, K, psi, nu = self._slope_and_precision(cs, ymk, xmk, yxTk, xxTk, yyTk, nk)
+            self.slope_posterior.M, self.slope_posterior.K = M, K
+            self.precision_posterior.psi, self.precision_posterior.nu = psi, nu
+            lmbda = self.precision_posterior.mean()
+            self.slope_posterior.V = lmbda
+            A = self.slope_posterior.mean()
+            self.offset_posterior.mus, self.offset_posterior.kappas =\
+                self._offsets(np.broadcast_to(A, (self.size,) + A.shape), ymk, xmk, nk)
+            self.offset_posterior.lmbdas = np.stack(self.size * [lmbda])
+        A, lmbda = self.slope_posterior.mode(), self.precision_posterior.mode()
+        self.likelihood.As = np.stack(self.size * [A])
+        self.likelihood.lmbdas = np.stack(self.size * [lmbda])
+        self.likelihood.cs = self.offset_posterior.mode()
+
+    def meanfield_sgd(self, x, y, weights, nb_iter, scale, step_size, stats=None):
+        raise NotImplementedError        # bayesian.py:1387-1388
+
+    # ---- the equivalent stacked Matrix-Normal-Wishart blocks (bayesian.py:1394-1419, :1453-1476) ----------
+    def _as_mnw(self, slope, offset, precision):
+        from mimo_amd.distributions.composite import StackedMatrixNormalWisharts
+        Kn, dx, dy = self.size, self.column_dim, self.row_dim
+        Ms = np.concatenate([np.broadcast_to(slope.M, (Kn, dy, dx)), offset.mus[:, :, None]], axis=2)
+        Ks = np.zeros((Kn, dx + 1, dx + 1))
+        Ks[:, :dx, :dx] = slope.K
+        Ks[:, dx, dx] = offset.kappas
+        return StackedMatrixNormalWisharts(Kn, dx + 1, dy, Ms=Ms, Ks=Ks, psis=np.stack(Kn * [precision.psi]),
+                                           nus=np.stack(Kn * [precision.nu]).astype(float))
+
+    def prior_mnw(self):
+        return self._as_mnw(self.slope_prior, self.offset_prior, self.precision_prior)
+
+    def posterior_mnw(self):
+        return self._as_mnw(self.slope_posterior, self.offset_posterior, self.precision_posterior)
+
+    def canonical_expected(self):
+        return self.posterior_mnw().canonical_expected(affine=True)
+
+    def expected_log_likelihood(self, x, y):
+        eng = self.likelihood._bind(x, y)
+        eng.estep(*self.canonical_expected(), stats=False, keep_logp=True)
+        return eng.get_logp(self.size)
+
+    def variational_lowerbound(self):
+        post, prior = self.posterior_mnw(), self.prior_mnw()
+        return post.entropy() - post.cross_entropy(prior)

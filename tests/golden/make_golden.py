@@ -610,7 +610,78 @@ def hier_gmm_case(name, N, D, K, M, seed, iters=4, sub=3):
     print(name, "ok")
 
 
+def hier_ilr_case(name, N, dx, dy, K, seed, iters=4, sub=3):
+    """Tied-activation mixture of linear-Gaussian experts (hilr.py:79-290, bayesian.py:1222-1522; examples/hilr):
+    shared slope and output precision, per-expert offsets, hierarchical input density — seeded Gibbs sweeps, VI
+    without and with per-datum weights, tables and the bound for explicit responsibilities."""
+    from mimo.distributions import (NormalWishart, TiedGaussiansWithScaledPrecision, TiedGaussiansWithHierarchicalNormalWisharts,
+                                    MatrixNormalWithPrecision, Wishart, TiedAffineLinearGaussiansWithMatrixNormalWisharts)
+    from mimo.mixtures.hilr import BayesianMixtureOfLinearGaussiansWithTiedActivation
+    npr.seed(seed)
+    X = np.sort(npr.uniform(-6., 6., size=(N, dx)), axis=0)
+    A = npr.randn(dy, dx)
+    seg = np.minimum((X[:, 0] + 6.) / 12. * K, K - 1).astype(int)
+    offs = 4. * npr.randn(K, dy)
+    Y = X @ A.T + offs[seg] + 0.3 * npr.randn(N, dy)
+    w = np.linspace(0.25, 1., N)
+    out = dict(X=X, Y=Y, w=w, K=np.array(K), dx=np.array(dx), dy=np.array(dy), seed=np.array(seed), iters=np.array(iters),
+               sub=np.array(sub))
+
+    def build():
+        gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones((K,))))
+        bh = NormalWishart(dim=dx, mu=np.zeros((dx,)), kappa=1e-2, psi=np.eye(dx), nu=dx + 1. + 1e-8)
+        bp = TiedGaussiansWithScaledPrecision(size=K, dim=dx, kappas=1e-2 * np.ones((K,)))
+        basis = TiedGaussiansWithHierarchicalNormalWisharts(size=K, dim=dx, hyper_prior=bh, prior=bp)
+        sp = MatrixNormalWithPrecision(column_dim=dx, row_dim=dy, M=np.zeros((dy, dx)), K=1e-2 * np.eye(dx))
+        op = TiedGaussiansWithScaledPrecision(size=K, dim=dy, mus=np.zeros((K, dy)), kappas=1e-2 * np.ones((K,)))
+        pp = Wishart(dim=dy, psi=np.eye(dy), nu=dy + 1. + 1e-16)
+        models = TiedAffineLinearGaussiansWithMatrixNormalWisharts(size=K, column_dim=dx, row_dim=dy, slope_prior=sp,
+                                                                   offset_prior=op, precision_prior=pp)
+        return BayesianMixtureOfLinearGaussiansWithTiedActivation(size=K, input_dim=dx, output_dim=dy, gating=gating,
+                                                                  basis=basis, models=models)
+
+    def state(m, pre):
+        mo, ba = m.models, m.basis
+        out[pre + "_slope_M"], out[pre + "_slope_K"] = mo.slope_posterior.M, mo.slope_posterior.K
+        out[pre + "_prec_psi"], out[pre + "_prec_nu"] = mo.precision_posterior.psi, np.asarray(mo.precision_posterior.nu)
+        out[pre + "_off_mus"], out[pre + "_off_kappas"] = mo.offset_posterior.mus, mo.offset_posterior.kappas
+        out[pre + "_off_lmbdas"] = mo.offset_posterior.lmbdas
+        out[pre + "_lik_As"], out[pre + "_lik_cs"], out[pre + "_lik_lmbdas"] = mo.likelihood.As, mo.likelihood.cs, mo.likelihood.lmbdas
+        out[pre + "_basis_mus"], out[pre + "_basis_hyper_psi"] = ba.posterior.mus, ba.hyper_posterior.wishart.psi
+        out[pre + "_galphas"] = m.gating.posterior.alphas
+
+    npr.seed(seed + 1); m = build()
+    state(m, "init")
+    out["init_loglik"] = m.models.likelihood.log_likelihood(X.copy(), Y.copy())
+    npr.seed(seed + 2)
+    m.resample(X.copy(), Y.copy(), maxiter=iters, maxsubiter=sub, progress_bar=False)
+    state(m, "gibbs")
+    npr.seed(seed + 3)
+    out["vi_return"] = np.array(m.meanfield_coordinate_descent(X.copy(), Y.copy(), randomize=False, maxiter=iters, maxsubiter=sub,
+                                                               progress_bar=False))
+    state(m, "vi")
+    out["vi_models_ell"] = m.models.expected_log_likelihood(X.copy(), Y.copy())
+    out["vi_basis_ell"] = m.basis.expected_log_likelihood(X.copy())
+    out["vi_resp"] = m.expected_responsibilities(X.copy(), Y.copy())
+    out["vi_models_vlb"] = np.asarray(m.models.variational_lowerbound())
+    out["vi_vlb"] = np.asarray(m.variational_lowerbound(X.copy(), Y.copy(), out["vi_resp"]))
+    npr.seed(seed + 4)
+    m.meanfield_coordinate_descent(X.copy(), Y.copy(), randomize=True, weights=w, maxiter=iters, maxsubiter=sub, progress_bar=False)
+    state(m, "viw")
+    try:
+        m.meanfield_stochastic_descent(X.copy(), Y.copy(), randomize=False, maxiter=2, maxsubiter=2, progress_bar=False)
+        out["svi_raises"] = np.array(False)
+    except NotImplementedError:
+        out["svi_raises"] = np.array(True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hilr":
+        hier_ilr_case("hier_ilr_dx1_dy1_k3", N=300, dx=1, dy=1, K=3, seed=1356)
+        hier_ilr_case("hier_ilr_dx2_dy2_k4", N=400, dx=2, dy=2, K=4, seed=1357)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hier":
         hier_gmm_case("hier_gmm_d2_k4_m2", N=400, D=2, K=4, M=2, seed=1354)
         hier_gmm_case("hier_gmm_d3_k3_m3", N=300, D=3, K=3, M=3, seed=1355)
@@ -648,3 +719,5 @@ if __name__ == "__main__":
     diag_gmm_case("tied_diag_gmm_d4_k6", N=400, D=4, K=6, seed=1353, tied=True)
     hier_gmm_case("hier_gmm_d2_k4_m2", N=400, D=2, K=4, M=2, seed=1354)
     hier_gmm_case("hier_gmm_d3_k3_m3", N=300, D=3, K=3, M=3, seed=1355)
+    hier_ilr_case("hier_ilr_dx1_dy1_k3", N=300, dx=1, dy=1, K=3, seed=1356)
+    hier_ilr_case("hier_ilr_dx2_dy2_k4", N=400, dx=2, dy=2, K=4, seed=1357)

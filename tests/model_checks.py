@@ -2,6 +2,7 @@
 vectors of the reference.  Run on CPU with the oracle-backed test double (tests/test_host_models.py)
 and on the GPU with the real HipEngine through the C ABI (tests/test_gpu_parity.py)."""
 import numpy as np
+import pytest
 import numpy.random as npr
 
 from conftest import load_golden, rel_err, gating_of, nw_of, mnw_of
@@ -449,6 +450,70 @@ def check_hier_gmm(name, engine, tol=1e-8):
     assert rel_err(np.array(ll), g["mom_em_loglik"]) < tol
     assert rel_err(np.stack([c.components.mus for c in em.components]), g["mom_em_mus"]) < 1e-7
     assert rel_err(em.gating.probs, g["mom_em_probs"]) < 1e-7
+
+
+def check_hier_ilr(name, engine, tol=1e-7):
+    """Tied-activation mixture of linear-Gaussian experts (hilr.py:79-290, bayesian.py:1222-1522): seeded Gibbs sweeps,
+    VI without and with per-row weights, tables, bounds; the stochastic driver raises like the reference."""
+    from mimo_amd.distributions import (NormalWishart, TiedGaussiansWithScaledPrecision, Wishart,
+                                        TiedGaussiansWithHierarchicalNormalWisharts, MatrixNormalWithPrecision,
+                                        TiedAffineLinearGaussiansWithMatrixNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfLinearGaussiansWithTiedActivation
+    g = load_golden(name)
+    X, Y, w = g["X"], g["Y"], g["w"]
+    K, dx, dy, seed, iters, sub = (int(g[k]) for k in ("K", "dx", "dy", "seed", "iters", "sub"))
+
+    def build():
+        gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones((K,))))
+        bh = NormalWishart(dim=dx, mu=np.zeros((dx,)), kappa=1e-2, psi=np.eye(dx), nu=dx + 1. + 1e-8)
+        bp = TiedGaussiansWithScaledPrecision(size=K, dim=dx, kappas=1e-2 * np.ones((K,)))
+        basis = TiedGaussiansWithHierarchicalNormalWisharts(size=K, dim=dx, hyper_prior=bh, prior=bp, engine=engine)
+        sp = MatrixNormalWithPrecision(column_dim=dx, row_dim=dy, M=np.zeros((dy, dx)), K=1e-2 * np.eye(dx))
+        op = TiedGaussiansWithScaledPrecision(size=K, dim=dy, mus=np.zeros((K, dy)), kappas=1e-2 * np.ones((K,)))
+        pp = Wishart(dim=dy, psi=np.eye(dy), nu=dy + 1. + 1e-16)
+        models = TiedAffineLinearGaussiansWithMatrixNormalWisharts(size=K, column_dim=dx, row_dim=dy, slope_prior=sp,
+                                                                   offset_prior=op, precision_prior=pp, engine=engine)
+        return BayesianMixtureOfLinearGaussiansWithTiedActivation(size=K, input_dim=dx, output_dim=dy, gating=gating,
+                                                                  basis=basis, models=models, engine=engine)
+
+    def check_state(m, pre, t):
+        mo, ba = m.models, m.basis
+        pairs = [(mo.slope_posterior.M, "_slope_M"), (mo.slope_posterior.K, "_slope_K"), (mo.precision_posterior.psi, "_prec_psi"),
+                 (np.asarray(mo.precision_posterior.nu), "_prec_nu"), (mo.offset_posterior.mus, "_off_mus"),
+                 (mo.offset_posterior.kappas, "_off_kappas"), (mo.offset_posterior.lmbdas, "_off_lmbdas"),
+                 (mo.likelihood.As, "_lik_As"), (mo.likelihood.cs, "_lik_cs"), (mo.likelihood.lmbdas, "_lik_lmbdas"),
+                 (ba.posterior.mus, "_basis_mus"), (ba.hyper_posterior.wishart.psi, "_basis_hyper_psi"),
+                 (m.gating.posterior.alphas, "_galphas")]
+        for a, key in pairs:
+            assert rel_err(a, g[pre + key]) < t, (pre, key, rel_err(a, g[pre + key]))
+
+    npr.seed(seed + 1)
+    m = build()
+    check_state(m, "init", 1e-12)
+    assert rel_err(m.models.likelihood.log_likelihood(X, Y), g["init_loglik"]) < 1e-9
+    npr.seed(seed + 2)
+    m.resample(X, Y, maxiter=iters, maxsubiter=sub, progress_bar=False)
+    check_state(m, "gibbs", tol)
+    npr.seed(seed + 3)
+    assert m.meanfield_coordinate_descent(X, Y, randomize=False, maxiter=iters, maxsubiter=sub, progress_bar=False) == []
+    assert g["vi_return"].size == 0
+    check_state(m, "vi", tol)
+    assert rel_err(m.models.expected_log_likelihood(X, Y), g["vi_models_ell"]) < tol
+    assert rel_err(m.basis.expected_log_likelihood(X), g["vi_basis_ell"]) < tol
+    assert rel_err(m.expected_responsibilities(X, Y), g["vi_resp"]) < tol
+    assert rel_err(np.asarray(m.models.variational_lowerbound()), g["vi_models_vlb"]) < tol
+    assert abs(m.variational_lowerbound(X, Y, g["vi_resp"]) - float(g["vi_vlb"])) < tol * abs(float(g["vi_vlb"]))
+    npr.seed(seed + 4)
+    m.meanfield_coordinate_descent(X, Y, randomize=True, weights=w, maxiter=iters, maxsubiter=sub, progress_bar=False)
+    check_state(m, "viw", tol)
+    # the bound that comes with the fused pass equals the explicit one (same posterior, unweighted responsibilities)
+    bound = m.meanfield_coordinate_descent(X, Y, randomize=False, maxiter=2, maxsubiter=sub, progress_bar=False,
+                                           record_bound=True)
+    explicit = m.variational_lowerbound(X, Y, m.expected_responsibilities(X, Y))
+    assert len(bound) == 2 and abs(bound[-1] - explicit) < 1e-9 * abs(explicit)
+    assert bool(g["svi_raises"])
+    with pytest.raises(NotImplementedError):
+        m.meanfield_stochastic_descent(X, Y, randomize=False, maxiter=2, maxsubiter=2, progress_bar=False)
 
 
 def check_tied_ilr_prediction(name, engine, tol=1e-7):

@@ -59,6 +59,11 @@ def test_hierarchical_gmm_all_drivers(engine, name):
     mc.check_hier_gmm(name, engine)
 
 
+@pytest.mark.parametrize("name", ["hier_ilr_dx1_dy1_k3", "hier_ilr_dx2_dy2_k4"])
+def test_hierarchical_ilr_tied_activation(engine, name):
+    mc.check_hier_ilr(name, engine)
+
+
 @pytest.mark.parametrize("name", ["tied_ilr_sine_k8", "tied_ilr_dx3_dy2_k6"])
 def test_tied_ilr_flow_and_prediction(name, engine):
     mc.check_tied_ilr_prediction(name, engine)
