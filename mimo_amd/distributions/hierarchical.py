@@ -436,10 +436,11 @@ class TiedAffineLinearGaussiansWithMatrixNormalWisharts:
     sum r (y - c)(y - c)' = yyTk - ymk c' - c ymk' + n_k c c'."""
 
     def __init__(self, size, column_dim, row_dim, slope_prior, offset_prior, precision_prior, likelihood=None,
-                 engine=None):
+                 engine=None, reference_rng=True):
         self.size = size
         self.column_dim = column_dim
         self.row_dim = row_dim
+        self.reference_rng = reference_rng
         As = np.zeros((size, row_dim, column_dim))
         lmbdas = np.zeros((size, row_dim, row_dim))
         for k in range(size):
@@ -541,7 +542,19 @@ class TiedAffineLinearGaussiansWithMatrixNormalWisharts:
     def posterior_mnw(self):
         return self._as_mnw(self.slope_posterior, self.offset_posterior, self.precision_posterior)
 
+    def reference_draw(self):
+        """The reference builds a throw-away StackedLinearGaussiansWithMatrixNormalWisharts for every table of
+        expected log-densities and every predictive call (bayesian.py:1410-1413, :1503-1506); that constructor
+        initialises a likelihood from `prior.rvs()` (bayesian.py:922-926): K Wishart and K matrix-normal draws
+        from the global stream per E-step.  Drawn and discarded here (`reference_rng=True`, the default) so that
+        whatever a seeded run draws next — the random initialisation of the next inner mixture, a later Gibbs
+        sweep — sees the reference's stream."""
+        if self.reference_rng:
+            self.prior_mnw().rvs()
+
     def canonical_expected(self):
+        """One call = one `expected_log_likelihood(x, y)` of the reference (see reference_draw)."""
+        self.reference_draw()
         return self.posterior_mnw().canonical_expected(affine=True)
 
     def expected_log_likelihood(self, x, y):
@@ -552,3 +565,19 @@ class TiedAffineLinearGaussiansWithMatrixNormalWisharts:
     def variational_lowerbound(self):
         post, prior = self.posterior_mnw(), self.prior_mnw()
         return post.entropy() - post.cross_entropy(prior)
+
+    # ---- posterior predictive (bayesian.py:1478-1522, through the same equivalent blocks) -----------------
+    def predictive_blocks(self):
+        """M~_k = [M | mu_k], Q = K~_k^-1, Cc = P^-1, P = df psi, logdet P — the inputs of mimo_predict."""
+        self.reference_draw()
+        q = self.posterior_mnw()
+        P = (q.nus - self.row_dim + 1)[:, None, None] * q.psis
+        return q.Ms, np.linalg.inv(q.Ks), np.linalg.inv(P), P, np.linalg.slogdet(P)[1]
+
+    def posterior_predictive_gaussian(self, x):
+        """-> mus (K, N, dy), lmbdas (K, N, dy, dy) (bayesian.py:949-962 on the equivalent blocks)."""
+        x = np.reshape(x, (-1, self.column_dim))
+        Ms, Q, _, P, _ = self.predictive_blocks()
+        xt = np.hstack((x, np.ones((len(x), 1))))
+        cs = 1. + np.einsum('nd,kdl,nl->kn', xt, Q, xt)
+        return np.einsum('kdl,nl->knd', Ms, xt), P[:, None, :, :] / cs[:, :, None, None]

@@ -673,6 +673,46 @@ def hier_ilr_case(name, N, dx, dy, K, seed, iters=4, sub=3):
         out["svi_raises"] = np.array(False)
     except NotImplementedError:
         out["svi_raises"] = np.array(True)
+
+    # mixture of M such mixtures (hilr.py:293-609): scaled data, VI, Gibbs, prediction
+    from mimo.mixtures.hilr import BayesianMixtureOfMixtureOfLinearGaussians
+    M = 2
+    out["M"] = np.array(M)
+
+    def mom_state(mm, pre):
+        out[pre + "_galphas"] = mm.gating.posterior.alphas
+        out[pre + "_slope_M"] = np.stack([c.models.slope_posterior.M for c in mm.components])
+        out[pre + "_off_mus"] = np.stack([c.models.offset_posterior.mus for c in mm.components])
+        out[pre + "_prec_psi"] = np.stack([c.models.precision_posterior.psi for c in mm.components])
+        out[pre + "_basis_mus"] = np.stack([c.basis.posterior.mus for c in mm.components])
+        out[pre + "_inner_galphas"] = np.stack([c.gating.posterior.alphas for c in mm.components])
+
+    npr.seed(seed + 6)
+    gating = CategoricalWithDirichlet(dim=M, prior=Dirichlet(dim=M, alphas=np.ones((M,))))
+    mm = BayesianMixtureOfMixtureOfLinearGaussians(cluster_size=M, mixture_size=K, input_dim=dx, output_dim=dy, gating=gating,
+                                                   components=[build() for _ in range(M)])
+    mm.init_transform(X, Y)
+    npr.seed(seed + 7)
+    mm.meanfield_coordinate_descent(X.copy(), Y.copy(), randomize=True, maxiter=3, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    mom_state(mm, "mom_vi")
+    xx = mm.input_transform.transform(X)
+    out["mom_pred_weights"] = mm.meanfield_predictive_weights(xx)
+    out["mom_pred_activation"] = mm.meanfield_predictive_activation(X.copy())
+    mus, covars = mm.meanfield_predictive_moments(xx)
+    out["mom_pred_mus"], out["mom_pred_covars"] = mus, covars
+    for pred in ("average", "mode"):
+        mu, var, std = mm.meanfield_prediction(X.copy(), prediction=pred)
+        out[f"mom_pred_{pred}_mu"], out[f"mom_pred_{pred}_var"], out[f"mom_pred_{pred}_std"] = mu, var, std
+    out["mom_pred_average_covar"] = mm.meanfield_prediction(X.copy(), prediction='average', variance='full')[1]
+    npr.seed(seed + 8)
+    mm.resample(X.copy(), Y.copy(), init_labels='random', maxiter=2, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    mom_state(mm, "mom_gibbs")
+    try:
+        mm.meanfield_stochastic_descent(X.copy(), Y.copy(), randomize=False, maxiter=1, maxsubiter=1, maxsubsubiter=1,
+                                        batch_size=32, progress_bar=False)
+        out["mom_svi_raises"] = np.array(False)
+    except NotImplementedError:
+        out["mom_svi_raises"] = np.array(True)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "ok")
 

@@ -515,6 +515,49 @@ def check_hier_ilr(name, engine, tol=1e-7):
     with pytest.raises(NotImplementedError):
         m.meanfield_stochastic_descent(X, Y, randomize=False, maxiter=2, maxsubiter=2, progress_bar=False)
 
+    # mixture of M such mixtures (hilr.py:293-609): scaled data, VI, prediction through ONE mimo_predict, Gibbs
+    from mimo_amd.mixtures import BayesianMixtureOfMixtureOfLinearGaussians
+    M = int(g["M"])
+
+    def check_mom(mm, pre, t):
+        pairs = [(mm.gating.posterior.alphas, "_galphas"),
+                 (np.stack([c.models.slope_posterior.M for c in mm.components]), "_slope_M"),
+                 (np.stack([c.models.offset_posterior.mus for c in mm.components]), "_off_mus"),
+                 (np.stack([c.models.precision_posterior.psi for c in mm.components]), "_prec_psi"),
+                 (np.stack([c.basis.posterior.mus for c in mm.components]), "_basis_mus"),
+                 (np.stack([c.gating.posterior.alphas for c in mm.components]), "_inner_galphas")]
+        for a, key in pairs:
+            assert rel_err(a, g[pre + key]) < t, (pre, key, rel_err(a, g[pre + key]))
+
+    npr.seed(seed + 6)
+    gating = CategoricalWithDirichlet(dim=M, prior=Dirichlet(dim=M, alphas=np.ones((M,))))
+    mm = BayesianMixtureOfMixtureOfLinearGaussians(cluster_size=M, mixture_size=K, input_dim=dx, output_dim=dy, gating=gating,
+                                                   components=[build() for _ in range(M)])
+    mm.init_transform(X, Y)
+    npr.seed(seed + 7)
+    assert mm.meanfield_coordinate_descent(X, Y, randomize=True, maxiter=3, maxsubiter=2, maxsubsubiter=2,
+                                           progress_bar=False) == []
+    check_mom(mm, "mom_vi", 1e-6)
+    xx = mm.input_transform.transform(X)
+    assert rel_err(mm.meanfield_predictive_weights(xx), g["mom_pred_weights"]) < 1e-6
+    assert rel_err(mm.meanfield_predictive_activation(X), g["mom_pred_activation"]) < 1e-6
+    mus, covars = mm.meanfield_predictive_moments(xx)
+    assert rel_err(mus, g["mom_pred_mus"]) < 1e-6 and rel_err(covars, g["mom_pred_covars"]) < 1e-6
+    for pred in ("average", "mode"):
+        mu, var, std = mm.meanfield_prediction(X, prediction=pred)
+        assert rel_err(mu, g[f"mom_pred_{pred}_mu"]) < 1e-6, pred
+        assert rel_err(var, g[f"mom_pred_{pred}_var"]) < 1e-6 and rel_err(std, g[f"mom_pred_{pred}_std"]) < 1e-6, pred
+    assert rel_err(mm.meanfield_prediction(X, prediction='average', variance='full')[1], g["mom_pred_average_covar"]) < 1e-6
+    npr.seed(seed + 8)
+    mm.resample(X, Y, init_labels='random', maxiter=2, maxsubiter=2, maxsubsubiter=2, progress_bar=False)
+    check_mom(mm, "mom_gibbs", 1e-6)
+    assert bool(g["mom_svi_raises"])
+    with pytest.raises(NotImplementedError):
+        mm.meanfield_stochastic_descent(X, Y, randomize=False, maxiter=1, maxsubiter=1, maxsubsubiter=1, batch_size=32,
+                                        progress_bar=False)
+    with pytest.raises(NotImplementedError):
+        mm.likelihood.max_likelihood(X, Y)
+
 
 def check_tied_ilr_prediction(name, engine, tol=1e-7):
     """examples/ilr/evaluate_sine.py at fixture size: tied MNW experts, Gibbs -> SVI -> VI -> prediction."""
