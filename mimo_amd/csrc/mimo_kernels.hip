@@ -1291,8 +1291,14 @@ static int rbw_stats(int K16) { return K16 <= 4 ? 1 : K16 <= 8 ? 2 : 4; }
 
 static int rbw_stats(int K16);
 
-// K > 128 runs 4 row blocks per wave: 5 column blocks (160 accumulator registers) per launch, else 10
-int stats_group_ncb(int K16) { return rbw_stats(K16) == 4 ? 5 : kMaxNCB; }
+// K > 128 runs 4 row blocks per wave: 5 column blocks (160 accumulator registers) per launch; 64 < K <= 128: 6; else 10
+int stats_group_ncb(int K16) {
+  static const int knob = [] { const char* e = getenv("MIMO_STATS_GROUP"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (knob >= 1 && knob <= kMaxNCB && rbw_stats(K16) >= 2) return knob;
+  // RBW = 2 (64 < K <= 128): six column blocks keep the launch at two workgroups per CU (249 VGPRs; seven or more
+  // need a whole CU per workgroup and lose the latency hiding): C5 shape 60.8 -> 56.5 ms, measured 3..10
+  return rbw_stats(K16) == 4 ? 5 : rbw_stats(K16) == 2 ? 6 : kMaxNCB;
+}
 
 bool fused_covers(int K16, int ncb, int src) {
   if (K16 > 16 || ncb < 1 || ncb > kMaxNCB) return false;
