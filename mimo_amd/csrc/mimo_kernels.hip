@@ -941,7 +941,10 @@ template <int RBW>
 __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(const KernelArgs a) {
   constexpr int T = kTile;
   constexpr int NCBc = kChunkNCB, CF = 16 * NCBc, NSc = CF / 4;
-  constexpr int RP = RBW >= 2 ? 2 : 1, NPASS = RBW / RP, LE = NSc * RP, PF = 6;
+  #ifndef MIMO_CHUNK_RING
+#define MIMO_CHUNK_RING 6
+#endif
+  constexpr int RP = RBW >= 2 ? 2 : 1, NPASS = RBW / RP, LE = NSc * RP, PF = MIMO_CHUNK_RING;
   static_assert(LE % PF == 0, "ring slots must line up across blocks");
   extern __shared__ __align__(16) unsigned char smem[];
   double* Zs = reinterpret_cast<double*>(smem);
