@@ -522,8 +522,12 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
 // Fused tile kernel.  NCB: 16-wide feature column blocks (F16 = 16*NCB); RBW: component
 // row-blocks (16 components each) per wavefront; SRC: where the weight tile comes from.
 // ------------------------------------------------------------------------------------------
+#ifndef MIMO_RBW4_ESTEP_WGS
+#define MIMO_RBW4_ESTEP_WGS 2   // workgroups per CU the RBW = 4 E-step kernels with NCB <= 3 are compiled for
+#endif
 template <int NCB, int RBW, int MODE, int DS = 0>
-__global__ __launch_bounds__(kWG, ((RBW == 1 || (MODE <= kGeneric && NCB <= 3) || (MODE > kGeneric && RBW * NCB <= 12)) ? 2 : 1))
+__global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : (MODE <= kGeneric && NCB <= 3) ? MIMO_RBW4_ESTEP_WGS
+                                   : (MODE > kGeneric && RBW * NCB <= 12) ? 2 : 1))
 void fused_kernel(const KernelArgs a) {
   constexpr int SRC = MODE == kModeWeights ? kSrcWeights : MODE == kModeLabels ? kSrcLabels : kSrcEstep;
   // flags fold to constants in the two fast modes
