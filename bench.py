@@ -137,9 +137,19 @@ def cpu_baseline(cfg, X_host):
             threads = blas[0]["num_threads"]
     except Exception:
         pass
-    return {"value": rows * K / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
-            "sample": f"first {rows} rows of the same synthetic data, one VI sweep of the NumPy restatement of the "
-                      f"reference (E-step in 1024-row chunks + softmax + weighted_statistics), {dt:.1f} s"}
+    out = {"value": rows * K / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+           "sample": f"first {rows} rows of the same synthetic data, one VI sweep of the NumPy restatement of the "
+                     f"reference (E-step in 1024-row chunks + softmax + weighted_statistics), {dt:.1f} s"}
+    try:      # per-core figure: the same sweep with the BLAS pool limited to one thread, ~5 s
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1, user_api="blas"):
+            r1 = int(max(2048, 1024 * round(rows * 5.0 / max(dt, 1e-3) / max(threads, 1) / 1024)))
+            r1 = min(r1, len(X_host))
+            t0 = time.time(); sweep(X_host[:r1]); d1 = time.time() - t0
+        out["one_core"] = {"value": r1 * K / d1, "unit": "evals/s", "cores": 1, "sample": f"first {r1} rows, {d1:.1f} s"}
+    except Exception:
+        pass
+    return out
 
 
 def main():
