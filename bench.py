@@ -143,8 +143,8 @@ def cpu_baseline(cfg, X_host):
     try:      # per-core figure: the same sweep with the BLAS pool limited to one thread, ~5 s
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1, user_api="blas"):
-            r1 = int(max(2048, 1024 * round(rows * 5.0 / max(dt, 1e-3) / max(threads, 1) / 1024)))
-            r1 = min(r1, len(X_host))
+            t0 = time.time(); sweep(X_host[:4096]); probe = time.time() - t0
+            r1 = int(min(len(X_host), max(4096, 1024 * round(4096 * 5.0 / max(probe, 1e-4) / 1024))))
             t0 = time.time(); sweep(X_host[:r1]); d1 = time.time() - t0
         out["one_core"] = {"value": r1 * K / d1, "unit": "evals/s", "cores": 1, "sample": f"first {r1} rows, {d1:.1f} s"}
     except Exception:
