@@ -31,7 +31,6 @@ def _outer(a, b):
 # a block is not positive definite, so errors surface exactly as before).  MIMO_HOST_NATIVE=0
 # switches it off.
 # ---------------------------------------------------------------------------------------------
-import ctypes as _C
 import os as _os
 
 NATIVE_HOST = _os.environ.get("MIMO_HOST_NATIVE", "1") != "0"

@@ -9,6 +9,7 @@ both conjugate blocks need (the reference re-contracts the data in every sub-ite
 """
 import numpy as np
 import numpy.random as npr
+from scipy.special import logsumexp
 from tqdm import tqdm
 
 from mimo_amd import engine as _engine
@@ -18,7 +19,6 @@ from mimo_amd.distributions.hierarchical import StackedAffineLinearGaussiansWith
 from mimo_amd.mixtures.ilr import MixtureOfLinearGaussians, Standardizer, embed_joint
 from mimo_amd.mixtures.gmm import canonical_inner
 from mimo_amd.utils.data import batches
-from scipy.special import logsumexp
 
 
 class BayesianMixtureOfLinearGaussiansWithTiedActivation:
