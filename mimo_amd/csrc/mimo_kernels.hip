@@ -47,6 +47,22 @@
 
 namespace mimo {
 
+// Workgroup barrier with the wave's own LDS traffic drained first.  hipcc places `s_waitcnt lgkmcnt(0)` in front
+// of an s_barrier only where its memory model asks for it, and for LDS-only ordering at workgroup scope it does
+// not: LLVM assumes the LDS operations of all waves execute in ONE total order, so stores issued before the
+// barrier would be seen by loads other waves issue after it.  On gfx950 with two workgroups resident per CU that
+// does not hold: a wave signalled the loop-top barrier with its z-tile stores still queued (behind the co-resident
+// workgroup's bank-conflicted traffic), the other waves built the feature tile from the PREVIOUS tile's rows, and
+// 2-8 rows of a tile came out wrong — sporadically, only on tiles after a workgroup's first, only with two
+// workgroups per CU (found with a lane-layout experiment that made the window wide: 35 of 48 stress runs bad,
+// 0 of 120 with this wait; DESIGN.md section 4 has the story).  88 of the 179
+// kernel instantiations had such a barrier (tools/check_barrier_waits.py, a CFG dataflow over the emitted ISA,
+// now part of the CPU tests).  The explicit wait costs nothing measurable: most barriers had it already.
+__device__ __forceinline__ void wg_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 // explicit global address space: a generic pointer that went through an opaque asm loads with flat_load,
 // which also counts on lgkmcnt and would make every LDS-operand wait an L2 round trip
@@ -636,7 +652,7 @@ void fused_kernel(const KernelArgs a) {
   // feature build: thread (row = tid & 31, g = tid >> 5) produces the 2*NCB consecutive features
   // [g*2*NCB, (g+1)*2*NCB); their (a,b) byte pairs are NCB consecutive 32-bit words of the table.
   const int frow = tid & (T - 1), fgrp = tid >> 5;
-  __syncthreads();  // feature table and exp table are in LDS
+  wg_sync();  // feature table and exp table are in LDS
   uint32_t w[NCB];
   if constexpr (DS == 0) {
 #pragma unroll
@@ -649,7 +665,7 @@ void fused_kernel(const KernelArgs a) {
 #endif
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
-    __syncthreads();  // z~ tile of this step is in LDS; the previous tile's readers are done
+    wg_sync();  // z~ tile of this step is in LDS; the previous tile's readers are done
     STAMP(0);
 
     // ---- 2. feature tile (+ externally supplied weights) --------------------------------
@@ -707,7 +723,7 @@ void fused_kernel(const KernelArgs a) {
     }
     STAMP(1);
     __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+    wg_sync();
     STAMP(2);
 
     if constexpr (SRC == kSrcEstep) {
@@ -770,7 +786,7 @@ void fused_kernel(const KernelArgs a) {
         for (int e = NE; e < NEP; ++e) ring[e % PF] = theta_slice((e + PF) % NEP);   // stream padding
       }
       STAMP(3);
-      __syncthreads();
+      wg_sync();
       STAMP(4);
 
       // ---- 4. normalise over k: 8 lanes per datum, 2*K16 consecutive components per lane ----------
@@ -790,7 +806,7 @@ void fused_kernel(const KernelArgs a) {
       }
       STAMP(5);
       __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
+      wg_sync();
       STAMP(6);
     }
 
@@ -922,9 +938,9 @@ void fused_kernel(const KernelArgs a) {
   if constexpr (MODE == kFastVI || MODE == kFastGibbs) sc_lse += log(sc_prod);
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
-  __syncthreads();
+  wg_sync();
   if (lane == 0) { red[2 * wave] = sc_lse; red[2 * wave + 1] = sc_rl; }
-  __syncthreads();
+  wg_sync();
   if (tid == 0 && a.write_scalars) {
     double* Ps = a.partials + (size_t)blockIdx.x * pstride + (size_t)Kpad * FT;
     Ps[0] = (red[0] + red[2]) + (red[4] + red[6]);
@@ -989,7 +1005,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
-    __syncthreads();
+    wg_sync();
     {
       const int64_t base = n0 * D, total = N * D;
       for (int e = tid; e < T * D; e += kWG) {
@@ -1006,7 +1022,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
     for (int i = 0; i < RBW; ++i) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
 
     for (int ch = 0; ch < nchunk; ++ch) {
-      __syncthreads();   // z~ rows visible / previous chunk's MFMA reads of Ph are done
+      wg_sync();   // z~ rows visible / previous chunk's MFMA reads of Ph are done
       {
         const double* zrow = Zs + frow * ZS;
         double* prow = Ph + frow * RS + fgrp * (2 * NCBc);
@@ -1014,7 +1030,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 #pragma unroll
         for (int jj = 0; jj < 2 * NCBc; ++jj) prow[jj] = zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]];
       }
-      __syncthreads();
+      wg_sync();
       if (wave < K16) {
         const double* p0 = Ph + j * RS + q;
         const double* p1 = Ph + (16 + j) * RS + q;
@@ -1053,7 +1069,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
         }
       }
     }
-    __syncthreads();
+    wg_sync();
     __builtin_amdgcn_s_setprio(2);
     if constexpr (RBW == 1)
       normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
@@ -1065,9 +1081,9 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
   }
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
-  __syncthreads();
+  wg_sync();
   if (lane == 0) { red[2 * wave] = sc_lse; red[2 * wave + 1] = sc_rl; }
-  __syncthreads();
+  wg_sync();
   if (tid == 0) {
     double* Ps = a.partials + (size_t)blockIdx.x * ((size_t)K16 * 16 * a.F16_total + 4) + (size_t)K16 * 16 * a.F16_total;
     Ps[0] = (red[0] + red[2]) + (red[4] + red[6]);
@@ -1253,7 +1269,7 @@ __global__ void table_entropy_partials(const double* __restrict__ t, int64_t cou
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
+  wg_sync();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
