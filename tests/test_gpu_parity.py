@@ -352,3 +352,39 @@ def test_full_size_properties(engine):
     assert rel_err(Sa.sxx + Sb.sxx, S.sxx) < 1e-12 and rel_err(Sa.n + Sb.n, S.n) < 1e-12
     assert abs((sca[0] + scb[0]) - sc[0]) < 1e-12 * abs(sc[0])
     assert np.array_equal(lab_b, lab_full[half:])
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """The boundary is a C ABI: a C99 program (tests/abi_smoke.c, gcc, no C++ / Python in the loop) uploads a
+    problem, runs the fused pass and the Philox label step through include/mimo_hip.h and must reproduce the oracle."""
+    import os
+    import shutil
+    import subprocess
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_smoke")
+    build = subprocess.run([gcc, "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_smoke.c"),
+                            "-L", os.path.join(root, "mimo_amd"), "-lmimo_hip", "-Wl,-rpath," + os.path.join(root, "mimo_amd"),
+                            "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    N, D, K = 333, 5, 7
+    rng = np.random.default_rng(5)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    text = f"{N} {D} {K}\n" + "\n".join(repr(float(v)) for a in (Z, c, b, W) for v in np.ravel(a)) + "\n"
+    run = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "done" in run.stdout, run.stdout[-500:] + run.stderr[-2000:]
+    lines = run.stdout.splitlines()
+    S = np.array([float(l.split()[1]) for l in lines if l.startswith("S ")]).reshape(K, 1 + D + D * D)
+    labels = np.array([int(l.split()[1]) for l in lines if l.startswith("L ")])
+    sc0 = float([l for l in lines if l.startswith("estep_scalar0")][0].split()[1])
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0)
+    n, sx, sxx = O.packed_stats(Z, np.exp(L - lse))
+    assert rel_err(S[:, 0], n) < 1e-11 and rel_err(S[:, 1:1 + D], sx) < 1e-11
+    assert rel_err(S[:, 1 + D:].reshape(K, D, D), sxx) < 1e-11 and abs(sc0 - lse.sum()) < 1e-12 * abs(lse.sum())
+    assert np.array_equal(labels, O.sample_discrete_from_log(L, O.philox_uniforms(42, np.arange(N), 3)))
+    assert any(l.startswith("error_message") and "K must be" in l for l in lines)
