@@ -67,3 +67,80 @@ def test_two_rank_vi_matches_single_process(name):
     ref_labels, _ = eng.gibbs_labels(*model.likelihood.canonical(), seed=1337, sweep=3, stats=False)
     assert np.array_equal(np.concatenate([res[0][5], res[1][5]]), ref_labels)
     assert np.array_equal(res[0][6], np.bincount(ref_labels, minlength=int(g["K"])))
+
+
+def _worker_hier(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy.random as npr
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        from mimo_amd.sharded import ShardedEngine, shard_rows
+        from mimo_amd.distributions import (Dirichlet, CategoricalWithDirichlet, NormalWishart, TiedGaussiansWithScaledPrecision,
+                                            TiedGaussiansWithHierarchicalNormalWisharts)
+        from mimo_amd.mixtures import BayesianMixtureOfGaussiansWithHierarchicalPrior
+        g = load_golden(name)
+        X, w = g["X"], g["w"]
+        K, D, seed, iters, sub = (int(g[k]) for k in ("K", "D", "seed", "iters", "sub"))
+        lo, hi = shard_rows(len(X), rank, world)
+        eng = ShardedEngine(OracleEngine(), row_offset=lo)
+        npr.seed(seed + 1)            # identical host state on every rank
+        gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones((K,))))
+        hyper = NormalWishart(dim=D, mu=np.zeros((D,)), kappa=1e-2, psi=np.eye(D), nu=D + 1. + 1e-8)
+        prior = TiedGaussiansWithScaledPrecision(size=K, dim=D, kappas=1e-2 * np.ones((K,)))
+        comps = TiedGaussiansWithHierarchicalNormalWisharts(size=K, dim=D, hyper_prior=hyper, prior=prior, engine=eng)
+        m = BayesianMixtureOfGaussiansWithHierarchicalPrior(size=K, dim=D, gating=gating, components=comps, engine=eng)
+        # start both the sharded and the reference run from the fixture's post-Gibbs state
+        c = m.components
+        c.posterior.mus, c.posterior.kappas, c.posterior.lmbdas = g["gibbs_post_mus"], g["gibbs_post_kappas"], g["gibbs_post_lmbdas"]
+        c.hyper_posterior.params = (g["gibbs_hyper_mu"], float(g["gibbs_hyper_kappa"]), g["gibbs_hyper_psi"], float(g["gibbs_hyper_nu"]))
+        m.gating.posterior.alphas = g["gibbs_galphas"].copy()
+        Xl, wl = np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(w[lo:hi])
+        vlb = m.meanfield_coordinate_descent(Xl, randomize=False, weights=wl, maxiter=3, maxsubiter=sub, tol=0., progress_bar=False)
+        q.put((rank, np.array(vlb), c.posterior.mus.copy(), c.hyper_posterior.wishart.psi.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_weighted_hierarchical_vi_matches_single_process():
+    """Row weights and the structure hint pass through the sharded engine: a hierarchical GMM with per-row weights on
+    two ranks reproduces the single-process run (bound trace, posterior means, pooled precision)."""
+    name = "hier_gmm_d2_k4_m2"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_hier, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # single-process reference with the same host code and the oracle engine
+    import numpy.random as npr
+    from oracle_engine import OracleEngine
+    from mimo_amd.distributions import (Dirichlet, CategoricalWithDirichlet, NormalWishart, TiedGaussiansWithScaledPrecision,
+                                        TiedGaussiansWithHierarchicalNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfGaussiansWithHierarchicalPrior
+    g = load_golden(name)
+    K, D, seed, sub = (int(g[k]) for k in ("K", "D", "seed", "sub"))
+    eng = OracleEngine()
+    npr.seed(seed + 1)
+    gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones((K,))))
+    hyper = NormalWishart(dim=D, mu=np.zeros((D,)), kappa=1e-2, psi=np.eye(D), nu=D + 1. + 1e-8)
+    prior = TiedGaussiansWithScaledPrecision(size=K, dim=D, kappas=1e-2 * np.ones((K,)))
+    comps = TiedGaussiansWithHierarchicalNormalWisharts(size=K, dim=D, hyper_prior=hyper, prior=prior, engine=eng)
+    m = BayesianMixtureOfGaussiansWithHierarchicalPrior(size=K, dim=D, gating=gating, components=comps, engine=eng)
+    c = m.components
+    c.posterior.mus, c.posterior.kappas, c.posterior.lmbdas = g["gibbs_post_mus"], g["gibbs_post_kappas"], g["gibbs_post_lmbdas"]
+    c.hyper_posterior.params = (g["gibbs_hyper_mu"], float(g["gibbs_hyper_kappa"]), g["gibbs_hyper_psi"], float(g["gibbs_hyper_nu"]))
+    m.gating.posterior.alphas = g["gibbs_galphas"].copy()
+    vlb = m.meanfield_coordinate_descent(g["X"], randomize=False, weights=g["w"], maxiter=3, maxsubiter=sub, tol=0., progress_bar=False)
+    assert np.max(np.abs(res[0][1] - np.array(vlb)) / np.abs(np.array(vlb))) < 1e-10
+    assert np.allclose(res[0][2], c.posterior.mus, rtol=1e-9, atol=1e-12)
+    assert np.allclose(res[0][3], c.hyper_posterior.wishart.psi, rtol=1e-9, atol=1e-14)
