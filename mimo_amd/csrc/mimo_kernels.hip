@@ -1242,18 +1242,28 @@ __global__ __launch_bounds__(256) void predict_kernel(const PredictArgs a) {
 
 __global__ void reduce_partials(const double* __restrict__ partials, int G, int64_t stride,
                                 double* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= stride) return;
+  // 64 consecutive elements per workgroup, the G partial blocks split into 4 contiguous slices (one per wave),
+  // every slice summed in 4 interleaved chains, the slices combined in a fixed order: the association depends
+  // on G only, never on timing.  (One thread per element over all G blocks left 41 workgroups for 256 CUs:
+  // 40 us per sweep at C2; this shape: 160 workgroups.)
+  __shared__ double part[4][64];
+  const int ex = threadIdx.x & 63, gs = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + ex;
+  const int g0 = (int)((int64_t)G * gs / 4), g1 = (int)((int64_t)G * (gs + 1) / 4);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int g = 0;
-  for (; g + 3 < G; g += 4) {
-    s0 += partials[(int64_t)g * stride + e];
-    s1 += partials[(int64_t)(g + 1) * stride + e];
-    s2 += partials[(int64_t)(g + 2) * stride + e];
-    s3 += partials[(int64_t)(g + 3) * stride + e];
+  if (e < stride) {
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+      s0 += partials[(int64_t)g * stride + e];
+      s1 += partials[(int64_t)(g + 1) * stride + e];
+      s2 += partials[(int64_t)(g + 2) * stride + e];
+      s3 += partials[(int64_t)(g + 3) * stride + e];
+    }
+    for (; g < g1; ++g) s0 += partials[(int64_t)g * stride + e];
   }
-  for (; g < G; ++g) s0 += partials[(int64_t)g * stride + e];
-  out[e] = (s0 + s1) + (s2 + s3);
+  part[gs][ex] = (s0 + s1) + (s2 + s3);
+  wg_sync();
+  if (gs == 0 && e < stride) out[e] = (part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex]);
 }
 
 // partial[b] = -sum t log t over this block's grid-stride share of a table; entries that are not
@@ -1483,8 +1493,7 @@ hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t strea
 
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out,
                          hipStream_t stream) {
-  const int bs = 256;
-  hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((stride + bs - 1) / bs)), dim3(bs), 0, stream,
+  hipLaunchKernelGGL(reduce_partials, dim3((unsigned)((stride + 63) / 64)), dim3(256), 0, stream,
                      partials, G, stride, out);
   return hipGetLastError();
 }
