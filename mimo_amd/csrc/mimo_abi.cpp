@@ -76,6 +76,11 @@ static int rs_pad() {
   static const int v = [] { const char* e = getenv("MIMO_RS_PAD"); return e ? atoi(e) : 1; }();
   return v;
 }
+// weight-tile row padding (doubles); MIMO_LS_PAD overrides for bank-conflict experiments
+static int ls_pad() {
+  static const int v = [] { const char* e = getenv("MIMO_LS_PAD"); return e ? atoi(e) : 2; }();
+  return v;
+}
 #ifdef MIMO_STAMPS
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_grid = 0;
@@ -178,7 +183,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->F16_total = ctx->F16;
   a->cb0 = 0;
   a->write_scalars = 1;
-  a->LS = a->K16 * 16 + 2;
+  a->LS = a->K16 * 16 + ls_pad();
   a->feat = ctx->feat_d;
   a->row0 = ctx->row0;
   a->do_stats = 1;
