@@ -98,6 +98,26 @@ double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep) {
   return philox_uniform(seed, row, sweep);
 }
 
+// The 8 lanes that share a datum would all run the same ten Philox rounds (~20 64-bit multiplies + ~40 integer
+// instructions on the pipe the f64 MFMAs use).  Instead a wave draws, every 8th tile, the uniforms of its 8 data
+// rows for the NEXT 8 tiles of the workgroup's grid-stride walk — lane (pt = lane & 7, j = lane >> 3) holds the
+// uniform of row pt of tile t + j * stride — and each tile fetches its value with one lane exchange.  The counter
+// is still (global row, sweep): the labels are the same labels.
+struct PhiloxBatch {
+  double u = 0.0;
+  int used = 8;     // tiles consumed from the batch (8 = empty)
+};
+__device__ __forceinline__ double philox_for_tile(PhiloxBatch& pb, const KernelArgs& a, const int64_t n, const int lane,
+                                                  const int64_t tile_stride_rows) {
+  if (pb.used == 8) {     // wave-uniform
+    pb.u = philox_uniform(a.seed, (uint64_t)(a.row0 + n + (int64_t)(lane >> 3) * tile_stride_rows), a.sweep);
+    pb.used = 0;
+  }
+  const double uu = __shfl(pb.u, (pb.used << 3) | (lane & 7));
+  pb.used += 1;
+  return uu;
+}
+
 #ifdef MIMO_STAMPS
 // diagnostic build: per-wave cycle sums of the phases of the tile loop (never in the shipped library)
 #define STAMP(i)                                                                          \
@@ -218,7 +238,8 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
                                                const int64_t N, const int64_t n0, const int wave, const int lane,
                                                const bool gibbs, double* const out_logp, double* const out_resp,
                                                double* const out_lse, double& sc_lse, double& sc_rl, double& sc_prod,
-                                               int* __restrict__ labs) {
+                                               int* __restrict__ labs, PhiloxBatch& pb,
+                                               const int64_t tstride) {
         static_assert(RBW == 1, "register variant: at most 8 components per lane");
         const int pt = 8 * wave + (lane & 7), part = lane >> 3;
         const int CPP = 2 * K16, k0 = part * CPP;
@@ -333,8 +354,7 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
               sc_prod *= ctot;
             }
           }
-          const double uu = a.u ? (valid ? a.u[n] : 0.0)
-                                : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+          const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_for_tile(pb, a, n, lane, tstride);
           const double tl = uu * ctot - excl;   // threshold in this lane's local cumulative scale
           int cnt = 0;
 #pragma unroll
@@ -367,7 +387,8 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
                                                        const int lane, const bool gibbs, double* const out_logp,
                                                        double* const out_resp, double* const out_lse,
                                                        double& sc_lse, double& sc_rl, double& sc_prod,
-                                                       int* __restrict__ labs) {
+                                                       int* __restrict__ labs, PhiloxBatch& pb,
+                                                       const int64_t tstride) {
   const int pt = 8 * wave + (lane & 7), part = lane >> 3;
   const int CPP = 2 * K16, k0 = part * CPP;
   const int64_t n = n0 + pt;
@@ -496,7 +517,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
         sc_prod *= ctot;
       }
     }
-    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_for_tile(pb, a, n, lane, tstride);
     const double tl = uu * ctot - excl;
     // chunk of the crossing: j = #{ch : tl > cumulative sum at the END of chunk ch}
     int j = 0;
@@ -615,6 +636,7 @@ void fused_kernel(const KernelArgs a) {
 
   double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
   int prod_tiles = 0;
+  PhiloxBatch pbatch;
 
   // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
@@ -793,10 +815,10 @@ void fused_kernel(const KernelArgs a) {
       __builtin_amdgcn_s_setprio(2);
       if constexpr (RBW == 1)
         normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
-                                  sc_lse, sc_rl, sc_prod, labs);
+                                  sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
       else
         normalise_tile_chunked<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp,
-                                          out_lse, sc_lse, sc_rl, sc_prod, labs);
+                                          out_lse, sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
       if constexpr (MODE != kGeneric) {
         if (++prod_tiles == 64) {   // K^64 <= 256^64 = 2^512 stays inside the float64 range
           sc_lse += log(sc_prod);
@@ -987,6 +1009,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
   for (int e = tid; e < nchunk * CF * 2; e += kWG) fe[e] = e < F16 * 2 ? a.feat[e] : (uint8_t)(D + 1);
   double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
+  PhiloxBatch pbatch;
   const int frow = tid & (T - 1), fgrp = tid >> 5;   // feature build: 8 groups x 2*NCBc features per chunk
 
   // Theta stream: block bl = (chunk, pass) consumes LE slices in the order (step s, row block i2 of the
@@ -1073,10 +1096,10 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
     __builtin_amdgcn_s_setprio(2);
     if constexpr (RBW == 1)
       normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
-                                    sc_lse, sc_rl, sc_prod, labs);
+                                    sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
     else
       normalise_tile_chunked<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp,
-                                            a.lse, sc_lse, sc_rl, sc_prod, labs);
+                                            a.lse, sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
     __builtin_amdgcn_s_setprio(0);
   }
   sc_lse = wave_sum(sc_lse);
