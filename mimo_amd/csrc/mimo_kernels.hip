@@ -102,7 +102,9 @@ double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep) {
 // instructions on the pipe the f64 MFMAs use).  Instead a wave draws, every 8th tile, the uniforms of its 8 data
 // rows for the NEXT 8 tiles of the workgroup's grid-stride walk — lane (pt = lane & 7, j = lane >> 3) holds the
 // uniform of row pt of tile t + j * stride — and each tile fetches its value with one lane exchange.  The counter
-// is still (global row, sweep): the labels are the same labels.
+// is still (global row, sweep): the labels are the same labels.  Used by the K <= 64 kernels only: in the K > 64
+// kernels (RBW = 4, already at the 256-register cap) the two extra loop-carried registers pushed other loop-carried
+// values into scratch — 3.6 GB of spill writes per launch at C3 for a 4 % gain — so those draw per tile.
 struct PhiloxBatch {
   double u = 0.0;
   int used = 8;     // tiles consumed from the batch (8 = empty)
@@ -517,7 +519,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
         sc_prod *= ctot;
       }
     }
-    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_for_tile(pb, a, n, lane, tstride);
+    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
     const double tl = uu * ctot - excl;
     // chunk of the crossing: j = #{ch : tl > cumulative sum at the END of chunk ch}
     int j = 0;
