@@ -16,7 +16,7 @@ def short(name):
 
 p = find("trace", "kernel_stats.csv")
 if p:
-    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 5 --warmup 2) ==")
+    print("== rocprofv3 --kernel-trace --stats (bench.py, default --steps 10 --warmup 2) ==")
     for row in csv.DictReader(open(p)):
         print(f"{short(row['Name']):70s} calls {row['Calls']:>6s} total_ns {row['TotalDurationNs']:>14s} "
               f"avg_ns {float(row['AverageNs']):14.1f} pct {row['Percentage']}")
@@ -42,7 +42,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     acc = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(p)):
         acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    print(f"\n== PMC pass {sub} (mean per launch of mimo::fused_kernel) ==")
+    print(f"\n== PMC pass {sub} (bench.py --steps 5 --warmup 2; mean per launch of mimo::fused_kernel) ==")
     for k, cs in acc.items():
         if "fused" not in k:
             continue
