@@ -188,8 +188,7 @@ def main():
     X = make_data(N, D, K, seed=1337 + rank, device=device, ilr=(mode == "ilr"))
     torch.cuda.synchronize()
 
-    hip = HipEngine(local_rank)
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip = HipEngine(local_rank)                    # (own stream; ShardedEngine moves it onto the stream of its all-reduce)
     hip.upload(X)                                  # borrows the device tensor (no copy)
     engine = ShardedEngine(hip, row_offset=rank * N) if dist is not None else hip
     if dist is not None:

@@ -72,8 +72,9 @@ int mimo_destroy(mimo_ctx* ctx);
 /* Last error message for `ctx` (or the last context-less error when ctx == NULL). */
 const char* mimo_last_error(const mimo_ctx* ctx);
 
-/* Launch on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) instead of
- * the context's own stream.  Pass NULL to return to the context's own stream. */
+/* Launch on an existing HIP stream instead of the context's own (non-blocking) stream.  Pass NULL to return to
+ * the context's own stream — so the NULL stream itself cannot be selected: a caller that orders other work
+ * (a collective, a copy) behind these kernels passes a stream it created (mimo_amd/sharded.py does). */
 int mimo_set_stream(mimo_ctx* ctx, void* hip_stream);
 
 /* ---- data ------------------------------------------------------------------------------ */

@@ -27,11 +27,17 @@ class ShardedEngine:
         self.device = getattr(inner, "device", 0)
         self._row0 = int(row_offset)
         self._buf = None
+        self._structure = 'full'
+        self._xx_global = None
         self._nccl = dist.get_backend(group) == "nccl"
         self._device_path = hasattr(inner, "estep_device") and self._nccl
         if self._device_path:
+            # kernel -> all-reduce -> copy to pinned memory are ordered by ONE stream of this object's own: torch's
+            # current stream may be the null stream, whose handle (0) means "the context's private stream" to
+            # mimo_set_stream — the collective would then not wait for the kernels
             import torch
-            inner.set_stream(torch.cuda.current_stream().cuda_stream)
+            self._stream = torch.cuda.Stream(device=self.device)
+            inner.set_stream(self._stream.cuda_stream)
 
     # ---- pass-throughs ---------------------------------------------------------------------------
     @property
@@ -46,6 +52,7 @@ class ShardedEngine:
         """Bind this rank's row block."""
         self.inner.upload(Z_local)
         self.inner.set_row_offset(self._row0)
+        self._xx_global = None
 
     def set_row_offset(self, row0):
         self._row0 = int(row0)
@@ -82,23 +89,67 @@ class ShardedEngine:
 
     def _allreduce_host(self, S, extra):
         K, D = S.sx.shape
+        if S.sxx is None:      # 'linear' structure: n, sum r z and the pooled second moment of the local rows
+            m = K * (1 + D)
+            out = self._allreduce_array(np.concatenate([S.n, S.sx.ravel(), np.asarray(S.sxx_total, dtype=float).ravel(),
+                                                        np.asarray(extra, dtype=float)]))
+            return (SuffStats(out[:K].copy(), out[K:m].reshape(K, D).copy(), None, out[m:m + D * D].reshape(D, D).copy()),
+                    out[m + D * D:])
         out = self._allreduce_array(np.concatenate([S.packed().ravel(), np.asarray(extra, dtype=float)]))
         return SuffStats.from_packed(out[:K * (1 + D + D * D)], K, D), out[K * (1 + D + D * D):]
+
+    # ---- 'linear' structure (one precision for all components) on the device path ---------------------------
+    def _linear(self):
+        return self._structure == 'linear'
+
+    def _tied(self, W):
+        W = np.asarray(W)
+        return np.array_equal(W, np.broadcast_to(W[:1], W.shape))
+
+    def _global_xx(self):
+        """sum_n z_n z_n' over the rows of ALL ranks: one extra all-reduce of Dz^2 numbers per data set."""
+        if self._xx_global is None:
+            self._xx_global = self._allreduce_array(self.inner._xx_total())
+        return self._xx_global
+
+    def _linear_finish(self, S, sc, W0):
+        """What HipEngine adds on one GPU (engine.py, _linear_stats / _linear_scalars), with the pooled moment of
+        all shards: the packed block the kernels reduced carries zeros in its second-moment columns."""
+        xx = self._global_xx()
+        S.sxx, S.sxx_total = None, xx
+        if sc is not None:
+            corr = - 0.5 * float(np.sum(W0 * xx))
+            sc[0] += corr
+            sc[1] += corr
+        return S, sc
 
     def _device_buffer(self, K):
         import torch
         D = self.inner.D
         n = K * (1 + D + D * D) + 4
         if self._buf is None or self._buf.numel() != n:
-            self._buf = torch.zeros(n, dtype=torch.float64, device=f"cuda:{self.device}")
+            self._stream.synchronize()             # the previous buffer may still be in flight
+            with torch.cuda.stream(self._stream):
+                self._buf = torch.zeros(n, dtype=torch.float64, device=f"cuda:{self.device}")
             self._host = torch.empty(n, dtype=torch.float64).pin_memory()
         return self._buf, n - 4
 
+    def _reduce_to_host(self, buf, wait=True):
+        """All-reduce the device block and bring it to pinned host memory, behind the kernels on this object's stream."""
+        import torch
+        with torch.cuda.stream(self._stream):
+            self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._host.copy_(buf, non_blocking=True)
+        if wait:
+            self._stream.synchronize()
+
     def set_structure(self, structure):
-        """'linear' needs the pooled second moment of ALL shards: the sharded path keeps such blocks on the
-        full feature map (same results; the tied fast path is single-GPU for now)."""
+        """Forwarded to every shard.  Under 'linear' the pooled second moment and the constant the shared quadratic
+        term adds to the bound are sums over rows like everything else: the host route all-reduces what the inner
+        engine returns for its rows, the device route adds them after the all-reduce (`_linear_finish`)."""
+        self._structure = structure
         if hasattr(self.inner, 'set_structure'):
-            self.inner.set_structure('full' if structure == 'linear' else structure)
+            self.inner.set_structure(structure)
 
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):
@@ -107,14 +158,18 @@ class ShardedEngine:
             S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
                                      entropy_split=entropy_split, row_weights=row_weights)
             return self._allreduce_host(S, sc) if stats else (None, self._allreduce_scalars(sc))
-        if self._device_path and stats and not (keep_resp or keep_logp or keep_lse or entropy_split):
+        linear = self._linear()
+        if self._device_path and stats and not (keep_resp or keep_logp or keep_lse or entropy_split) \
+                and (not linear or self._tied(W)):
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)
+            if linear:
+                self._global_xx()       # (a first call runs its own pass and all-reduce)
             self.inner.estep_device(c, b, W, buf.data_ptr(), buf.data_ptr() + 8 * slen)
-            self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
-            self._host.copy_(buf, non_blocking=False)
+            self._reduce_to_host(buf)
             out = self._host.numpy()
-            return SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
+            S, sc = SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
+            return self._linear_finish(S, sc, np.asarray(W, dtype=float)[0]) if linear else (S, sc)
         S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
                                  entropy_split=entropy_split)
         if not stats:
@@ -125,37 +180,47 @@ class ShardedEngine:
     def estep_async(self, c, b, W):
         """Enqueue the fused pass, the RCCL all-reduce of the statistic block and its copy to pinned host
         memory on the shared stream; estep_wait() synchronises.  Host work in between overlaps all three."""
-        if not self._device_path:
+        if not self._device_path or (self._linear() and not self._tied(W)):
             self._pending = self.estep(c, b, W)
+            self._pending_sync = True
             return
         import torch
         K = np.asarray(c).shape[0]
         buf, slen = self._device_buffer(K)
+        W0 = None
+        if self._linear():
+            self._global_xx()
+            W0 = np.array(np.asarray(W, dtype=float)[0])
         self.inner.estep_device(c, b, W, buf.data_ptr(), buf.data_ptr() + 8 * slen)
-        self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
-        self._host.copy_(buf, non_blocking=True)
-        self._pending = (K, slen, torch.cuda.current_stream())
+        self._reduce_to_host(buf, wait=False)
+        self._pending = (K, slen, self._stream, W0)
+        self._pending_sync = False
 
     def estep_wait(self):
         p, self._pending = self._pending, None
-        if not self._device_path:
+        if self._pending_sync:
             return p
-        K, slen, stream = p
+        K, slen, stream, W0 = p
         stream.synchronize()
         out = self._host.numpy()
-        return SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
+        S, sc = SuffStats.from_packed(out[:slen], K, self.inner.D), out[slen:slen + 3].copy()
+        return (S, sc) if W0 is None else self._linear_finish(S, sc, W0)
 
     def _allreduce_scalars(self, sc):
         return self._allreduce_array(np.array(sc, dtype=float))
 
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
-        if self._device_path and stats and u is None and not return_labels and not keep_logp:
+        linear = self._linear()
+        if self._device_path and stats and u is None and not return_labels and not keep_logp \
+                and (not linear or self._tied(W)):
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)
+            if linear:
+                self._global_xx()
             self.inner.gibbs_labels_device(c, b, W, seed, sweep, buf.data_ptr())
-            self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
-            self._host.copy_(buf, non_blocking=False)
-            return None, SuffStats.from_packed(self._host.numpy()[:slen], K, self.inner.D)
+            self._reduce_to_host(buf)
+            S = SuffStats.from_packed(self._host.numpy()[:slen], K, self.inner.D)
+            return None, (self._linear_finish(S, None, None)[0] if linear else S)
         labels, S = self.inner.gibbs_labels(c, b, W, seed=seed, sweep=sweep, u=u, stats=stats,
                                             return_labels=return_labels, keep_logp=keep_logp)
         if S is not None:

@@ -35,11 +35,20 @@ class OracleEngine:
         pass
 
     def set_structure(self, structure):
-        self.structure = structure      # (the double always computes the full block; diagonal callers read its diagonal)
+        # the double always computes the full block (diagonal callers read its diagonal); under 'linear' it hands
+        # back what HipEngine does for tied blocks: no per-component second moments, only their pooled sum
+        self.structure = structure
 
-    def _stats(self, R):
+    def _tied(self, W):
+        W = np.asarray(W)
+        return getattr(self, 'structure', 'full') == 'linear' and np.array_equal(W, np.broadcast_to(W[:1], W.shape))
+
+    def _xx_total(self):
+        return self.Z.T @ self.Z
+
+    def _stats(self, R, pooled=False):
         n, sx, sxx = O.packed_stats(self.Z, R)
-        return SuffStats(n, sx, sxx)
+        return SuffStats(n, sx, None, np.sum(sxx, axis=0)) if pooled else SuffStats(n, sx, sxx)
 
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):
@@ -56,7 +65,7 @@ class OracleEngine:
         srl = float(np.sum(R * L))
         sc = np.array([float(np.sum(lse)), srl, float(np.sum(lse)) - srl])
         Rw = R if row_weights is None else R * np.asarray(row_weights, float).reshape(1, -1)
-        return (self._stats(Rw) if stats else None), sc
+        return (self._stats(Rw, self._tied(W) and not (keep_logp or keep_lse)) if stats else None), sc
 
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
         L = O.canonical_eval(self.Z, np.asarray(c, float), np.asarray(b, float), np.asarray(W, float))
@@ -66,17 +75,17 @@ class OracleEngine:
         self._labels, self._K = labels, L.shape[0]
         if keep_logp:
             self._logp = L
-        S = self._stats(O.one_hot(labels, L.shape[0])) if stats else None
+        S = self._stats(O.one_hot(labels, L.shape[0]), self._tied(W) and not keep_logp) if stats else None
         return (labels if return_labels else None), S
 
     def weighted_stats(self, resp=None, K=None):
-        return self._stats(self._resp if resp is None else np.asarray(resp, float))
+        return self._stats(self._resp if resp is None else np.asarray(resp, float), getattr(self, 'structure', 'full') == 'linear')
 
     def label_stats(self, labels, K):
         labels = self._labels if labels is None else np.asarray(labels).astype(int)
         if labels.size and (labels.min() < 0 or labels.max() >= K):
             raise ValueError("labels out of range")
-        return self._stats(O.one_hot(labels, K))
+        return self._stats(O.one_hot(labels, K), getattr(self, 'structure', 'full') == 'linear')
 
     def table_entropy(self, table=None):
         t = self._resp if table is None else np.asarray(table, float)

@@ -328,6 +328,57 @@ def test_linear_structure_for_tied_blocks(engine, D, K, N):
         engine.set_structure('full')
 
 
+def test_sharded_device_route_over_one_rank_rccl(engine):
+    """ShardedEngine on the GPU: the statistic block goes kernel -> device buffer -> RCCL all-reduce -> pinned host
+    memory.  With a one-rank group the result must equal the plain engine's, for the full and the 'linear' structure,
+    synchronous, asynchronous and for the Gibbs step (the two-rank arithmetic is covered on CPU in test_sharded_gloo)."""
+    import torch
+    import torch.distributed as dist
+    from mimo_amd.sharded import ShardedEngine
+    from mimo_amd.engine import HipEngine
+    rng = np.random.default_rng(77)
+    N, D, K = 50000, 16, 64
+    Z, c, b, Wf = _random_problem(rng, N, D, K)
+    Wt = np.ascontiguousarray(np.broadcast_to(Wf[:1], Wf.shape))
+    engine.upload(Z)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda:0"))
+    try:
+        sh = ShardedEngine(HipEngine(0), row_offset=0)
+        assert sh._device_path
+        sh.upload(Z)
+        for structure, W in (("full", Wf), ("linear", Wt), ("linear", Wf)):
+            try:
+                engine.set_structure(structure)
+                sh.set_structure(structure)
+                S0, sc0 = engine.estep(c, b, W)
+                S1, sc1 = sh.estep(c, b, W)
+                sh.estep_async(c, b, W)
+                S2, sc2 = sh.estep_wait()
+                for S, sc in ((S1, sc1), (S2, sc2)):
+                    assert np.array_equal(S.n, S0.n) and np.array_equal(S.sx, S0.sx) and sc[0] == sc0[0]
+                    if S0.sxx is None:
+                        assert S.sxx is None and np.array_equal(S.sxx_total, S0.sxx_total)
+                    else:
+                        assert np.array_equal(S.sxx, S0.sxx)
+                _, G0 = engine.gibbs_labels(c, b, W, seed=5, sweep=2, return_labels=False)
+                _, G1 = sh.gibbs_labels(c, b, W, seed=5, sweep=2, return_labels=False)
+                assert np.array_equal(G0.n, G1.n) and np.array_equal(G0.sx, G1.sx)
+                if G0.sxx is None:
+                    assert G1.sxx is None and np.array_equal(G1.sxx_total, G0.sxx_total)
+                else:
+                    assert np.array_equal(G0.sxx, G1.sxx)
+            finally:
+                engine.set_structure('full')
+                sh.set_structure('full')
+        sh.inner.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the

@@ -101,7 +101,9 @@ def _worker_hier(rank, world, port, name, q):
         m.gating.posterior.alphas = g["gibbs_galphas"].copy()
         Xl, wl = np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(w[lo:hi])
         vlb = m.meanfield_coordinate_descent(Xl, randomize=False, weights=wl, maxiter=3, maxsubiter=sub, tol=0., progress_bar=False)
-        q.put((rank, np.array(vlb), c.posterior.mus.copy(), c.hyper_posterior.wishart.psi.copy()))
+        S, _ = eng.estep(*m.canonical_expected())
+        q.put((rank, np.array(vlb), c.posterior.mus.copy(), c.hyper_posterior.wishart.psi.copy(), eng._structure,
+               S.sxx is None, S.sxx_total.copy()))
     finally:
         dist.destroy_process_group()
 
@@ -121,6 +123,9 @@ def test_two_rank_weighted_hierarchical_vi_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # tied blocks travel on the 'linear' structure: no per-component second moments, the pooled one summed over the shards
+    assert res[0][4] == 'linear' and res[0][5] and np.array_equal(res[0][6], res[1][6])
+    assert np.allclose(res[0][6], load_golden(name)["X"].T @ load_golden(name)["X"], rtol=1e-12)
     # single-process reference with the same host code and the oracle engine
     import numpy.random as npr
     from oracle_engine import OracleEngine
