@@ -48,7 +48,15 @@ def mnw_of(g, prefix):
 
 
 @pytest.fixture(scope="session")
-def engine():
-    """One HIP engine for the whole GPU session (fails loudly if the library / GPU is missing)."""
+def _session_engine():
     from mimo_amd.engine import HipEngine
     return HipEngine(0)
+
+
+@pytest.fixture
+def engine(_session_engine):
+    """One HIP engine for the whole GPU session (fails loudly if the library / GPU is missing).  The structure hint
+    is engine state (a tied model leaves it at 'linear'): every test starts from the full feature map."""
+    _session_engine.set_structure('full')
+    _session_engine.set_row_offset(0)
+    return _session_engine
