@@ -275,20 +275,20 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
     g_stamps = stamps_d; g_stamps_grid = grid;
   }
 #endif
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct EventPair {      // destroyed on every early return; handed to ctx->pending once both are recorded
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  } ev;
   if (ctx->prof) {
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    HIP_TRY(ctx, hipEventCreate(&ev.e0));
+    HIP_TRY(ctx, hipEventCreate(&ev.e1));
+    HIP_TRY(ctx, hipEventRecord(ev.e0, ctx->stream));
   }
   const int ncb_total = a.F16 / 16;
   if (fused_covers(a.K16, ncb_total, src)) {
     bool unsupported = false;
     hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
-    if (unsupported) {
-      if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-      return fail(ctx, MIMO_E_UNSUPPORTED, "no fused kernel for K=%d, Dz=%d", K, D);
-    }
+    if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no fused kernel for K=%d, Dz=%d", K, D);
     HIP_TRY(ctx, he);
   } else {
     // two-stage path: chunked E-step writes responsibilities / labels, then the statistics kernel
@@ -324,8 +324,9 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
     }
   }
   if (ctx->prof) {
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->pending.emplace_back(e0, e1);
+    HIP_TRY(ctx, hipEventRecord(ev.e1, ctx->stream));
+    ctx->pending.emplace_back(ev.e0, ev.e1);
+    ev.e0 = ev.e1 = nullptr;
   }
   const bool async = (flags & MIMO_F_ASYNC) != 0;
   const bool want_stats = a.do_stats && (S || async);
