@@ -141,16 +141,20 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// exp(x) for x <= 0 in 9 float64 pipe operations + 6 integer ones (the f64 VALU shares its pipe with the
+// exp(x) for x <= 0 in 10 float64 pipe operations + 4 integer ones (the f64 VALU shares its pipe with the
 // f64 MFMA on gfx950 and the normalise phase is bound by its instruction count, so every instruction of
 // the softmax is paid in matrix issue slots):
 //   n = rint(x * 64/ln2) via the 1.5*2^52 trick, r = x - n ln2/64 in ONE fma (|r| <= ln2/128),
 //   exp(x) = 2^(n>>6) * tab[n & 63] * (1 + r + ... + r^5/120),  tab[j] = 2^(j/64) in LDS.
 // The single-constant reduction leaves an error of |n| * 1.2e-18 in r, i.e. a relative error of
 // 1.1e-16 * |x| in the result — an ABSOLUTE error below 4e-17 for every x <= 0 (max of |x| e^x), which is
-// what a sum of exponentials whose largest term is 1 sees.  x < -700 (exp < 1e-304) returns a denormal
-// below 1e-308 (only the high word is cleared) — zero for every purpose here.
+// what a sum of exponentials whose largest term is 1 sees.  The argument is clamped at -707 (also -inf and the
+// -1e300 of padding components): everything below returns exp(-707) = 8e-308, the smallest value whose exponent
+// field the integer add below cannot underflow — zero for every purpose here (sums whose largest term is 1), and
+// one v_max_f64 instead of a 64-bit compare and two selects per element.  The shift by 6 goes through an opaque
+// asm: LLVM otherwise rewrites ((n >> 6) << 20) + hi as shift, mask and a 64-bit add (3 instructions for 2).
 __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
+  x = fmax(x, -707.0);
   const double t = fma(x, 92.33248261689366, 6755399441055744.0);
   const int n = __double2loint(t);
   const double nf = t - 6755399441055744.0;
@@ -160,10 +164,9 @@ __device__ inline double exp_nonpos(double x, const double* __restrict__ tab) {
   q = fma(r, q, 0.5);
   q = fma(r, q, 1.0);
   const double e = tab[n & 63] * fma(r, q, 1.0);
-  // x < -700 (also -inf and the -1e300 of padding components) tested on the high word with an integer
-  // compare — not an f64 pipe slot: for x <= 0 the bit pattern grows with |x|; hi(-700.0) = 0xC085E000
-  const int hi = (unsigned)__double2hiint(x) > 0xC085E000u ? 0 : __double2hiint(e) + ((n >> 6) << 20);
-  return __hiloint2double(hi, __double2loint(e));
+  int n6;
+  asm("v_ashrrev_i32 %0, 6, %1" : "=v"(n6) : "v"(n));
+  return __hiloint2double(__double2hiint(e) + (n6 << 20), __double2loint(e));
 }
 
 // ------------------------------------------------------------------------------------------
