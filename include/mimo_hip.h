@@ -231,6 +231,21 @@ int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const d
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4);
 
+/* Gibbs draw of K Normal-Wishart posteriors and the canonical form of the drawn Gaussians, in one call.  Replaces
+ * per sweep: StackedNormalWisharts.rvs (composite.py:82-86) = K x Wishart.rvs (Bartlett, wishart.py:72-92) +
+ * K x GaussianWithPrecision.rvs (gaussian.py:311-313, two more Cholesky factorisations each), and the log-partition /
+ * canonical form of the refreshed likelihood (gaussian.py:352-354, 510-521).  The random variates come from the
+ * caller (any generator), so this routine is deterministic:
+ *   in : mus (K,D), kappas (K), psis (K,D,D) — standard parameters of the posterior;
+ *        z (K, D(D-1)/2) standard normals = strict lower triangle of the Bartlett factor in the order of
+ *        numpy.tril_indices(D, -1); g (K,D) = sqrt of chi-square(nu_k - i) draws (its diagonal); eps (K,D) standard normals
+ *   out: mu (K,D), lmbda (K,D,D) — the draw: Lambda = T T' with T = chol(psi) A, mu = m + (sqrt(kappa) T)^-T eps;
+ *        c (K), b (K,D) — log N(x; mu, Lambda^-1) = c + b.x - 1/2 x'Lambda x  (W = lmbda).
+ * MIMO_E_INVALID if a psi_k is not positive definite. */
+int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, const double* psis,
+                       const double* z, const double* g, const double* eps,
+                       double* out_mu, double* out_lmbda, double* out_c, double* out_b);
+
 /* digamma used by the two routines above (recurrence + asymptotic series), for tests. */
 double mimo_host_digamma(double x);
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mimo_table_entropy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _dp]),
     "mimo_host_nw_vi": (C.c_int, [C.c_int, C.c_int] + [_vp] * 13),
     "mimo_host_mnw_vi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_vp] * 15),
+    "mimo_host_nw_gibbs": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "mimo_host_digamma": (C.c_double, [C.c_double]),
     "mimo_predict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -281,6 +281,72 @@ int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const d
   });
 }
 
+int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, const double* psis,
+                       const double* z, const double* g, const double* eps,
+                       double* out_mu, double* out_lmbda, double* out_c, double* out_b) {
+  if (K < 1 || D < 1 || D > 64) return MIMO_E_INVALID;
+  const int nt = D * (D - 1) / 2;
+  std::vector<double> Lb((size_t)D * D), Tb((size_t)D * D);
+  double* L = Lb.data();
+  double* T = Tb.data();
+  double y[64];
+  for (int k = 0; k < K; ++k) {
+    const double* psi = psis + (size_t)k * D * D;
+    // psi = L L' (lower; the upper triangle of psi is not read)
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = psi[i * D + j];
+        for (int m = 0; m < j; ++m) s -= L[i * D + m] * L[j * D + m];
+        if (i == j) {
+          if (!(s > 0.0)) return MIMO_E_INVALID;
+          L[i * D + i] = std::sqrt(s);
+        } else {
+          L[i * D + j] = s / L[j * D + j];
+        }
+      }
+    // Bartlett factor A (lower: sqrt-chi-square diagonal, standard normals below it, in the order of
+    // numpy.tril_indices(D, -1)) and T = L A: Lambda = T T', and T IS the lower Cholesky factor of Lambda
+    const double* zk = z + (size_t)k * nt;
+    const double* gk = g + (size_t)k * D;
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = L[i * D + j] * gk[j];                                   // m = j: A_jj
+        for (int m = j + 1; m <= i; ++m) s += L[i * D + m] * zk[m * (m - 1) / 2 + j];
+        T[i * D + j] = s;
+      }
+    double* lam = out_lmbda + (size_t)k * D * D;
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = 0.0;
+        for (int m = 0; m <= j; ++m) s += T[i * D + m] * T[j * D + m];
+        lam[i * D + j] = s;
+        lam[j * D + i] = s;
+      }
+    // mu = m + (sqrt(kappa) T)^-T eps  (covariance (kappa Lambda)^-1): back substitution on T'
+    const double rk = 1.0 / std::sqrt(kappas[k]);
+    const double* ek = eps + (size_t)k * D;
+    double sld = 0.0;
+    for (int i = D - 1; i >= 0; --i) {
+      double s = ek[i] * rk;
+      for (int m = i + 1; m < D; ++m) s -= T[m * D + i] * y[m];
+      y[i] = s / T[i * D + i];
+      sld += std::log(T[i * D + i]);
+    }
+    double* mu = out_mu + (size_t)k * D;
+    double* bk = out_b + (size_t)k * D;
+    for (int i = 0; i < D; ++i) mu[i] = mus[(size_t)k * D + i] + y[i];
+    double quad = 0.0;
+    for (int i = 0; i < D; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < D; ++j) s += lam[i * D + j] * mu[j];
+      bk[i] = s;
+      quad += s * mu[i];
+    }
+    out_c[k] = -0.5 * quad + sld - 0.5 * D * kLog2Pi;
+  }
+  return MIMO_OK;
+}
+
 double mimo_host_digamma(double x) { return digamma(x); }
 
 }  // extern "C"

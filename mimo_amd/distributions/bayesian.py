@@ -158,6 +158,9 @@ class StackedGaussiansWithNormalWisharts(_ConjugateBlock):
     def resample(self, data, labels=None, stats=None, rng=None):
         self._apply(stats if stats is not None else self._stats(data, labels))
         self.likelihood.params = self.posterior.rvs(rng) if rng is not None else self.posterior.rvs()
+        drawn = getattr(self.posterior, 'drawn_canonical', None)
+        if drawn is not None and hasattr(self.likelihood, 'adopt_canonical'):
+            self.likelihood.adopt_canonical(*drawn)     # (no-op unless the likelihood holds exactly this draw)
 
     def meanfield_update(self, data, weights=None, stats=None, sample=True):
         """bayesian.py:225-230.  `sample=False` skips the (numerically irrelevant for VI) refresh

@@ -144,6 +144,9 @@ class StackedNormalWisharts:
         gaussian.py:311-313): Wishart draw, then mu = m + normal(D) . chol_upper(kappa Lambda)^-T.
         With `rng` (a numpy Generator) all K draws are batched (same law, different stream)."""
         if rng is not None:
+            drawn = self._rvs_native(rng)
+            if drawn is not None:
+                return drawn
             lmbdas = wishart_rvs_batched(self.psis, self.nus, rng)
             # mu = m + L^-T eps with kappa Lambda = L L'  =>  cov = (kappa Lambda)^-1
             L = np.linalg.cholesky(self.kappas[:, None, None] * lmbdas)
@@ -156,6 +159,28 @@ class StackedNormalWisharts:
             mus.append(self.mus[k] + npr.normal(size=self.dim).dot(chol_inv.T))
             lmbdas.append(lmbda)
         return np.stack(mus, axis=0), np.stack(lmbdas, axis=0)
+
+    def _rvs_native(self, rng):
+        """mimo_host_nw_gibbs: the K Bartlett draws, the K conditional Gaussian draws and the canonical (c, b, W) of
+        the drawn Gaussians in one call — three batched Cholesky factorisations, a batched solve and ~20 NumPy calls
+        less between two label kernels.  The variates come from `rng` (one normal block, one chi-square block), the
+        law is that of the NumPy route below; `self.drawn_canonical` carries (mu, Lambda, c, b) for the likelihood
+        that receives the draw (StackedGaussiansWithNormalWisharts.resample)."""
+        lib = _native()
+        if lib is None or type(self).rvs is not StackedNormalWisharts.rvs:
+            return None
+        K, D = self.size, self.dim
+        nt = D * (D - 1) // 2
+        zz = rng.standard_normal((K, nt + D))
+        z, eps = np.ascontiguousarray(zz[:, :nt]), np.ascontiguousarray(zz[:, nt:])
+        g = np.sqrt(rng.chisquare(np.asarray(self.nus)[:, None] - np.arange(D)[None, :]))
+        mus, kappas, psis = _c64(self.mus), _c64(self.kappas), _c64(self.psis)
+        mu, lmbda, c, b = np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty((K, D))
+        if lib.mimo_host_nw_gibbs(K, D, _p(mus), _p(kappas), _p(psis), _p(z), _p(g), _p(eps),
+                                  _p(mu), _p(lmbda), _p(c), _p(b)) != 0:
+            return None       # a block that is not positive definite: the NumPy route raises as before
+        self.drawn_canonical = (mu, lmbda, c, b)
+        return mu, lmbda
 
     @property
     def base(self):

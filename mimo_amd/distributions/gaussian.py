@@ -120,8 +120,16 @@ class StackedGaussiansWithPrecision:
     # ---- canonical form for the engine --------------------------------------------------------
     def canonical(self):
         """(c, b, W) of the point-estimate log-density (Gibbs / EM form, gaussian.py:510-521)."""
+        memo = getattr(self, '_canon', None)
+        if memo is not None and memo[0] is self.mus and memo[1] is self.lmbdas:
+            return memo[2].copy(), memo[3], self.lmbdas
         b = np.einsum('kdl,kl->kd', self.lmbdas, self.mus)
         return - self.log_partition() + self.log_base(), b, self.lmbdas
+
+    def adopt_canonical(self, mus, lmbdas, c, b):
+        """(c, b) computed by whoever produced (mus, lmbdas) — the native Gibbs draw (mimo_host_nw_gibbs); kept only
+        while the parameters are these very arrays, so any later assignment falls back to the formulas above."""
+        self._canon = (mus, lmbdas, c, b) if (mus is self.mus and lmbdas is self.lmbdas) else None
 
     # ---- O(N) methods: on the engine ----------------------------------------------------------
     @property

@@ -23,6 +23,16 @@ int main() {
     int rc = mimo_host_nw_vi(K, D, a.data(), b.data(), c.data(), d.data(), mus.data(), psis.data(), nus.data(), hld.data(),
                              cc.data(), bb.data(), W.data(), E2.data(), E4.data());
     if (rc != 0 || !std::isfinite(cc[K - 1])) { printf("nw K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    {   // Gibbs draw from the posterior just computed (psis is SPD here)
+      const int nt = D * (D - 1) / 2;
+      std::vector<double> z((size_t)K * nt + 1), gg(K * D), ee(K * D), omu(K * D), olam((size_t)K * D * D), oc(K), ob(K * D);
+      for (auto& v : z) v = nd(g);
+      for (auto& v : ee) v = nd(g);
+      for (auto& v : gg) v = 0.5 + std::fabs(nd(g));
+      rc = mimo_host_nw_gibbs(K, D, mus.data(), b.data(), psis.data(), z.data(), gg.data(), ee.data(), omu.data(), olam.data(),
+                              oc.data(), ob.data());
+      if (rc != 0 || !std::isfinite(oc[K - 1])) { printf("gibbs K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    }
     // matrix-normal-Wishart: dy x dc blocks
     int dy = D > 8 ? 8 : D, dc = (D > 9 ? 9 : D) + 1;
     for (int affine : {0, 1}) {
@@ -44,6 +54,8 @@ int main() {
   // a block that is not positive definite must come back as an error, not as a crash
   double a1[2] = {0, 0}, b1[1] = {1}, c1[4] = {1, 2, 2, 1}, d1[1] = {3}, o[64];
   int rc = mimo_host_nw_vi(1, 2, a1, b1, c1, d1, o, o + 2, o + 6, o + 7, o + 8, o + 9, o + 11, o + 15, o + 16);
-  printf("non-SPD rc=%d (expected negative)\nsanitizer run ok\n", rc);
-  return rc < 0 ? 0 : 1;
+  double m1[2] = {0, 0}, k1[1] = {1}, z1[1] = {0.3}, g1[2] = {1, 1}, e1[2] = {0.1, -0.2};
+  int rc2 = mimo_host_nw_gibbs(1, 2, m1, k1, c1, z1, g1, e1, o, o + 2, o + 6, o + 7);
+  printf("non-SPD rc=%d, %d (expected negative)\nsanitizer run ok\n", rc, rc2);
+  return rc < 0 && rc2 < 0 ? 0 : 1;
 }

@@ -109,3 +109,81 @@ def test_host_routines_under_asan_ubsan(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "sanitizer run ok" in run.stdout, run.stdout[-1000:] + run.stderr[-3000:]
+
+
+def _random_nw(K, D, seed):
+    rs = np.random.default_rng(seed)
+    A = rs.standard_normal((K, D, D))
+    return StackedNormalWisharts(K, D, rs.standard_normal((K, D)), rs.uniform(0.5, 3., K),
+                                 A @ A.transpose(0, 2, 1) / D + 0.2 * np.eye(D), D + rs.uniform(1., 30., K))
+
+
+@pytest.mark.parametrize("K,D", [(1, 1), (4, 2), (37, 6), (256, 8), (64, 16), (9, 33)])
+def test_native_gibbs_draw_equals_the_formulas(K, D):
+    """mimo_host_nw_gibbs against NumPy with the SAME variates: Bartlett factor A (wishart.py:72-92), Lambda = T T'
+    with T = chol(psi) A, mu = m + chol(kappa Lambda)^-T eps (gaussian.py:311-313), and the canonical form of the
+    drawn Gaussians against StackedGaussiansWithPrecision.canonical (gaussian.py:352-354, 510-521)."""
+    from mimo_amd.distributions import StackedGaussiansWithPrecision
+    nw = _random_nw(K, D, 7 * K + D)
+    mu, lam = nw.rvs(np.random.Generator(np.random.PCG64(5)))
+    assert nw.drawn_canonical[0] is mu                                 # the native route really ran
+    rng = np.random.Generator(np.random.PCG64(5))
+    nt = D * (D - 1) // 2
+    zz = rng.standard_normal((K, nt + D))
+    z, eps = zz[:, :nt], zz[:, nt:]
+    g = np.sqrt(rng.chisquare(nw.nus[:, None] - np.arange(D)[None, :]))
+    A = np.zeros((K, D, D))
+    ii = np.tril_indices(D, -1)
+    A[:, ii[0], ii[1]] = z
+    A[:, np.arange(D), np.arange(D)] = g
+    T = np.linalg.cholesky(nw.psis) @ A
+    lam2 = T @ T.transpose(0, 2, 1)
+    L2 = np.linalg.cholesky(nw.kappas[:, None, None] * lam2)
+    mu2 = nw.mus + np.linalg.solve(L2.transpose(0, 2, 1), eps[..., None])[..., 0]
+    assert rel_err(lam, lam2) < 1e-12 and rel_err(mu, mu2) < 1e-11
+    c2, b2, _ = StackedGaussiansWithPrecision(K, D, mu2, lam2).canonical()
+    assert rel_err(nw.drawn_canonical[2], c2) < 1e-11 and rel_err(nw.drawn_canonical[3], b2) < 1e-11
+
+
+def test_native_gibbs_draw_has_the_normal_wishart_law():
+    """20000 draws from ONE Normal-Wishart: E[Lambda] = nu psi, E[mu] = m, cov(mu) = E[(kappa Lambda)^-1]
+    = psi^-1 / (kappa (nu - D - 1))."""
+    K, D = 20000, 3
+    rs = np.random.default_rng(0)
+    A = rs.standard_normal((D, D))
+    psi = A @ A.T / D + 0.3 * np.eye(D)
+    m, kappa, nu = rs.standard_normal(D), 2.5, 9.
+    nw = StackedNormalWisharts(K, D, np.tile(m, (K, 1)), np.full(K, kappa), np.tile(psi, (K, 1, 1)), np.full(K, nu))
+    mu, lam = nw.rvs(np.random.Generator(np.random.PCG64(11)))
+    assert getattr(nw, 'drawn_canonical', None) is not None
+    assert np.abs(lam.mean(axis=0) - nu * psi).max() < 0.05 * np.abs(nu * psi).max()
+    assert np.abs(mu.mean(axis=0) - m).max() < 0.02
+    cov = np.cov(mu.T)
+    want = np.linalg.inv(psi) / (kappa * (nu - D - 1.))
+    assert np.abs(cov - want).max() < 0.06 * np.abs(want).max()
+
+
+def test_gibbs_step_hands_the_canonical_form_to_the_likelihood():
+    """components.resample(rng=...) -> likelihood.canonical() returns the native (c, b) only while the likelihood holds
+    exactly the drawn arrays; a later assignment of parameters recomputes."""
+    from mimo_amd.distributions import StackedGaussiansWithNormalWisharts, StackedGaussiansWithPrecision
+    from mimo_amd.engine import SuffStats
+    from mimo_amd.mixtures.gmm import _component_stats
+    K, D = 12, 5
+    np.random.seed(3)
+    prior = StackedNormalWisharts(K, D, np.zeros((K, D)), 1e-2 * np.ones(K), np.stack(K * [np.eye(D)]), (D + 2.) * np.ones(K))
+    comp = StackedGaussiansWithNormalWisharts(K, D, prior, engine=object())
+    rs = np.random.default_rng(1)
+    X = rs.standard_normal((500, D)) + 3. * rs.integers(0, 3, size=(500, 1))
+    lab = rs.integers(0, K, 500)
+    R = np.eye(K)[lab].T
+    S = SuffStats(R.sum(axis=1), R @ X, np.einsum('kn,nd,ne->kde', R, X, X))
+    comp.resample(None, stats=_component_stats(S, comp), rng=np.random.Generator(np.random.PCG64(2)))
+    assert comp.likelihood._canon is not None
+    c, b, W = comp.likelihood.canonical()
+    c2, b2, W2 = StackedGaussiansWithPrecision(K, D, comp.likelihood.mus.copy(), comp.likelihood.lmbdas.copy()).canonical()
+    assert rel_err(c, c2) < 1e-11 and rel_err(b, b2) < 1e-11 and np.array_equal(W, W2)
+    comp.likelihood.params = (comp.likelihood.mus + 1., comp.likelihood.lmbdas)
+    c3, _, _ = comp.likelihood.canonical()
+    assert rel_err(c3, StackedGaussiansWithPrecision(K, D, comp.likelihood.mus, comp.likelihood.lmbdas).canonical()[0]) < 1e-14
+    assert np.abs(c3 - c).max() > 1e-3
