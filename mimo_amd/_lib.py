@@ -6,6 +6,7 @@ this module raises, and so does every engine call.  Build it with
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
@@ -69,6 +70,15 @@ def load():
         raise MimoHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `make -C mimo_amd/csrc`.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the same SONAMEs this library
+    # links against: the dynamic loader keeps whichever copy arrives first for BOTH.  With this library first,
+    # torch ends up on the system runtime and reports "no GPUs found" (seen with the one-rank RCCL test); with
+    # torch first both share the bundled one, which works.  So when torch is installed it is imported first.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
