@@ -126,7 +126,10 @@ int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0);
  *   expected_responsibilities / responsibilities (mimo/mixtures/gmm.py:72-75,256-259),
  *   weighted_statistics (gaussian.py:491-502, lingauss.py:306-322, categorical.py:41-43) and the
  *   data/label ELBO terms (gmm.py:338-356).
- * c (K), b (K,Dz), W (K,Dz,Dz).  S: K×(1+Dz+Dz²) or NULL with MIMO_F_NO_STATS; scalars: 3 or NULL. */
+ * c (K), b (K,Dz), W (K,Dz,Dz).  S: K×(1+Dz+Dz²) or NULL with MIMO_F_NO_STATS; scalars: 3 or NULL.
+ * c[k] = -inf (a component whose weight is exactly 0: log(probs) in gmm.py:72) is allowed and gives r_kn = 0
+ * (it enters the kernels as -1e300; an l table kept with MIMO_F_KEEP_LOGP holds about -1e300 there, not -inf);
+ * NaN / +inf anywhere in c, b, W is MIMO_E_INVALID.  The same holds for every entry point that takes (c, b, W). */
 int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                int flags, double* S, double* scalars);
 

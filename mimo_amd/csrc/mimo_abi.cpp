@@ -5,6 +5,7 @@
 #include "../../include/mimo_hip.h"
 #include "mimo_kernels.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -206,15 +207,22 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   double* img = ctx->theta_h;
   memset(img, 0, count * sizeof(double));
+  bool finite = true;
   for (int k = 0; k < K; ++k) {
     const int rb = k / 16, i = k % 16;
     const double* bk = b + (size_t)k * D;
     const double* Wk = W + (size_t)k * D * D;
     auto put = [&](int f, double v) {
       const int s = f / 4, kk = f % 4;
+      finite = finite && std::fabs(v) <= 1.7976931348623157e308;
       img[((size_t)rb * NS + s) * 64 + kk * 16 + i] = v;
     };
-    put(fidx(ctx, D, D), c[k]);
+    // a component switched off by its weight (log 0 = -inf in c_k, gmm.py:84 of the host mirror) enters like a
+    // padding component: l = -1e300 for every datum, r = 0 — an infinite operand would turn the zero features of the
+    // rows past N into NaN statistics
+    if (c[k] != c[k] || c[k] > 1.7976931348623157e308)
+      return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
+    put(fidx(ctx, D, D), c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
     for (int a = 0; a < D; ++a) put(fidx(ctx, a, D), bk[a]);
     if (ctx->structure == MIMO_STRUCT_LINEAR) {
       // the common quadratic term stays with the caller (see mimo_set_structure); all W[k] must be one matrix
@@ -232,6 +240,7 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
       }
     }
   }
+  if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
   // padding components of the last row block: l = -1e300 for every datum, so the normalise phase needs no
   // "does this component exist" test (exp -> 0, never the maximum, zero weight in the statistics)
   for (int k = K; k < 16 * ((K + 15) / 16); ++k) {

@@ -379,6 +379,48 @@ def test_sharded_device_route_over_one_rank_rccl(engine):
             dist.destroy_process_group()
 
 
+def test_switched_off_component_and_far_clusters(engine):
+    """A component with log-weight -inf (gating probability exactly 0: np.log(probs) in the host mirror) and clusters
+    so far apart that l - max < -707 for most components (the clamp of the kernel's exp): responsibilities of the
+    switched-off / far components are 0 to 1e-300, statistics and the bound match the oracle, no label falls on the
+    switched-off component, the draw is the oracle's; ragged N so that rows past N sit in the last tile.  NaN / +inf
+    parameters are rejected."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(123)
+    N, D, K = 3001, 4, 37
+    centres = 400. * rng.standard_normal((K, D))
+    lab = rng.integers(0, K, N)
+    Z = centres[lab] + rng.standard_normal((N, D))
+    W = np.stack(K * [np.eye(D)]) * rng.uniform(0.5, 2., K)[:, None, None]
+    b = np.einsum('kde,ke->kd', W, centres)
+    c = -0.5 * np.einsum('kd,kd->k', centres, b) + rng.standard_normal(K)
+    c[5] = -np.inf
+    with np.errstate(invalid='ignore'):
+        L = O.canonical_eval(Z, c, b, W)
+    L[5] = -np.inf
+    lse = logsumexp(L, axis=0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    engine.upload(Z)
+    S, sc = engine.estep(c, b, W, keep_resp=True)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-11 * abs(lse.sum()) and np.all(np.isfinite(S.sxx))
+    Rg = engine.get_resp(K)
+    assert np.abs(Rg - R).max() < 1e-14 and Rg[5].max() < 1e-300 and S.n[5] < 1e-290
+    labels, Sg = engine.gibbs_labels(c, b, W, seed=9, sweep=4)
+    ref = O.sample_discrete_from_log(L, O.philox_uniforms(9, np.arange(N), 4))
+    assert np.array_equal(labels, ref) and not np.any(labels == 5)
+    assert np.array_equal(Sg.n, np.bincount(ref, minlength=K))
+    for bad in (np.nan, np.inf):
+        c2 = c.copy(); c2[3] = bad
+        with pytest.raises(ValueError):
+            engine.estep(c2, b, W)
+    b2 = b.copy(); b2[7, 1] = np.nan
+    with pytest.raises(ValueError):
+        engine.estep(c, b2, W)
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the
