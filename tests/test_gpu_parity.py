@@ -421,6 +421,29 @@ def test_switched_off_component_and_far_clusters(engine):
         engine.estep(c, b2, W)
 
 
+def test_example_scripts_run_on_the_gpu():
+    """examples/: the command-line counterparts of the reference's toy GMM / DP-GMM / sine-regression scripts run
+    end to end on the HIP engine (own processes, one at a time) and recover what they should."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(*args):
+        r = subprocess.run([sys.executable] + list(args), cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+
+    truth = np.array([[-5., -5.], [-3., 3.], [3., -3.], [5., 5.]])
+    for method in ("gibbs", "vi", "em"):
+        out = run("examples/gmm_toy.py", "--method", method, "--rows", "5000", "--iters", "40")
+        rows = re.findall(r"\[\s*\[?\s*(-?\d+\.?\d*)\s+(-?\d+\.?\d*)\s*\]", out)
+        means = np.array(rows[-4:], dtype=float)
+        assert means.shape == (4, 2) and np.abs(means - truth).max() < 0.5, out
+    out = run("examples/dpgmm_gibbs.py", "--rows", "200000", "--dim", "4", "--kmax", "64", "--clusters", "6", "--sweeps", "40")
+    assert "evaluations/s" in out
+    out = run("examples/ilr_sine.py", "--rows", "5000", "--experts", "12", "--iters", "60")
+    assert float(re.search(r"RMSE against the noiseless curve: ([0-9.]+)", out).group(1)) < 0.5, out
+
+
 def test_full_size_properties(engine):
     """BASELINE config 2 shape at full N (1e7 x 16, K=64): size-independent properties —
     (i) responsibilities sum to one => sum_k n_k = N exactly to rounding; (ii) linearity: the
