@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--method", choices=["gibbs", "vi", "em"], default="gibbs")
     ap.add_argument("--rows", type=int, default=10000)
-    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1337)
     ap.add_argument("--init", choices=["prior", "random"], default="random", help="initial labels of the Gibbs sweeps")
     args = ap.parse_args()
@@ -44,13 +44,13 @@ def main():
         mus = model.components.likelihood.mus
     elif args.method == "vi":
         # (the reference's vi_toy.py starts from random responsibilities and runs 1000 iterations to leave the
-        # symmetric start; a few Gibbs sweeps first get there in a fraction of that)
-        model.resample(obs, init_labels=args.init, maxiter=50, progress_bar=False)
+        # symmetric start; Gibbs sweeps first get there in a fraction of that)
+        model.resample(obs, init_labels=args.init, maxiter=args.iters, progress_bar=False)
         vlb = model.meanfield_coordinate_descent(obs, randomize=False, maxiter=args.iters, tol=1e-8, progress_bar=False)
         print(f"ELBO: {vlb[0]:.3f} -> {vlb[-1]:.3f} in {len(vlb)} iterations, monotone: {bool(np.all(np.diff(vlb) > -1e-6))}")
         mus = model.components.posterior.mus
     else:
-        model.resample(obs, init_labels=args.init, maxiter=50, progress_bar=False)
+        model.resample(obs, init_labels=args.init, maxiter=args.iters, progress_bar=False)
         model.max_aposteriori(obs, randomize=False, maxiter=args.iters, progress_bar=False)
         mus = model.components.likelihood.mus
     order = np.lexsort((mus[:, 1], mus[:, 0]))

