@@ -567,7 +567,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
 #ifndef MIMO_RBW4_ESTEP_WGS
 #define MIMO_RBW4_ESTEP_WGS 2   // workgroups per CU the RBW = 4 E-step kernels with NCB <= 3 are compiled for
 #endif
-template <int NCB, int RBW, int MODE, int DS = 0>
+template <int NCB, int RBW, int MODE, int DS = 0, bool SPLIT = false>
 __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : (MODE <= kGeneric && NCB <= 3) ? MIMO_RBW4_ESTEP_WGS
                                    : (MODE > kGeneric && RBW * NCB <= 12) ? 2 : 1))
 void fused_kernel(const KernelArgs a) {
@@ -642,6 +642,14 @@ void fused_kernel(const KernelArgs a) {
   double sc_lse = 0.0, sc_rl = 0.0, sc_prod = 1.0;
   int prod_tiles = 0;
   PhiloxBatch pbatch;
+  // K <= 16 (one row block): row-block ownership would leave waves 1..3 without matrix work — a K = 16 sweep cost
+  // what a K = 64 sweep costs.  Instead the two column groups (rows 0-15 / 16-31) of the L tile go to waves 0 and 1,
+  // and the feature column blocks of the statistics to all four waves (wave w: blocks w, w + 4, w + 8, held in
+  // sacc[0][0..NWS)).  Separate instantiations (SPLIT, launched for K <= 16 and Dz >= 7): with the two paths in one
+  // kernel the C2 instantiation lost 9 % to register allocation.
+  static_assert(!SPLIT || RBW == 1, "the split distribution is the one-row-block case");
+  constexpr bool split1 = SPLIT;
+  constexpr int NWS = (NCB + 3) / 4;
 
   // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
@@ -757,7 +765,33 @@ void fused_kernel(const KernelArgs a) {
       // ---- 3. L tile = Theta . Phi' ------------------------------------------------------
       // B operand: lane (kk = q, col = j) holds Phi[row 16 g + j][4 s + q].
       // C/D layout of v_mfma_f64_16x16x4_f64: reg r of lane (q, j) = row q + 4 r, col j.
-      if (wave < K16) {   // wave-uniform (scalar) test: this wave owns at least row block `wave`
+      if constexpr (split1) {
+        if (wave < 2) {
+          gptr_t th = (gptr_t)a.theta;      // row block 0 for both waves
+          asm volatile("" : "+s"(th));
+          const double* p = Ph + (16 * wave + j) * RS + q;
+          d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+          constexpr int PD = NS < 8 ? NS : 8;       // Theta slices in flight (straight from L2, no cross-tile ring)
+          double tr[PD], bq[3];
+#pragma unroll
+          for (int e = 0; e < PD; ++e) tr[e] = th[e * 64 + lane];
+          bq[0] = p[0];
+          if (NS > 1) bq[1] = p[4];
+#pragma unroll
+          for (int s2 = 0; s2 < NS; ++s2) {
+            if (s2 + 2 < NS) bq[(s2 + 2) % 3] = p[4 * (s2 + 2)];
+            __builtin_amdgcn_sched_barrier(0);
+            const double av = tr[s2 % PD];
+            if (s2 + PD < NS) tr[s2 % PD] = th[(s2 + PD) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[s2 % 3], acc, 0, 0, 0);
+          }
+          int lw_off = (16 * wave + j) * LS + q;
+          asm volatile("" : "+v"(lw_off));
+          double* lw = Lt + lw_off;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lw[4 * r] = acc[r];
+        }
+      } else if (wave < K16) {   // wave-uniform (scalar) test: this wave owns at least row block `wave`
         thw = thw0;
         asm volatile("" : "+s"(thw));  // opaque per tile: slice addresses = scalar base + immediates, not 2*NE hoisted VGPRs
         const double* p0 = Ph + j * RS + q;
@@ -840,7 +874,40 @@ void fused_kernel(const KernelArgs a) {
     // ---- 5. S += R . Phi ----------------------------------------------------------------
     // step s contracts the 4 rows {s, s+8, s+16, s+24}: A lane (i = j, kk = q) = R[8q+s][16rb+j],
     // B lane (kk = q, col = j) = Phi[8q+s][16cb+j].
-    if (do_stats && wave < K16) {
+    if constexpr (split1) {
+     if (do_stats) {
+      int lt_off = 8 * q * LS + j, ph_off = 8 * q * RS + j;
+      asm volatile("" : "+v"(lt_off), "+v"(ph_off));
+      const double* ltq = Lt + lt_off;
+      const double* phq = Ph + ph_off;
+      int cbo[NWS];      // scalar: column offsets of this wave's blocks (a block past NCB repeats the last one; never stored)
+#pragma unroll
+      for (int i = 0; i < NWS; ++i) cbo[i] = 16 * (wave + 4 * i < NCB ? wave + 4 * i : NCB - 1);
+      auto stats_split = [&](auto lab_c) {
+        constexpr bool LAB = decltype(lab_c)::value;
+        double avq[2], bvq[2][NWS];
+        auto fetch = [&](int s2, int slot) {
+          const double* pb = phq + s2 * RS;
+          if constexpr (LAB) avq[slot] = labs[8 * q + s2] == j ? 1.0 : 0.0;
+          else avq[slot] = ltq[s2 * LS];
+#pragma unroll
+          for (int i = 0; i < NWS; ++i) bvq[slot][i] = pb[cbo[i]];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          if (s2 + 1 < 8) fetch(s2 + 1, (s2 + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NWS; ++i)
+            sacc[0][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(avq[s2 & 1], bvq[s2 & 1][i], sacc[0][i], 0, 0, 0);
+        }
+      };
+      if constexpr (MODE == kFastGibbs || MODE == kModeLabels) stats_split(std::true_type{});
+      else if constexpr (MODE == kGeneric) { if (gibbs) stats_split(std::true_type{}); else stats_split(std::false_type{}); }
+      else stats_split(std::false_type{});
+     }
+    } else if (do_stats && wave < K16) {
       // per-tile opaque bases: every operand address below is base + s * stride + immediate, instead of
       // 8 * (RBW + 1) loop-invariant addresses the compiler would otherwise pin in (and spill from) VGPRs
       // (the OFFSETS are made opaque, not the pointers: a pointer that went through an asm loses its LDS
@@ -951,15 +1018,26 @@ void fused_kernel(const KernelArgs a) {
   const int FT = a.F16_total;   // row stride of the partial block (= F16 unless this launch is one column group)
   const size_t pstride = (size_t)Kpad * FT + 4;
   double* P = a.partials + (size_t)blockIdx.x * pstride + (SRC == kSrcEstep ? 0 : 16 * a.cb0);
+  if constexpr (split1) {
 #pragma unroll
-  for (int i = 0; i < RBW; ++i) {
-    const int rb = wave + 4 * i;
-    if (rb < K16) {
+    for (int i = 0; i < NWS; ++i) {
+      const int cb = wave + 4 * i;
+      if (cb < NCB) {
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
+        for (int r = 0; r < 4; ++r) P[(size_t)(q + 4 * r) * FT + 16 * cb + j] = sacc[0][i][r];
+      }
+    }
+  } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          P[(size_t)(16 * rb + q + 4 * r) * FT + 16 * cb + j] = sacc[i][cb][r];
+    for (int i = 0; i < RBW; ++i) {
+      const int rb = wave + 4 * i;
+      if (rb < K16) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            P[(size_t)(16 * rb + q + 4 * r) * FT + 16 * cb + j] = sacc[i][cb][r];
+      }
     }
   }
   if constexpr (MODE == kFastVI || MODE == kFastGibbs) sc_lse += log(sc_prod);
@@ -1410,6 +1488,34 @@ static fused_fn pick_estep(int D, int mode) {
   return nullptr;
 }
 
+// K <= 16 at Dz >= 7 (three or more feature column blocks): the split work distribution (fused_kernel, SPLIT)
+template <int D>
+static fused_fn pick_estep_split_mode(int mode) {
+  switch (mode) {
+    case kFastVI: return fused_kernel<ncb_of(D), 1, kFastVI, D, true>;
+    case kFastGibbs: return fused_kernel<ncb_of(D), 1, kFastGibbs, D, true>;
+    case kGeneric: return fused_kernel<ncb_of(D), 1, kGeneric, D, true>;
+  }
+  return nullptr;
+}
+static fused_fn pick_estep_split(int D, int mode) {
+  static const int min_d = [] { const char* e = getenv("MIMO_SPLIT_MIN_D"); return e ? atoi(e) : 7; }();   // tuning knob
+  if (D < min_d) return nullptr;
+  switch (D) {
+    case 7: return pick_estep_split_mode<7>(mode);
+    case 8: return pick_estep_split_mode<8>(mode);
+    case 9: return pick_estep_split_mode<9>(mode);
+    case 10: return pick_estep_split_mode<10>(mode);
+    case 11: return pick_estep_split_mode<11>(mode);
+    case 12: return pick_estep_split_mode<12>(mode);
+    case 13: return pick_estep_split_mode<13>(mode);
+    case 14: return pick_estep_split_mode<14>(mode);
+    case 15: return pick_estep_split_mode<15>(mode);
+    case 16: return pick_estep_split_mode<16>(mode);
+  }
+  return nullptr;
+}
+
 // E-step modes over a table-driven feature set (diagonal structure: 2 Dz + 1 features, at most 5 column blocks)
 template <int RBW>
 static fused_fn pick_estep_table(int ncb, int mode) {
@@ -1443,6 +1549,9 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
   if (!fused_covers(a.K16, ncb, src)) return nullptr;
   if (src == kSrcEstep && a.diag)
     return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : pick_estep_table<4>(ncb, mode);
+  if (src == kSrcEstep && a.K16 == 1) {
+    if (fused_fn f = pick_estep_split(a.D, mode)) return f;
+  }
   if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
   return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
          : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
