@@ -567,7 +567,7 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
 #ifndef MIMO_RBW4_ESTEP_WGS
 #define MIMO_RBW4_ESTEP_WGS 2   // workgroups per CU the RBW = 4 E-step kernels with NCB <= 3 are compiled for
 #endif
-template <int NCB, int RBW, int MODE, int DS = 0, bool SPLIT = false>
+template <int NCB, int RBW, int MODE, int DS = 0, int SPLIT = 0>
 __global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : (MODE <= kGeneric && NCB <= 3) ? MIMO_RBW4_ESTEP_WGS
                                    : (MODE > kGeneric && RBW * NCB <= 12) ? 2 : 1))
 void fused_kernel(const KernelArgs a) {
@@ -647,9 +647,12 @@ void fused_kernel(const KernelArgs a) {
   // and the feature column blocks of the statistics to all four waves (wave w: blocks w, w + 4, w + 8, held in
   // sacc[0][0..NWS)).  Separate instantiations (SPLIT, launched for K <= 16 and Dz >= 7): with the two paths in one
   // kernel the C2 instantiation lost 9 % to register allocation.
-  static_assert(!SPLIT || RBW == 1, "the split distribution is the one-row-block case");
-  constexpr bool split1 = SPLIT;
-  constexpr int NWS = (NCB + 3) / 4;
+  // SPLIT = 2 is the same idea for 16 < K <= 32: row block wave & 1, column group / column-block parity wave >> 1.
+  static_assert(SPLIT == 0 || (RBW == 1 && SPLIT <= 2), "SPLIT = number of row blocks shared by the four waves");
+  constexpr bool split1 = SPLIT != 0;
+  constexpr int NRB = SPLIT ? SPLIT : 1, WPR = 4 / NRB;       // row blocks, waves per row block
+  constexpr int NWS = (NCB + WPR - 1) / WPR;
+  const int srb = wave % NRB, sidx = wave / NRB;              // (scalar) row block and rank of this wave within it
 
   // Z tile staging: every thread owns up to ZPT elements of the (T, D) tile; the NEXT tile is
   // fetched into registers while the current one is processed, so the HBM latency is off the
@@ -766,10 +769,10 @@ void fused_kernel(const KernelArgs a) {
       // B operand: lane (kk = q, col = j) holds Phi[row 16 g + j][4 s + q].
       // C/D layout of v_mfma_f64_16x16x4_f64: reg r of lane (q, j) = row q + 4 r, col j.
       if constexpr (split1) {
-        if (wave < 2) {
-          gptr_t th = (gptr_t)a.theta;      // row block 0 for both waves
+        if (sidx < 2) {                     // column group sidx of row block srb
+          gptr_t th = (gptr_t)(a.theta + (size_t)srb * NSI * 64);
           asm volatile("" : "+s"(th));
-          const double* p = Ph + (16 * wave + j) * RS + q;
+          const double* p = Ph + (16 * sidx + j) * RS + q;
           d4 acc = d4{0.0, 0.0, 0.0, 0.0};
           constexpr int PD = NS < 8 ? NS : 8;       // Theta slices in flight (straight from L2, no cross-tile ring)
           double tr[PD], bq[3];
@@ -785,7 +788,7 @@ void fused_kernel(const KernelArgs a) {
             if (s2 + PD < NS) tr[s2 % PD] = th[(s2 + PD) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[s2 % 3], acc, 0, 0, 0);
           }
-          int lw_off = (16 * wave + j) * LS + q;
+          int lw_off = (16 * sidx + j) * LS + 16 * srb + q;
           asm volatile("" : "+v"(lw_off));
           double* lw = Lt + lw_off;
 #pragma unroll
@@ -876,19 +879,19 @@ void fused_kernel(const KernelArgs a) {
     // B lane (kk = q, col = j) = Phi[8q+s][16cb+j].
     if constexpr (split1) {
      if (do_stats) {
-      int lt_off = 8 * q * LS + j, ph_off = 8 * q * RS + j;
+      int lt_off = 8 * q * LS + 16 * srb + j, ph_off = 8 * q * RS + j;
       asm volatile("" : "+v"(lt_off), "+v"(ph_off));
       const double* ltq = Lt + lt_off;
       const double* phq = Ph + ph_off;
       int cbo[NWS];      // scalar: column offsets of this wave's blocks (a block past NCB repeats the last one; never stored)
 #pragma unroll
-      for (int i = 0; i < NWS; ++i) cbo[i] = 16 * (wave + 4 * i < NCB ? wave + 4 * i : NCB - 1);
+      for (int i = 0; i < NWS; ++i) cbo[i] = 16 * (sidx + WPR * i < NCB ? sidx + WPR * i : NCB - 1);
       auto stats_split = [&](auto lab_c) {
         constexpr bool LAB = decltype(lab_c)::value;
         double avq[2], bvq[2][NWS];
         auto fetch = [&](int s2, int slot) {
           const double* pb = phq + s2 * RS;
-          if constexpr (LAB) avq[slot] = labs[8 * q + s2] == j ? 1.0 : 0.0;
+          if constexpr (LAB) avq[slot] = labs[8 * q + s2] == 16 * srb + j ? 1.0 : 0.0;
           else avq[slot] = ltq[s2 * LS];
 #pragma unroll
           for (int i = 0; i < NWS; ++i) bvq[slot][i] = pb[cbo[i]];
@@ -1021,10 +1024,10 @@ void fused_kernel(const KernelArgs a) {
   if constexpr (split1) {
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
-      const int cb = wave + 4 * i;
+      const int cb = sidx + WPR * i;
       if (cb < NCB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[(size_t)(q + 4 * r) * FT + 16 * cb + j] = sacc[0][i][r];
+        for (int r = 0; r < 4; ++r) P[(size_t)(16 * srb + q + 4 * r) * FT + 16 * cb + j] = sacc[0][i][r];
       }
     }
   } else {
@@ -1488,30 +1491,31 @@ static fused_fn pick_estep(int D, int mode) {
   return nullptr;
 }
 
-// K <= 16 at Dz >= 7 (three or more feature column blocks): the split work distribution (fused_kernel, SPLIT)
-template <int D>
+// K <= 32 at Dz >= 7 (three or more feature column blocks): the split work distribution (fused_kernel, SPLIT = K16)
+template <int D, int SP>
 static fused_fn pick_estep_split_mode(int mode) {
   switch (mode) {
-    case kFastVI: return fused_kernel<ncb_of(D), 1, kFastVI, D, true>;
-    case kFastGibbs: return fused_kernel<ncb_of(D), 1, kFastGibbs, D, true>;
-    case kGeneric: return fused_kernel<ncb_of(D), 1, kGeneric, D, true>;
+    case kFastVI: return fused_kernel<ncb_of(D), 1, kFastVI, D, SP>;
+    case kFastGibbs: return fused_kernel<ncb_of(D), 1, kFastGibbs, D, SP>;
+    case kGeneric: return fused_kernel<ncb_of(D), 1, kGeneric, D, SP>;
   }
   return nullptr;
 }
+template <int SP>
 static fused_fn pick_estep_split(int D, int mode) {
   static const int min_d = [] { const char* e = getenv("MIMO_SPLIT_MIN_D"); return e ? atoi(e) : 7; }();   // tuning knob
   if (D < min_d) return nullptr;
   switch (D) {
-    case 7: return pick_estep_split_mode<7>(mode);
-    case 8: return pick_estep_split_mode<8>(mode);
-    case 9: return pick_estep_split_mode<9>(mode);
-    case 10: return pick_estep_split_mode<10>(mode);
-    case 11: return pick_estep_split_mode<11>(mode);
-    case 12: return pick_estep_split_mode<12>(mode);
-    case 13: return pick_estep_split_mode<13>(mode);
-    case 14: return pick_estep_split_mode<14>(mode);
-    case 15: return pick_estep_split_mode<15>(mode);
-    case 16: return pick_estep_split_mode<16>(mode);
+    case 7: return pick_estep_split_mode<7, SP>(mode);
+    case 8: return pick_estep_split_mode<8, SP>(mode);
+    case 9: return pick_estep_split_mode<9, SP>(mode);
+    case 10: return pick_estep_split_mode<10, SP>(mode);
+    case 11: return pick_estep_split_mode<11, SP>(mode);
+    case 12: return pick_estep_split_mode<12, SP>(mode);
+    case 13: return pick_estep_split_mode<13, SP>(mode);
+    case 14: return pick_estep_split_mode<14, SP>(mode);
+    case 15: return pick_estep_split_mode<15, SP>(mode);
+    case 16: return pick_estep_split_mode<16, SP>(mode);
   }
   return nullptr;
 }
@@ -1549,8 +1553,8 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
   if (!fused_covers(a.K16, ncb, src)) return nullptr;
   if (src == kSrcEstep && a.diag)
     return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : pick_estep_table<4>(ncb, mode);
-  if (src == kSrcEstep && a.K16 == 1) {
-    if (fused_fn f = pick_estep_split(a.D, mode)) return f;
+  if (src == kSrcEstep && a.K16 <= 2) {
+    if (fused_fn f = a.K16 == 1 ? pick_estep_split<1>(a.D, mode) : pick_estep_split<2>(a.D, mode)) return f;
   }
   if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
   return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)

@@ -164,7 +164,8 @@ def test_engine_vs_oracle_seeded(engine, N, D, K):
 
 @pytest.mark.parametrize("D,K", [(7, 20), (8, 33), (10, 64), (11, 5), (13, 40), (15, 64), (16, 64), (8, 200), (3, 256),
                                  (32, 128), (20, 16), (12, 100), (16, 128), (24, 70),
-                                 (16, 16), (16, 3), (12, 16), (9, 4), (7, 1), (14, 11)])     # K <= 16, Dz >= 7: split kernels
+                                 (16, 16), (16, 3), (12, 16), (9, 4), (7, 1), (14, 11),      # K <= 32, Dz >= 7: split kernels
+                                 (16, 32), (16, 17), (11, 25), (8, 32), (7, 30)])
 def test_many_tiles_per_workgroup(engine, D, K):
     """N large enough that every workgroup walks several tiles (the Theta ring wraps from tile to tile):
     fused E-step, Gibbs labels and statistics against the oracle for every ring geometry."""
@@ -187,7 +188,7 @@ def test_many_tiles_per_workgroup(engine, D, K):
     assert np.array_equal(lab, ref) and np.array_equal(S3.n, np.bincount(ref, minlength=K))
 
 
-@pytest.mark.parametrize("D,K", [(15, 64), (8, 256), (3, 256), (16, 64), (16, 16), (10, 7)])
+@pytest.mark.parametrize("D,K", [(15, 64), (8, 256), (3, 256), (16, 64), (16, 16), (10, 7), (16, 32), (9, 20)])
 def test_repeated_launches_are_bit_identical(engine, D, K):
     """Every launch of every mode returns the SAME bits (fixed summation order, no float atomics) with all
     workgroups co-resident and several tiles per workgroup.  Regression for a lane-layout experiment whose
@@ -216,7 +217,7 @@ def test_repeated_launches_are_bit_identical(engine, D, K):
 
 
 @pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (8, 200, 33000), (5, 7, 0), (20, 16, 5000),
-                                   (12, 9, 21000), (16, 16, 40000)])
+                                   (12, 9, 21000), (16, 16, 40000), (13, 27, 30000)])
 def test_row_weighted_estep(engine, D, K, N):
     """mimo_estep_weighted: statistics of r_kn w_n, scalars / tables of the unweighted r_kn (hgmm.py:199-207) —
     single-pass shapes in-kernel, two-stage shapes (Dz = 20) through the table route."""
