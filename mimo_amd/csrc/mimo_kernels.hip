@@ -1534,9 +1534,9 @@ static fused_fn pick_estep_table(int ncb, int mode) {
 }
 
 // statistics modes: table-driven feature build, one instantiation per column-block count
-template <int RBW>
+template <int RBW, int SP = 0>
 static fused_fn pick_stats(int ncb, int mode) {
-#define MIMO_STATS_CASE(n) case n: return mode == kModeWeights ? fused_kernel<n, RBW, kModeWeights> : fused_kernel<n, RBW, kModeLabels>;
+#define MIMO_STATS_CASE(n) case n: return mode == kModeWeights ? fused_kernel<n, RBW, kModeWeights, 0, SP> : fused_kernel<n, RBW, kModeLabels, 0, SP>;
   switch (ncb) {
     MIMO_STATS_CASE(1) MIMO_STATS_CASE(2) MIMO_STATS_CASE(3) MIMO_STATS_CASE(4) MIMO_STATS_CASE(5)
     MIMO_STATS_CASE(6) MIMO_STATS_CASE(7) MIMO_STATS_CASE(8) MIMO_STATS_CASE(9) MIMO_STATS_CASE(10)
@@ -1557,6 +1557,10 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
     if (fused_fn f = a.K16 == 1 ? pick_estep_split<1>(a.D, mode) : pick_estep_split<2>(a.D, mode)) return f;
   }
   if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
+  if (a.K16 <= 2 && ncb >= 3) {   // K <= 32: split distribution of the statistics column blocks (see fused_kernel, SPLIT)
+    static const bool on = [] { const char* e = getenv("MIMO_SPLIT_STATS"); return !e || atoi(e) != 0; }();   // tuning knob
+    if (on) return a.K16 == 1 ? pick_stats<1, 1>(ncb, mode) : pick_stats<1, 2>(ncb, mode);
+  }
   return rbw_stats(a.K16) == 1 ? pick_stats<1>(ncb, mode)
          : rbw_stats(a.K16) == 2 ? pick_stats<2>(ncb, mode) : pick_stats<4>(ncb, mode);
 }
