@@ -1065,8 +1065,12 @@ void fused_kernel(const KernelArgs a) {
 // accumulates in registers.  Writes the responsibility table / labels (+ optional logp, lse) to
 // HBM; the statistics then come from fused_kernel<.., kModeWeights / kModeLabels> per column group.
 // ------------------------------------------------------------------------------------------
-template <int RBW>
+template <int RBW, int SPLIT = 0>
 __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(const KernelArgs a) {
+  // SPLIT (K <= 32, see fused_kernel): NRB = SPLIT row blocks shared by the four waves — wave w works on row block
+  // w % NRB and on ONE column group (w / NRB) of the L tile instead of both; waves with w / NRB >= 2 have no part.
+  static_assert(SPLIT == 0 || (RBW == 1 && SPLIT <= 2), "SPLIT = number of row blocks shared by the four waves");
+  constexpr int NRB = SPLIT ? SPLIT : 1;
   constexpr int T = kTile;
   constexpr int NCBc = kChunkNCB, CF = 16 * NCBc, NSc = CF / 4;
   #ifndef MIMO_CHUNK_RING
@@ -1100,14 +1104,16 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 
   // Theta stream: block bl = (chunk, pass) consumes LE slices in the order (step s, row block i2 of the
   // pass); a 6-deep register ring prefetches across block and tile boundaries.
-  gptr_t thw = (gptr_t)(a.theta + (size_t)wave * NSP * 64 + lane);
+  const int srb = SPLIT ? wave % NRB : wave, sidx = SPLIT ? wave / NRB : 0;   // (scalar)
+  const bool mfma_wave = SPLIT ? sidx < 2 : wave < K16;
+  gptr_t thw = (gptr_t)(a.theta + (size_t)srb * NSP * 64 + lane);
   auto block_base = [&](int bl) {
     const int ch = bl / NPASS, h = bl - ch * NPASS;
     return thw + ((size_t)(4 * h * RP) * NSP + (size_t)ch * NSc) * 64;
   };
   auto slice = [&](gptr_t base, int ee) { return base[((size_t)(4 * (ee % RP)) * NSP + ee / RP) * 64]; };
   double ring[PF];
-  if (wave < K16) {
+  if (mfma_wave) {
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = slice(block_base(0), e);
   }
@@ -1140,7 +1146,19 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
         for (int jj = 0; jj < 2 * NCBc; ++jj) prow[jj] = zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]];
       }
       wg_sync();
-      if (wave < K16) {
+      if constexpr (SPLIT != 0) {
+        if (mfma_wave) {     // RBW = 1: one pass, LE = NSc slices per chunk, one column group
+          const double* p = Ph + (16 * sidx + j) * RS + q;
+          gptr_t base = block_base(ch);
+          gptr_t nbase = block_base(ch + 1 == NB ? 0 : ch + 1);
+#pragma unroll
+          for (int ee = 0; ee < LE; ++ee) {
+            const double av = ring[ee % PF];
+            ring[ee % PF] = ee + PF < LE ? slice(base, ee + PF) : slice(nbase, ee + PF - LE);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, p[4 * ee], acc[0][0], 0, 0, 0);
+          }
+        }
+      } else if (wave < K16) {
         const double* p0 = Ph + j * RS + q;
         const double* p1 = Ph + (16 + j) * RS + q;
 #pragma unroll
@@ -1167,14 +1185,21 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
         }
       }
     }
+    if constexpr (SPLIT != 0) {
+      if (mfma_wave) {
 #pragma unroll
-    for (int i = 0; i < RBW; ++i) {
-      const int rb = wave + 4 * i;
-      if (rb < K16) {
+        for (int r = 0; r < 4; ++r) Lt[(16 * sidx + j) * LS + 16 * srb + q + 4 * r] = acc[0][0][r];
+      }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          Lt[j * LS + 16 * rb + q + 4 * r] = acc[i][0][r];
-          Lt[(16 + j) * LS + 16 * rb + q + 4 * r] = acc[i][1][r];
+      for (int i = 0; i < RBW; ++i) {
+        const int rb = wave + 4 * i;
+        if (rb < K16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Lt[j * LS + 16 * rb + q + 4 * r] = acc[i][0][r];
+            Lt[(16 + j) * LS + 16 * rb + q + 4 * r] = acc[i][1][r];
+          }
         }
       }
     }
@@ -1625,7 +1650,9 @@ size_t chunked_lds_bytes(const KernelArgs& a) {
 
 hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  fn_t fn = rbw_stats(a.K16) == 1 ? estep_chunked_kernel<1>
+  static const bool split_on = [] { const char* e = getenv("MIMO_SPLIT_CHUNKED"); return !e || atoi(e) != 0; }();   // tuning knob
+  fn_t fn = (split_on && a.K16 == 1) ? estep_chunked_kernel<1, 1> : (split_on && a.K16 == 2) ? estep_chunked_kernel<1, 2>
+            : rbw_stats(a.K16) == 1 ? estep_chunked_kernel<1>
             : rbw_stats(a.K16) == 2 ? estep_chunked_kernel<2> : estep_chunked_kernel<4>;
   const size_t lds = chunked_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
