@@ -649,7 +649,7 @@ void fused_kernel(const KernelArgs a) {
   // kernel the C2 instantiation lost 9 % to register allocation.
   // SPLIT = 2 is the same idea for 16 < K <= 32: row block wave & 1, column group / column-block parity wave >> 1.
   static_assert(SPLIT == 0 || (RBW == 1 && SPLIT <= 2), "SPLIT = number of row blocks shared by the four waves");
-  constexpr bool split1 = SPLIT != 0;
+  constexpr bool is_split = SPLIT != 0;
   constexpr int NRB = SPLIT ? SPLIT : 1, WPR = 4 / NRB;       // row blocks, waves per row block
   constexpr int NWS = (NCB + WPR - 1) / WPR;
   const int srb = wave % NRB, sidx = wave / NRB;              // (scalar) row block and rank of this wave within it
@@ -768,7 +768,7 @@ void fused_kernel(const KernelArgs a) {
       // ---- 3. L tile = Theta . Phi' ------------------------------------------------------
       // B operand: lane (kk = q, col = j) holds Phi[row 16 g + j][4 s + q].
       // C/D layout of v_mfma_f64_16x16x4_f64: reg r of lane (q, j) = row q + 4 r, col j.
-      if constexpr (split1) {
+      if constexpr (is_split) {
         if (sidx < 2) {                     // column group sidx of row block srb
           gptr_t th = (gptr_t)(a.theta + (size_t)srb * NSI * 64);
           asm volatile("" : "+s"(th));
@@ -877,7 +877,7 @@ void fused_kernel(const KernelArgs a) {
     // ---- 5. S += R . Phi ----------------------------------------------------------------
     // step s contracts the 4 rows {s, s+8, s+16, s+24}: A lane (i = j, kk = q) = R[8q+s][16rb+j],
     // B lane (kk = q, col = j) = Phi[8q+s][16cb+j].
-    if constexpr (split1) {
+    if constexpr (is_split) {
      if (do_stats) {
       int lt_off = 8 * q * LS + 16 * srb + j, ph_off = 8 * q * RS + j;
       asm volatile("" : "+v"(lt_off), "+v"(ph_off));
@@ -1021,7 +1021,7 @@ void fused_kernel(const KernelArgs a) {
   const int FT = a.F16_total;   // row stride of the partial block (= F16 unless this launch is one column group)
   const size_t pstride = (size_t)Kpad * FT + 4;
   double* P = a.partials + (size_t)blockIdx.x * pstride + (SRC == kSrcEstep ? 0 : 16 * a.cb0);
-  if constexpr (split1) {
+  if constexpr (is_split) {
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
       const int cb = sidx + WPR * i;
