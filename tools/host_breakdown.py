@@ -9,7 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c2"
 cfg = bench.CONFIGS[name]; desc, N, D, K, mode = cfg
 if len(sys.argv) > 2: N = int(float(sys.argv[2]))
 X = bench.make_data(N, D, K, seed=1337, device="cuda:0", ilr=(mode == "ilr")); torch.cuda.synchronize()
-hip = HipEngine(0); hip.set_stream(torch.cuda.current_stream().cuda_stream); hip.upload(X)
+hip = HipEngine(0); hip.upload(X)
 model = bench.build_model(cfg, hip)
 S = hip.label_stats(np.random.default_rng(1).integers(0, K, size=N).astype(np.int32), K)
 T = {k: 0.0 for k in ("update", "canonical", "launch", "prior_terms", "wait")}
