@@ -1557,6 +1557,15 @@ static fused_fn pick_estep_table(int ncb, int mode) {
 #undef MIMO_ESTEP_TABLE_CASE
   return nullptr;
 }
+// the same for K <= 32 with three or more column blocks (diagonal structure at Dz >= 16): split distribution
+template <int SP>
+static fused_fn pick_estep_table_split(int ncb, int mode) {
+#define MIMO_ESTEP_TABLE_CASE(n) case n: return mode == kFastVI ? fused_kernel<n, 1, kFastVI, 0, SP> \
+    : mode == kFastGibbs ? fused_kernel<n, 1, kFastGibbs, 0, SP> : fused_kernel<n, 1, kGeneric, 0, SP>;
+  switch (ncb) { MIMO_ESTEP_TABLE_CASE(3) MIMO_ESTEP_TABLE_CASE(4) MIMO_ESTEP_TABLE_CASE(5) }
+#undef MIMO_ESTEP_TABLE_CASE
+  return nullptr;
+}
 
 // statistics modes: table-driven feature build, one instantiation per column-block count
 template <int RBW, int SP = 0>
@@ -1576,6 +1585,10 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
   if (src == kSrcEstep && a.do_stats && !a.split && !a.logp && !a.resp && !a.lse && (a.gibbs || !a.u))
     mode = a.gibbs ? kFastGibbs : kFastVI;   // (per-row weights of a mean-field pass live in the generic kernels)
   if (!fused_covers(a.K16, ncb, src)) return nullptr;
+  if (src == kSrcEstep && a.diag && a.K16 <= 2 && ncb >= 3) {
+    static const bool on = [] { const char* e = getenv("MIMO_SPLIT_TABLE"); return !e || atoi(e) != 0; }();   // tuning knob
+    if (on) return a.K16 == 1 ? pick_estep_table_split<1>(ncb, mode) : pick_estep_table_split<2>(ncb, mode);
+  }
   if (src == kSrcEstep && a.diag)
     return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : pick_estep_table<4>(ncb, mode);
   if (src == kSrcEstep && a.K16 <= 2) {

@@ -244,7 +244,8 @@ def test_row_weighted_estep(engine, D, K, N):
 
 
 @pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (32, 64, 20000), (8, 256, 33000), (32, 128, 9000),
-                                   (5, 7, 0), (24, 200, 5000)])
+                                   (5, 7, 0), (24, 200, 5000),
+                                   (16, 16, 30000), (32, 24, 20000), (24, 8, 9000), (31, 32, 33000)])   # K <= 32: split kernels
 def test_diagonal_structure(engine, D, K, N):
     """mimo_set_structure(MIMO_STRUCT_DIAG): the 2 Dz + 1 feature kernels against the oracle with W = diag —
     tables, statistics (zero off-diagonal second moments), bound, labels; full W is rejected; switching back."""
