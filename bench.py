@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — E-step datapoint-component evaluations per second (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5|c1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment launches the N ranks itself (fresh child
+processes through torch.distributed.run on 127.0.0.1, before this process touches the GPU) and relays rank 0's JSON
+line, so both forms of the driver's command work.
 
 Workload (default c2 = BASELINE.json configs[1]): mean-field VB of a full-covariance GMM, N = 1e7 rows
 PER GPU (weak scaling), D = 16, K = 64, synthetic float64 data already resident in HBM.  One timed
-"step" is one complete VI iteration: the fused HIP pass over the data (log-densities -> softmax ->
-sufficient statistics -> ELBO terms; the (K,N) responsibilities never leave the GPU), the RCCL
-all-reduce of the statistic block when N > 1, the host conjugate update of all K posteriors and the
-ELBO.  value = (rows on all ranks x K) / max-over-ranks step time.
+"step" is one iteration of the PUBLIC driver loop (`BayesianMixtureOfGaussians.meanfield_iteration`, the body of
+`meanfield_coordinate_descent` with its defaults — including the reference's per-iteration
+likelihood.params = posterior.rvs()): host conjugate update of all K posteriors, the fused HIP pass over the data
+(log-densities -> softmax -> sufficient statistics -> ELBO terms; the (K,N) responsibilities never leave the GPU),
+the RCCL all-reduce of the statistic block when N > 1, the point-estimate draws and the ELBO's prior terms on the
+host while the kernel runs.  value = (rows on all ranks x K) / max-over-ranks step time.
 
 The JSON line also carries
-  roofline     : the fused kernel against the float64 matrix-core peak (HIP events around every launch
-                 on the launch stream, averaged over the timed steps; algorithmic flops of SURVEY.md §8(d))
+  roofline     : the dominant kernel against the float64 matrix-core peak (HIP events around every launch
+                 on the launch stream, averaged over the timed steps; algorithmic flops of SURVEY.md §8(d)),
+                 or against the HBM roof for the small-shape kernel (config c1)
   cpu_baseline : the NumPy restatement of the reference algorithm (oracle/, verified equal to the
-                 reference on golden vectors) timed on this box's host cores on a bounded row sample.
+                 reference on golden vectors) timed on this box's host cores on a bounded row sample
+  sustained    : the same step repeated for >= 3 s after the timed steps (median / min ms per step).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,6 +42,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB
 
 CONFIGS = {
     # name: (description, N per GPU, D (Dz), K, mode)
+    "c1": ("C1 shape at scale: the reference's own toy workload (examples/gmm/toy: 2-D, K=4 full-covariance GMM, "
+           "mean-field VB), N=1e7 per GPU — small-shape VALU kernel, HBM-bound", 10_000_000, 2, 4, "vi"),
     "c2": ("C2: mean-field VB GMM, N=1e7 per GPU, D=16, K=64, full covariance", 10_000_000, 16, 64, "vi"),
     "c3": ("C3: DP-GMM truncated stick-breaking Kmax=256, N=1e7 per GPU, D=8, Gibbs (Philox labels)",
            10_000_000, 8, 256, "gibbs"),
@@ -152,6 +163,48 @@ def cpu_baseline(cfg, X_host):
     return out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a distributed launcher: start the N ranks as children of a fresh
+    torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has touched the GPU (torch is not
+    even imported yet) and nothing is exec'ed: the launcher is a child process, its return code is ours."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)           # the JSON line is the last line of stdout
+    if p.returncode != 0 or not js:
+        raise SystemExit(p.returncode or 1)
+    raise SystemExit(0)
+
+
+def shader_clock_mhz(device_index):
+    """Current shader clock from sysfs (the '*' line of pp_dpm_sclk), or None."""
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if not cards:
+            return None
+        with open(cards[min(device_index, len(cards) - 1)]) as f:
+            for ln in f:
+                if "*" in ln:
+                    return float(ln.split(":")[1].strip().split("M")[0])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,25 +213,39 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--no-sample", action="store_true",
+                    help="drop the reference's per-iteration likelihood.params = posterior.rvs() (sample_likelihood=False)")
+    ap.add_argument("--dry-run-engine", default="",
+                    help="TEST HOOK (tests/test_bench_launch.py): 'module:Class' of an engine double; the ranks then run "
+                         "on the CPU over gloo, the JSON line is marked dry_run and carries no measurement")
     args = ap.parse_args()
 
-    import torch
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None and "RANK" not in os.environ:
+        self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dry = bool(args.dry_run_engine)
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    device = "cpu" if dry else f"cuda:{local_rank}"
     dist = None
     force_dist = os.environ.get("MIMO_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
-    from mimo_amd.engine import HipEngine
     from mimo_amd.sharded import ShardedEngine
 
     cfg = CONFIGS[args.config]
@@ -186,10 +253,17 @@ def main():
     if args.rows:
         N = args.rows
     X = make_data(N, D, K, seed=1337 + rank, device=device, ilr=(mode == "ilr"))
-    torch.cuda.synchronize()
-
-    hip = HipEngine(local_rank)                    # (own stream; ShardedEngine moves it onto the stream of its all-reduce)
-    hip.upload(X)                                  # borrows the device tensor (no copy)
+    if dry:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        mod, cls = args.dry_run_engine.split(":")
+        hip = getattr(importlib.import_module(mod), cls)()
+        hip.upload(X.numpy())
+    else:
+        from mimo_amd.engine import HipEngine
+        torch.cuda.synchronize()
+        hip = HipEngine(local_rank)                    # (own stream; ShardedEngine moves it onto the stream of its all-reduce)
+        hip.upload(X)                                  # borrows the device tensor (no copy)
     engine = ShardedEngine(hip, row_offset=rank * N) if dist is not None else hip
     if dist is not None:
         hip.set_row_offset(rank * N)
@@ -200,38 +274,34 @@ def main():
     S = engine.label_stats(labels0, K)
 
     param_rng = np.random.Generator(np.random.Philox(99))     # identical on every rank
+    sample = not args.no_sample
 
     def step(S, it):
+        """One iteration of the public driver loop (mixtures/gmm.py, ilr.py)."""
         if mode == "gibbs":
-            bs = S
-            model.components.resample(None, stats=_comp_stats(bs), rng=param_rng)
-            model.gating.resample(None, counts=bs.n)
-            _, S2 = engine.gibbs_labels(*model.likelihood.canonical(), seed=2024, sweep=it, stats=True,
-                                        return_labels=False)
+            _, S2 = model.gibbs_iteration(engine, S, it, label_rng='philox', seed=2024, param_rng=param_rng,
+                                          stats=True, return_labels=False)
             return S2, None
-        model._update_from_stats(S, sample=False)
-        if hasattr(engine, "estep_async"):       # same overlap as meanfield_coordinate_descent
-            engine.estep_async(*model.canonical_expected())
-            prior_terms = model._vlb_prior_terms()
-            S2, sc = engine.estep_wait()
-        else:
-            S2, sc = engine.estep(*model.canonical_expected())
-            prior_terms = model._vlb_prior_terms()
-        return S2, prior_terms + sc[0]
-
-    from mimo_amd.mixtures.gmm import _component_stats as _comp_stats
+        return model.meanfield_iteration(engine, S, sample_likelihood=sample)
 
     def barrier():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
+
+    def prof(on):
+        if hasattr(hip, "profile"):
+            hip.profile(on)
+            return hip.profile_read(reset=True)
+        return 0.0, 0
 
     vlb = []
     for it in range(args.warmup):
         S, v = step(S, it)
-    hip.profile(True)
-    hip.profile_read(reset=True)
+    prof(True)
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -239,51 +309,96 @@ def main():
         vlb.append(v)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = hip.profile_read(reset=True)
+    kernel_ms, launches = prof(True)
+    kinfo = hip.profile_kernels() if hasattr(hip, "profile_kernels") else {}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    sustained = None
+    if not args.no_sustained and not dry and dist is None:
+        # the same step for >= 3 s after the timed steps: a 20-launch burst says nothing about sustained FP64 clocks
+        ts, t_end, it = [], time.perf_counter() + 3.0, args.warmup + args.steps
+        clk0 = shader_clock_mhz(local_rank)
+        while time.perf_counter() < t_end or len(ts) < 5:
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            S, _ = step(S, it)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - a) * 1e3)
+            it += 1
+        sustained = {"seconds": float(np.sum(ts)) / 1e3, "steps": len(ts), "ms_per_step_median": float(np.median(ts)),
+                     "ms_per_step_min": float(np.min(ts)), "ms_per_step_last10_median": float(np.median(ts[-10:])),
+                     "shader_clock_mhz_before_after": [clk0, shader_clock_mhz(local_rank)]}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * N * K / (elapsed / args.steps)
         FE, FS = algorithmic_flops_per_eval(D, mode)
         flops_per_launch = N * K * FE + (N * K * FS if mode != "gibbs" else N * FS)
-        k_ms = kernel_ms / max(launches, 1)
-        achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
-        hbm_bytes = 8.0 * N * D + (4.0 * N if mode == "gibbs" else 0.0)
+        per_step = max(args.steps, 1)
+        k_ms = kernel_ms / per_step            # device time of ALL kernels of the pass, per step (HIP events on the launch stream)
+        achieved = flops_per_launch / (max(k_ms, 1e-9) * 1e-3) / 1e12
+        plan = hip.plan(K, gibbs=(mode == "gibbs")) if hasattr(hip, "plan") else {}
+        # algorithmic HBM bytes of one pass: the data once (+ labels written by a Gibbs pass and read back by an
+        # unfused statistics pass); a two-stage plan also writes the (K, N) table and reads it once per column group
+        data_bytes = 8.0 * N * D
+        hbm_bytes = data_bytes * max(1, plan.get("data_passes", 1)) + (4.0 * N * plan.get("label_passes", 1) if mode == "gibbs" else 0.0)
+        table_bytes = 8.0 * N * K * (1 + plan.get("table_reads", 0)) if plan.get("table_in_hbm") else 0.0
         out = {
             "metric": "E-step datapoint-component evals/sec",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": None if dry else value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "allreduce_bytes_per_step": (8 * (K * (1 + D + D * D) + 4)) if dist is not None else 0,
             "config": {"workload": desc, "rows_per_gpu": N, "Dz": D, "K": K,
-                       "step": "fused HIP pass (log-densities, softmax/label draw, sufficient statistics, ELBO terms)"
+                       "step": "one iteration of the public driver loop ("
+                               + ("gibbs_iteration" if mode == "gibbs" else "meanfield_iteration, sample_likelihood=%s" % sample)
+                               + "): host conjugate update of all K posteriors, HIP pass over the data (log-densities, "
+                                 "softmax/label draw, sufficient statistics, ELBO terms)"
                                + (", RCCL all-reduce of the statistic block" if world > 1 else "")
-                               + ", host conjugate update of all K posteriors",
-                       "resp_materialised_in_hbm": False, "parallelism": f"rows sharded over {world} GPU(s)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "mimo::fused_kernel", "kernel_ms": k_ms, "launches": launches,
-                         "flops_per_eval": {"estep": FE, "stats": FS},
-                         "hbm": {"algorithmic_bytes_per_launch": hbm_bytes,
-                                 "achieved_GBs": hbm_bytes / (k_ms * 1e-3) / 1e9,
-                                 "frac_of_8TBs": hbm_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-            "kernel_evals_per_s": N * K / (k_ms * 1e-3),
+                               + ", point-estimate draws + ELBO prior terms on the host while the kernel runs",
+                       "plan": plan,
+                       "resp_materialised_in_hbm": bool(plan.get("table_in_hbm", False)),
+                       "parallelism": f"rows sharded over {world} GPU(s)"},
+            "kernel_evals_per_s": N * K / (max(k_ms, 1e-9) * 1e-3),
         }
+        hbm_block = {"algorithmic_bytes_per_step": hbm_bytes, "table_bytes_per_step": table_bytes,
+                     "achieved_GBs": (hbm_bytes + table_bytes) / (max(k_ms, 1e-9) * 1e-3) / 1e9,
+                     "frac_of_8TBs": (hbm_bytes + table_bytes) / (max(k_ms, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if plan.get("kind") == "small":
+            # small-shape VALU kernel: bound by HBM (8 N Dz bytes per pass), not by the matrix pipe
+            out["roofline"] = {"bound": "hbm", "achieved": hbm_block["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": hbm_block["frac_of_8TBs"], "traffic": None, "kernel": "mimo::small_kernel",
+                               "kernel_ms": k_ms, "launches": launches,
+                               "algorithmic_bytes_per_launch": hbm_bytes,
+                               "f64_valu": {"flops_per_eval": {"estep": FE, "stats": FS}, "achieved_TFLOPs": achieved,
+                                            "frac_of_78.6": achieved / F64_MATRIX_PEAK_TFLOPS}}
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                               "kernel": plan.get("kernel", "mimo::fused_kernel"), "kernel_ms": k_ms,
+                               "launches": launches, "kernels_per_step": kinfo,
+                               "flops_per_eval": {"estep": FE, "stats": FS}, "hbm": hbm_block}
+        if dry:
+            out["dry_run"] = True
+            out["roofline"] = None
         try:     # HBM bytes per launch measured with rocprofv3 PMC counters for this workload (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 t = json.load(f).get(args.config)
-            if t and not args.rows:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_hbm_traffic.json"
+            if t and not args.rows and out["roofline"]:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_step"]
+                out["roofline"]["traffic_source"] = t.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/hbm_traffic.json")
         except Exception:
             pass
         if vlb and vlb[0] is not None:
             out["elbo_first_last"] = [float(vlb[0]), float(vlb[-1])]
-        if world == 1 and not args.no_cpu_baseline and mode == "vi":
+        if sustained:
+            out["sustained"] = sustained
+        if world == 1 and not args.no_cpu_baseline and mode == "vi" and not dry:
             out["cpu_baseline"] = cpu_baseline(cfg, X[:600_000].cpu().numpy())
         else:
             out["cpu_baseline"] = None

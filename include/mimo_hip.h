@@ -26,7 +26,9 @@
  *     into scalars[1], scalars[2] costs extra float64 work per (datum, component) and is only
  *     computed with MIMO_F_ENTROPY_SPLIT or any MIMO_F_KEEP_* flag (otherwise both are NaN).
  *   - every function returns 0 on success or a negative MIMO_E_* code; the message is
- *     available from mimo_last_error().  No C++ exception crosses this boundary.
+ *     available from mimo_last_error().  No C++ exception crosses this boundary: every entry point runs
+ *     inside a catch-all guard (std::bad_alloc -> MIMO_E_NOMEM, anything else -> MIMO_E_INTERNAL), and the
+ *     error message lives in a fixed buffer, so reporting a failure never allocates.
  *   - pointers are HOST pointers unless MIMO_F_DEVICE_OUT is set in `flags`, in which case the
  *     *output* pointers (S, scalars) are DEVICE pointers, nothing is copied to the host and the
  *     call returns without synchronising the context's stream (used by the multi-GPU driver,
@@ -51,6 +53,8 @@ typedef struct mimo_ctx mimo_ctx;
 #define MIMO_E_NODATA        -3   /* no data uploaded / attached                  */
 #define MIMO_E_UNSUPPORTED   -4   /* (K, Dz) outside the ranges the kernels cover */
 #define MIMO_E_STATE         -5   /* requested buffer was never produced          */
+#define MIMO_E_NOMEM         -6   /* host allocation failed inside the library    */
+#define MIMO_E_INTERNAL      -7   /* any other C++ exception, caught at the boundary */
 
 /* flags */
 #define MIMO_F_KEEP_RESP      0x01  /* keep the (K,N) responsibility table on the device          */
@@ -262,6 +266,14 @@ double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep);
  * dominant fused kernel since the last reset; enable with mimo_profile(ctx, 1). */
 int mimo_profile(mimo_ctx* ctx, int enable);
 int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset);
+
+/* Test hook for the no-exception contract: throws, INSIDE the guarded boundary, kind 1: std::bad_alloc,
+ * 2: std::runtime_error, 3: a non-std exception; returns the code the guard maps it to (MIMO_E_NOMEM,
+ * MIMO_E_INTERNAL, MIMO_E_INTERNAL) with the message in mimo_last_error(ctx) (ctx may be NULL).  kind 0: MIMO_OK.
+ * mimo_host_debug_fault does the same for the host-only entry points (mimo_host_*), kind 4 additionally makes
+ * a worker thread of the batched routines fail to start (the call then finishes on the threads that did). */
+int mimo_debug_fault(mimo_ctx* ctx, int kind);
+int mimo_host_debug_fault(int kind);
 
 /* Library version string. */
 const char* mimo_version(void);

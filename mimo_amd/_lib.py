@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
 
 # error codes / flags (mirror include/mimo_hip.h)
 OK = 0
-E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
+E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN, F_ENTROPY_SPLIT, F_ASYNC = 1, 2, 4, 8, 0x10, 0x20, 0x40, 0x80
 
 _dp = C.POINTER(C.c_double)
@@ -51,6 +51,8 @@ SIGNATURES = {
     "mimo_philox_uniform": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "mimo_profile": (C.c_int, [_vp, C.c_int]),
     "mimo_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.c_int]),
+    "mimo_debug_fault": (C.c_int, [_vp, C.c_int]),
+    "mimo_host_debug_fault": (C.c_int, [C.c_int]),
     "mimo_version": (C.c_char_p, []),
 }
 

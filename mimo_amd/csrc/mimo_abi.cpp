@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -21,7 +22,7 @@ struct mimo_ctx {
   int num_cu = 256;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  std::string err;
+  char err[512] = {0};   // fixed buffer: reporting an error never allocates
 
   // data
   const double* Z = nullptr;  // device
@@ -70,7 +71,7 @@ struct mimo_ctx {
   int64_t prof_n = 0;
 };
 
-static std::string g_err;
+static char g_err[512] = {0};
 
 // feature-tile row padding (doubles); MIMO_RS_PAD overrides for bank-conflict experiments
 static int rs_pad() {
@@ -102,8 +103,24 @@ static int fail(mimo_ctx* ctx, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (ctx) ctx->err = buf; else g_err = buf;
+  memcpy(ctx ? ctx->err : g_err, buf, sizeof buf);
   return code;
+}
+
+// Every extern "C" entry point runs inside this guard: no C++ exception crosses the boundary (include/mimo_hip.h).
+// std::bad_alloc (the std::vector staging buffers, the event list of the profiler) -> MIMO_E_NOMEM, anything else ->
+// MIMO_E_INTERNAL; the message goes to the fixed error buffer, so the handlers themselves cannot throw.
+template <typename F>
+static int guarded(mimo_ctx* ctx, F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, MIMO_E_NOMEM, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(ctx, MIMO_E_INTERNAL, "internal error: %s", e.what());
+  } catch (...) {
+    return fail(ctx, MIMO_E_INTERNAL, "internal error: unknown exception");
+  }
 }
 
 #define HIP_TRY(ctx, expr)                                                                \
@@ -369,6 +386,7 @@ extern "C" {
 const char* mimo_version(void) { return "mimo_hip 0.1 (gfx950, f64 MFMA feature-GEMM)"; }
 
 int mimo_create(mimo_ctx** out, int device) {
+  return guarded(nullptr, [&]() -> int {
   if (!out) return fail(nullptr, MIMO_E_INVALID, "mimo_create: out is NULL");
   *out = nullptr;
   int ndev = 0;
@@ -390,9 +408,11 @@ int mimo_create(mimo_ctx** out, int device) {
   ctx->stream = ctx->own_stream;
   *out = ctx;
   return MIMO_OK;
+  });
 }
 
 int mimo_destroy(mimo_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MIMO_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -405,15 +425,18 @@ int mimo_destroy(mimo_ctx* ctx) {
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return MIMO_OK;
+  });
 }
 
-const char* mimo_last_error(const mimo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char* mimo_last_error(const mimo_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 int mimo_set_stream(mimo_ctx* ctx, void* hip_stream) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return MIMO_OK;
+  });
 }
 
 static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
@@ -426,6 +449,7 @@ static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
 }
 
 int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (!Z_host && N > 0) return fail(ctx, MIMO_E_INVALID, "mimo_upload: Z is NULL");
   if ((rc = set_data(ctx, N, Dz))) return rc;
@@ -436,9 +460,11 @@ int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
   if (N > 0) HIP_TRY(ctx, hipMemcpy(ctx->Z_owned, Z_host, (size_t)N * Dz * sizeof(double), hipMemcpyHostToDevice));
   ctx->Z = ctx->Z_owned;
   return MIMO_OK;
+  });
 }
 
 int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (!Z_dev) return fail(ctx, MIMO_E_INVALID, "mimo_attach: Z is NULL");
   if ((rc = set_data(ctx, N, Dz))) return rc;
@@ -446,9 +472,11 @@ int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
   if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
   ctx->Z = Z_dev;
   return MIMO_OK;
+  });
 }
 
 int mimo_set_structure(mimo_ctx* ctx, int structure) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (structure != MIMO_STRUCT_FULL && structure != MIMO_STRUCT_DIAG && structure != MIMO_STRUCT_LINEAR)
     return fail(ctx, MIMO_E_INVALID, "mimo_set_structure: unknown structure %d", structure);
@@ -457,12 +485,15 @@ int mimo_set_structure(mimo_ctx* ctx, int structure) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the feature table may be in use
   ctx->structure = structure;
   return ctx->D > 0 ? prepare_features(ctx, ctx->D) : MIMO_OK;
+  });
 }
 
 int mimo_set_row_offset(mimo_ctx* ctx, int64_t row0) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   ctx->row0 = row0;
   return MIMO_OK;
+  });
 }
 
 static int keep_tables(mimo_ctx* ctx, int K, int flags, KernelArgs* a) {
@@ -485,6 +516,7 @@ static int keep_tables(mimo_ctx* ctx, int K, int flags, KernelArgs* a) {
 
 int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                int flags, double* S, double* scalars) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!c || !b || !W) return fail(ctx, MIMO_E_INVALID, "mimo_estep: c, b, W must be non-NULL");
@@ -499,10 +531,12 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   return run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
+  });
 }
 
 int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                         const double* row_weights, int flags, double* S, double* scalars) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!c || !b || !W || !row_weights) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: c, b, W, row_weights must be non-NULL");
@@ -527,9 +561,11 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
   if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   return run_fused(ctx, a, kSrcEstep, flags, S, scalars);
+  });
 }
 
 int mimo_wait(mimo_ctx* ctx, double* S, double* scalars) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (!ctx->pending_async) return fail(ctx, MIMO_E_STATE, "mimo_wait: no asynchronous call is pending");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,11 +576,13 @@ int mimo_wait(mimo_ctx* ctx, double* S, double* scalars) {
   }
   if (scalars) memcpy(scalars, ctx->S_h + ctx->pending_slen, 3 * sizeof(double));
   return MIMO_OK;
+  });
 }
 
 int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                       uint64_t seed, uint64_t sweep, const double* u, int flags,
                       int32_t* labels_out, double* S) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!c || !b || !W) return fail(ctx, MIMO_E_INVALID, "mimo_gibbs_labels: c, b, W must be non-NULL");
@@ -576,9 +614,11 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return MIMO_OK;
+  });
 }
 
 int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, double* S) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!S) return fail(ctx, MIMO_E_INVALID, "mimo_weighted_stats: S is NULL");
@@ -598,9 +638,11 @@ int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, dou
     a.resp = ctx->win;
   }
   return run_fused(ctx, a, kSrcWeights, flags, S, nullptr);
+  });
 }
 
 int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, double* S) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
   if (!S) return fail(ctx, MIMO_E_INVALID, "mimo_label_stats: S is NULL");
@@ -619,9 +661,11 @@ int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, dou
     a.labels = ctx->lin;
   }
   return run_fused(ctx, a, kSrcLabels, flags, S, nullptr);
+  });
 }
 
 int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int flags, double* out) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (!out || count < 0) return fail(ctx, MIMO_E_INVALID, "mimo_table_entropy: bad arguments");
   const double* src = table;
@@ -642,12 +686,14 @@ int mimo_table_entropy(mimo_ctx* ctx, const double* table, int64_t count, int fl
   HIP_TRY(ctx, hipMemcpyAsync(out, ctx->reduced, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIMO_OK;
+  });
 }
 
 int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                  const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
                  const double* y, const double* P, const double* ld,
                  double* mu, double* covar, double* nlpd) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "mimo_predict: no data resident (call mimo_upload)");
   if (!c || !b || !W || !M || !Q || !Cc || !mu || !covar || K < 1 || (mode != 0 && mode != 1))
@@ -697,6 +743,7 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIMO_OK;
+  });
 }
 
 static int copy_out(mimo_ctx* ctx, void* dst, const void* src, size_t bytes, bool valid, const char* what) {
@@ -709,20 +756,37 @@ static int copy_out(mimo_ctx* ctx, void* dst, const void* src, size_t bytes, boo
 }
 
 int mimo_get_resp(mimo_ctx* ctx, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   return copy_out(ctx, out, ctx->resp, (size_t)ctx->resp_K * ctx->N * sizeof(double), ctx->resp_valid, "mimo_get_resp");
+  });
 }
 int mimo_get_logp(mimo_ctx* ctx, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   return copy_out(ctx, out, ctx->logp, (size_t)ctx->logp_K * ctx->N * sizeof(double), ctx->logp_valid, "mimo_get_logp");
+  });
 }
 int mimo_get_lse(mimo_ctx* ctx, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   return copy_out(ctx, out, ctx->lse, (size_t)ctx->N * sizeof(double), ctx->lse_valid, "mimo_get_lse");
+  });
 }
 int mimo_get_labels(mimo_ctx* ctx, int32_t* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   return copy_out(ctx, out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), ctx->labels_valid, "mimo_get_labels");
+  });
+}
+
+int mimo_debug_fault(mimo_ctx* ctx, int kind) {
+  return guarded(ctx, [&]() -> int {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::runtime_error("mimo_debug_fault");
+    if (kind == 3) throw 42;
+    return kind == 0 ? MIMO_OK : fail(ctx, MIMO_E_INVALID, "mimo_debug_fault: unknown kind %d", kind);
+  });
 }
 
 double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep) {
@@ -730,18 +794,22 @@ double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep) {
 }
 
 int mimo_profile(mimo_ctx* ctx, int enable) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   ctx->prof = enable != 0;
   return MIMO_OK;
+  });
 }
 
 int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset) {
+  return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   drain_profile(ctx);
   if (kernel_ms) *kernel_ms = ctx->prof_ms;
   if (launches) *launches = ctx->prof_n;
   if (reset) { ctx->prof_ms = 0.0; ctx->prof_n = 0; }
   return MIMO_OK;
+  });
 }
 
 }  // extern "C"

@@ -7,8 +7,12 @@
 //
 // Reference semantics: mimo/distributions/composite.py:50-72,106-118 (Normal-Wishart),
 // :577-599,635-647 (Matrix-Normal-Wishart), wishart.py:139-143, bayesian.py:287-301,933-947.
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -100,8 +104,27 @@ double expected_logdet(double nu, int D, double half_logdet_psi) {   // wishart.
   return s + D * kLog2 + 2.0 * half_logdet_psi;
 }
 
+// Guard of the host-only entry points (no context, no message buffer): see mimo_abi.cpp.
+template <typename F>
+int guarded_host(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return MIMO_E_NOMEM;
+  } catch (...) {
+    return MIMO_E_INTERNAL;
+  }
+}
+
+std::atomic<int> g_fail_thread_start{0};   // mimo_host_debug_fault(4): the next helper-thread start throws
+
 // body(k0, count, work, Cbuf) handles components k0 .. k0+count-1 (count <= 4) with per-thread scratch
-// (work: 2 n n v4d, Cbuf: 4 n n doubles) and returns false on a non-SPD block
+// (work: 2 n n v4d, Cbuf: 4 n n doubles) and returns false on a non-SPD block.
+// The groups are handed out through one counter, so the call completes on however many threads did start: a
+// helper that cannot be created (std::system_error) or cannot allocate its scratch leaves its share to the
+// others, and every thread that was started is joined before the function returns or rethrows — a joinable
+// std::thread is never destroyed (that would be std::terminate).  Groups are independent, so the result does
+// not depend on which thread ran which group.
 template <typename F>
 int for_component_groups(int K, int n, double work_per_component, F&& body) {
   const int G = (K + 3) / 4;
@@ -111,23 +134,35 @@ int for_component_groups(int K, int n, double work_per_component, F&& body) {
     const double want = work_per_component * G / 2.5e5;
     nt = (int)std::min<double>(std::min<double>(hc ? hc : 1, 8), std::min<double>(G, want));
     if (nt < 1) nt = 1;
+    if (g_fail_thread_start.load() && nt < 2 && G >= 2) nt = 2;   // the test hook wants a helper to fail
   }
-  std::vector<int> bad((size_t)nt, 0);
-  auto run = [&](int t) {
-    std::vector<v4d> work((size_t)2 * n * n);
-    std::vector<double> Cbuf((size_t)4 * n * n);
-    for (int g = t; g < G; g += nt)
-      if (!body(4 * g, std::min(4, K - 4 * g), work.data(), Cbuf.data())) bad[t] = 1;
+  std::atomic<int> next{0}, bad{0}, processed{0};
+  auto run = [&]() noexcept {
+    try {
+      std::vector<v4d> work((size_t)2 * n * n);
+      std::vector<double> Cbuf((size_t)4 * n * n);
+      for (int g; (g = next.fetch_add(1)) < G;) {
+        if (!body(4 * g, std::min(4, K - 4 * g), work.data(), Cbuf.data())) bad.store(1);
+        processed.fetch_add(1);
+      }
+    } catch (...) {
+      // scratch allocation failed on this thread: the others take its groups (none processed here)
+    }
   };
-  if (nt == 1) run(0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(run, t);
-    run(0);
-    for (auto& x : th) x.join();
+  std::vector<std::thread> th;
+  try {
+    th.reserve((size_t)(nt > 1 ? nt - 1 : 0));
+    for (int t = 1; t < nt; ++t) {
+      if (g_fail_thread_start.exchange(0)) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+      th.emplace_back(run);
+    }
+  } catch (...) {
+    // fewer helpers than planned (or none): the calling thread picks the remaining groups up below
   }
-  for (int v : bad) if (v) return MIMO_E_INVALID;
-  return MIMO_OK;
+  run();
+  for (auto& x : th) x.join();
+  if (processed.load() != G) return MIMO_E_NOMEM;   // no thread could allocate its scratch
+  return bad.load() ? MIMO_E_INVALID : MIMO_OK;
 }
 
 }  // namespace
@@ -137,6 +172,7 @@ extern "C" {
 int mimo_host_nw_vi(int K, int D, const double* a, const double* b, const double* c, const double* d,
                     double* mus, double* psis, double* nus, double* half_logdet_psi,
                     double* cc, double* bb, double* W, double* E2, double* E4) {
+  return guarded_host([&]() -> int {
   if (K < 1 || D < 1 || !a || !b || !c || !d || !mus || !psis || !nus || !half_logdet_psi || !cc || !bb || !W ||
       !E2 || !E4)
     return MIMO_E_INVALID;
@@ -183,11 +219,13 @@ int mimo_host_nw_vi(int K, int D, const double* a, const double* b, const double
     }
     return ok;
   });
+  });
 }
 
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {
+  return guarded_host([&]() -> int {
   if (K < 1 || dy < 1 || dc < 1 || (affine && dc < 2) || !a || !b || !c || !d || !Ms || !psis || !nus ||
       !half_logdet_psi || !Kinv || !cc || !bb || !W || !E1 || !E2 || !E4)
     return MIMO_E_INVALID;
@@ -279,11 +317,13 @@ int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const d
     }
     return ok;
   });
+  });
 }
 
 int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, const double* psis,
                        const double* z, const double* g, const double* eps,
                        double* out_mu, double* out_lmbda, double* out_c, double* out_b) {
+  return guarded_host([&]() -> int {
   if (K < 1 || D < 1 || D > 64) return MIMO_E_INVALID;
   const int nt = D * (D - 1) / 2;
   std::vector<double> Lb((size_t)D * D), Tb((size_t)D * D);
@@ -345,8 +385,19 @@ int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, co
     out_c[k] = -0.5 * quad + sld - 0.5 * D * kLog2Pi;
   }
   return MIMO_OK;
+  });
 }
 
 double mimo_host_digamma(double x) { return digamma(x); }
+
+int mimo_host_debug_fault(int kind) {
+  return guarded_host([&]() -> int {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::runtime_error("mimo_host_debug_fault");
+    if (kind == 3) throw 42;
+    if (kind == 4) { g_fail_thread_start.store(1); return MIMO_OK; }
+    return kind == 0 ? MIMO_OK : MIMO_E_INVALID;
+  });
+}
 
 }  // extern "C"

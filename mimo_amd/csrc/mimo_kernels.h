@@ -98,6 +98,7 @@ struct PredictArgs {
 };
 constexpr int kMaxPredictDy = 8;
 constexpr double kPadLogDensity = -1e300;   // c_k of the padding components k in [K, 16*K16)
+constexpr double kOffLogDensity = -1e299;   // l below this: a padding or switched-off component (its l is -1e300 to the last bit)
 hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupported);
 
 }  // namespace mimo

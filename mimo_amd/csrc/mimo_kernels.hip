@@ -274,7 +274,9 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          if constexpr (MODE == kGeneric) lsave[c] = (c < CPP && k0 + c < K) ? x[c] : 0.0;
+          // (a component switched off by c_k = -inf carries l = -1e300: its e is exp(-707) = 8e-308, not 0, and
+          // e * l would add -8e-8 per datum to sum_k r l — its term is 0 * (-inf) := 0, like the padding's)
+          if constexpr (MODE == kGeneric) lsave[c] = (c < CPP && k0 + c < K && x[c] > kOffLogDensity) ? x[c] : 0.0;
           x[c] = exp_nonpos(x[c] - m, etab);              // masked / padding slots -> 0
         }
         double sel = 0.0;
@@ -441,7 +443,8 @@ __device__ __forceinline__ void normalise_tile_chunked(const KernelArgs& a, doub
       if constexpr (MODE == kGeneric) {
         double t[8];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) t[cc] = x[cc] * (active(8 * ch + cc) ? lc[cc] : 0.0);
+        for (int cc = 0; cc < 8; ++cc)     // (switched-off components: see normalise_tile)
+          t[cc] = x[cc] * ((active(8 * ch + cc) && lc[cc] > kOffLogDensity) ? lc[cc] : 0.0);
         selv[ch] = tree_sum8(t);
       }
 #pragma unroll

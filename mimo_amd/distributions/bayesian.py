@@ -48,6 +48,12 @@ class _CategoricalWrapper:
     def variational_lowerbound(self):
         return self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
 
+    def refresh_likelihood(self):
+        """The draw meanfield_update(sample=True) ends with (bayesian.py:73-76 / 150-152 of the reference), as a
+        step of its own: the mean-field drivers issue it AFTER the next data pass has been launched — the pass reads
+        the posterior, never the drawn point estimate — so the host draws overlap the kernel."""
+        self.likelihood.params = self.posterior.rvs()
+
     def expected_log_likelihood(self):
         return self.posterior.expected_statistics()
 
@@ -132,6 +138,11 @@ class _ConjugateBlock:
 
     def log_marginal_likelihood(self):
         return self.posterior.log_partition() - self.prior.log_partition()
+
+    def refresh_likelihood(self):
+        """likelihood.params = posterior.rvs() — the tail of meanfield_update(sample=True) (bayesian.py:225-230,
+        864-869 of the reference) as a separate step, see _CategoricalWrapper.refresh_likelihood."""
+        self.likelihood.params = self.posterior.rvs()
 
 
 class StackedGaussiansWithNormalWisharts(_ConjugateBlock):

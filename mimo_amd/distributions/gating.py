@@ -40,33 +40,38 @@ class Categorical:
         return npr.choice(a=self.dim, p=self.probs, size=size)          # categorical.py:32
 
     def statistics(self, data):
-        """categorical.py:35-39 (counts of integer labels)."""
+        """Label counts, one per class (categorical.py:35-39).  A list of label arrays is pooled."""
         if isinstance(data, np.ndarray):
             return np.bincount(data, minlength=self.dim)
-        return sum(list(map(self.statistics, data)))
+        total = np.zeros(self.dim, dtype=np.int64)
+        for part in data:
+            total = total + self.statistics(part)
+        return total
 
     def weighted_statistics(self, data, weights):
-        """categorical.py:41-46 — sum_n r_kn.  `weights` may already be the (K,) count vector the
-        engine produced (the drivers' path); a (K,N) table is reduced as in the reference."""
+        """sum_n r_kn (categorical.py:41-46).  `data` is unused, as in the reference; `weights` is either the
+        (K,) vector of counts the engine already reduced (what the drivers pass) or a (K,N) table, or a list
+        of such tables whose sums are pooled."""
         if isinstance(weights, np.ndarray):
-            if weights.ndim == 1:
-                return weights
-            return np.sum(np.atleast_2d(weights), axis=1)
-        data = data if data else [None] * len(weights)
-        return sum(list(map(self.weighted_statistics, data, weights)))
+            return weights if weights.ndim == 1 else np.atleast_2d(weights).sum(axis=1)
+        total = np.zeros(self.dim)
+        for table in weights:
+            total = total + self.weighted_statistics(None, table)
+        return total
 
     def log_likelihood(self, x):
-        """categorical.py:51-59"""
-        log_lik = np.zeros_like(x, dtype=np.double)
-        err = np.seterr(invalid='ignore', divide='ignore')
-        bads = np.isnan(x)
-        log_lik[~bads] = np.log(self.probs)[list(x[~bads])]
-        np.seterr(**err)
-        return log_lik
+        """log probs[x_n]; NaN labels score 0 (categorical.py:51-59)."""
+        x = np.asarray(x)
+        known = ~np.isnan(x)
+        out = np.zeros(x.shape, dtype=np.double)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out[known] = np.log(self.probs)[x[known].astype(np.intp)]
+        return out
 
     def max_likelihood(self, data, weights=None):
-        counts = self.statistics(data) if weights is None else self.weighted_statistics(data, weights)
-        self.probs = counts / counts.sum()
+        """probs = normalised counts (categorical.py:65-68)."""
+        n = self.statistics(data) if weights is None else self.weighted_statistics(data, weights)
+        self.probs = n / np.sum(n)
 
 
 class Dirichlet:

@@ -200,9 +200,12 @@ _joint_cache = {}
 
 
 def joint_rows(x, y):
-    """z = [x, y] as one C-contiguous (N, dx+dy) array; the same (x, y) pair maps to the same z
-    object so that the engine's identity-based binding recognises it across calls."""
-    key = (x.__array_interface__['data'][0], y.__array_interface__['data'][0], x.shape, y.shape)
+    """z = [x, y] as one C-contiguous (N, dx+dy) array; the same (x, y) pair WITH THE SAME CONTENT maps to the
+    same z object so that the engine's binding recognises it across calls (an in-place edit of x or y changes
+    the fingerprint and a fresh z is stacked)."""
+    from mimo_amd.engine import content_fingerprint
+    key = (x.__array_interface__['data'][0], y.__array_interface__['data'][0], x.shape, y.shape,
+           content_fingerprint(x), content_fingerprint(y))
     hit = _joint_cache.get('last')
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -77,6 +77,15 @@ class HipEngine:
         except Exception:
             pass
 
+    def spawn(self):
+        """A second, independent engine on the same device (own context, stream and resident data): the SVI
+        drivers keep the full data set on one and push minibatches through the other."""
+        return HipEngine(self.device)
+
+    def global_rows(self, n_local):
+        """Rows over all shards for `n_local` rows here (one GPU: itself; ShardedEngine sums over the ranks)."""
+        return int(n_local)
+
     def set_stream(self, stream_ptr):
         self._check(self._lib.mimo_set_stream(self._ctx, C.c_void_p(stream_ptr or 0)))
 
@@ -369,14 +378,37 @@ def philox_uniforms(seed, rows, sweep):
 # data binding used by the reference-shaped array methods (log_likelihood(x), weighted_statistics
 # (x, w), ...): the array last bound stays resident, so passing the SAME array again costs nothing.
 # ---------------------------------------------------------------------------------------------
+_FULL_HASH_BYTES = 1 << 21       # arrays up to 2 MB are fingerprinted in full
+_SAMPLE_ELEMS = 8192
+
+
+def content_fingerprint(Z):
+    """Cheap fingerprint of an array's CONTENT, so that an in-place edit between two calls (centring, whitening,
+    a reused buffer filled with the next data set — the reference re-reads its arguments on every call, and itself
+    edits caller arrays in place, gaussian.py:513) is seen and the device copy refreshed.  Small arrays (<= 2 MB):
+    CRC of every byte.  Large arrays: CRC of ~8192 evenly strided elements plus the first and last rows — O(1),
+    catches every edit that touches the whole array or a contiguous block of it, not a change of a few isolated
+    elements (call engine.unbind() after such a surgical edit)."""
+    import zlib
+    Z = np.asarray(Z)
+    if Z.nbytes <= _FULL_HASH_BYTES:
+        return zlib.crc32(np.ascontiguousarray(Z).view(np.uint8).reshape(-1))
+    flat = Z.reshape(-1) if Z.flags.c_contiguous else Z.ravel()
+    step = max(1, flat.shape[0] // _SAMPLE_ELEMS)
+    h = zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8))
+    h = zlib.crc32(np.ascontiguousarray(Z[0]).view(np.uint8).reshape(-1), h)
+    return zlib.crc32(np.ascontiguousarray(Z[-1]).view(np.uint8).reshape(-1), h)
+
+
 def _bind_key(Z):
-    return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str)
+    return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str, content_fingerprint(Z))
 
 
 def bind(engine, Z, structure='full'):
-    """Make `Z` ((N,Dz) float64 host array) the engine's resident data set, uploading it only if it
-    is not the array bound last (identity = address + shape; in-place edits need engine.unbind()), and
-    select the structure of the precision blocks the caller is going to pass."""
+    """Make `Z` ((N,Dz) float64 host array) the engine's resident data set, uploading it only if it is not the
+    array bound last — identity = address + shape + a content fingerprint (`content_fingerprint`), so an in-place
+    edit of the bound array re-uploads it and drops the cached sum z z' — and select the structure of the
+    precision blocks the caller is going to pass."""
     if hasattr(engine, 'set_structure'):
         engine.set_structure(structure)
     Z = np.asarray(Z)
@@ -384,7 +416,7 @@ def bind(engine, Z, structure='full'):
         Z = Z.reshape(-1, 1)
     key = _bind_key(Z)
     if getattr(engine, "_bound_key", None) != key:
-        engine.upload(Z)
+        engine.upload(Z)                 # (also invalidates the cached pooled second moment)
         engine._bound_key = key
         engine._bound_ref = Z        # keeps the address from being recycled
     return engine

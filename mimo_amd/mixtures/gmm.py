@@ -240,15 +240,21 @@ class BayesianMixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'Init #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for it in range(maxiter):
-                self.components.resample(None, stats=_component_stats(S, self.components), rng=param_rng)
-                self.gating.resample(None, counts=S.n)
                 last = it == maxiter - 1
-                labels, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last,
-                                              return_labels=last)
+                labels, S = self.gibbs_iteration(eng, S, it + 1, label_rng, seed, param_rng, stats=not last,
+                                                 return_labels=last)
                 pbar.update(1)
         self.labels_ = labels
 
     resample_model = resample      # pybasicbayes-era name used by BASELINE.json's north star
+
+    def gibbs_iteration(self, eng, S, sweep, label_rng='host', seed=0, param_rng=None, stats=True,
+                        return_labels=False):
+        """One sweep of `resample` (gmm.py:217-223): components and gating from the statistics `S` of the labels
+        drawn last, then the label pass.  Returns (labels | None, S' | None)."""
+        self.components.resample(None, stats=_component_stats(S, self.components), rng=param_rng)
+        self.gating.resample(None, counts=S.n)
+        return self._draw_labels(eng, label_rng, seed, sweep, stats=stats, return_labels=return_labels)
 
     def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
         c, b, W = self.likelihood.canonical()
@@ -305,19 +311,38 @@ class BayesianMixtureOfGaussians:
         with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
-                self._update_from_stats(S, sample_likelihood)
-                if hasattr(eng, "estep_async"):      # ELBO prior terms computed while the data pass runs
-                    eng.estep_async(*self.canonical_expected())
-                    prior_terms = self._vlb_prior_terms()
-                    S, sc = eng.estep_wait()
-                else:
-                    S, sc = eng.estep(*self.canonical_expected())
-                    prior_terms = self._vlb_prior_terms()
-                vlb.append(prior_terms + sc[0])
+                S, bound = self.meanfield_iteration(eng, S, sample_likelihood)
+                vlb.append(bound)
                 if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
                     return vlb
                 pbar.update(1)
         return vlb
+
+    def meanfield_iteration(self, eng, S, sample_likelihood=True):
+        """One iteration of the coordinate descent (gmm.py:275-285): conjugate update from the statistics `S` of
+        the previous data pass, the next fused pass, the bound.  Returns (S', ELBO).
+
+        The reference draws likelihood.params = posterior.rvs() inside meanfield_update (bayesian.py:225-230): K
+        Bartlett draws, 2.6 ms at K = 64, D = 16.  The next E-step reads the posterior only, so the pass is launched
+        first and the draws (same numpy.random call order: components, then gating) and the bound's prior terms run
+        on the host while the kernel is in flight."""
+        self._update_from_stats(S, sample=False)
+        if hasattr(eng, "estep_async"):
+            eng.estep_async(*self.canonical_expected())
+            if sample_likelihood:
+                self._refresh_likelihoods()
+            prior_terms = self._vlb_prior_terms()
+            S, sc = eng.estep_wait()
+        else:
+            S, sc = eng.estep(*self.canonical_expected())
+            if sample_likelihood:
+                self._refresh_likelihoods()
+            prior_terms = self._vlb_prior_terms()
+        return S, prior_terms + sc[0]
+
+    def _refresh_likelihoods(self):
+        self.components.refresh_likelihood()
+        self.gating.refresh_likelihood()
 
     def _update_from_stats(self, S, sample=True):
         self.components.meanfield_update(None, stats=_component_stats(S, self.components), sample=sample)
@@ -345,10 +370,12 @@ class BayesianMixtureOfGaussians:
         obs = np.asarray(obs, dtype=float).reshape(-1, self.dim)
         eng = self._bind(obs)
         if self._batch_engine is None:
-            self._batch_engine = type(eng)(eng.device) if hasattr(eng, "device") else eng.spawn()
+            self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
         vlb = []
-        scale = batch_size / float(len(obs))
+        # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
+        # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
+        scale = eng.global_rows(batch_size) / float(eng.global_rows(len(obs)))
         with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
                   disable=not progress_bar) as pbar:
             for i in range(maxiter):

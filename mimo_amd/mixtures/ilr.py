@@ -255,19 +255,35 @@ class BayesianMixtureOfLinearGaussians:
         with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
-                self._update_from_stats(S, sample_likelihood)
-                if hasattr(eng, "estep_async"):      # ELBO prior terms computed while the data pass runs
-                    eng.estep_async(*self.canonical_expected())
-                    prior_terms = self._vlb_prior_terms()
-                    S, sc = eng.estep_wait()
-                else:
-                    S, sc = eng.estep(*self.canonical_expected())
-                    prior_terms = self._vlb_prior_terms()
-                vlb.append(prior_terms + sc[0])
+                S, bound = self.meanfield_iteration(eng, S, sample_likelihood)
+                vlb.append(bound)
                 if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
                     return vlb
                 pbar.update(1)
         return vlb
+
+    def meanfield_iteration(self, eng, S, sample_likelihood=True):
+        """One iteration of the coordinate descent (ilr.py:211-226): returns (S', ELBO).  The point-estimate draws
+        the reference makes inside meanfield_update (basis, models, gating — in that order) run after the next
+        pass has been launched, like the bound's prior terms: the pass only reads the posteriors."""
+        self._update_from_stats(S, sample=False)
+        if hasattr(eng, "estep_async"):
+            eng.estep_async(*self.canonical_expected())
+            if sample_likelihood:
+                self._refresh_likelihoods()
+            prior_terms = self._vlb_prior_terms()
+            S, sc = eng.estep_wait()
+        else:
+            S, sc = eng.estep(*self.canonical_expected())
+            if sample_likelihood:
+                self._refresh_likelihoods()
+            prior_terms = self._vlb_prior_terms()
+        return S, prior_terms + sc[0]
+
+    def _refresh_likelihoods(self):
+        self.basis.refresh_likelihood()
+        self.models.refresh_likelihood()
+        self.gating.refresh_likelihood()
 
     def _update_from_stats(self, S, sample=True):
         bstats, mstats = self._block_stats(S)
@@ -300,10 +316,12 @@ class BayesianMixtureOfLinearGaussians:
         eng = self._bind(xx, yy)
         zz = joint_rows(xx, yy)
         if self._batch_engine is None:
-            self._batch_engine = type(eng)(eng.device) if hasattr(eng, "device") else eng.spawn()
+            self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
         vlb = []
-        scale = batch_size / float(len(xx))
+        # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
+        # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
+        scale = eng.global_rows(batch_size) / float(eng.global_rows(len(xx)))
         with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
                   disable=not progress_bar) as pbar:
             for i in range(maxiter):

@@ -59,8 +59,20 @@ class ShardedEngine:
         self.inner.set_row_offset(self._row0)
 
     def spawn(self):
-        return ShardedEngine(self.inner.spawn() if hasattr(self.inner, "spawn") else type(self.inner)(self.device),
-                             self.group, self._row0)
+        """A second sharded engine over the same ranks (the SVI minibatch engine): its statistics are all-reduced
+        like the main one's, so a minibatch is the union of the ranks' local draws."""
+        return ShardedEngine(self.inner.spawn(), self.group, self._row0)
+
+    def global_rows(self, n_local):
+        """sum over the ranks of `n_local` (cached per value: one scalar all-reduce)."""
+        cache = self.__dict__.setdefault('_rows_cache', {})
+        if n_local not in cache:
+            cache[n_local] = int(round(float(self._allreduce_array(np.array([float(n_local)]))[0])))
+        return cache[n_local]
+
+    def predict(self, *args, **kwargs):
+        """Posterior-predictive moments are row-local: every rank predicts its own rows, nothing is exchanged."""
+        return self.inner.predict(*args, **kwargs)
 
     def get_resp(self, K=None):
         return self.inner.get_resp(K)

@@ -24,6 +24,9 @@ class OracleEngine:
     def spawn(self):
         return OracleEngine()
 
+    def global_rows(self, n_local):
+        return int(n_local)
+
     def upload(self, Z):
         self.Z = np.ascontiguousarray(Z, dtype=float)
         self.N, self.D = self.Z.shape

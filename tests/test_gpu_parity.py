@@ -412,6 +412,22 @@ def test_switched_off_component_and_far_clusters(engine):
     assert abs(sc[0] - lse.sum()) < 1e-11 * abs(lse.sum()) and np.all(np.isfinite(S.sxx))
     Rg = engine.get_resp(K)
     assert np.abs(Rg - R).max() < 1e-14 and Rg[5].max() < 1e-300 and S.n[5] < 1e-290
+    # entropy split with the switched-off component: sum r l counts 0 for it (it used to add exp(-707) * -1e300 =
+    # -8e-8 per datum), here with few far clusters so that the terms are not swamped, and on the chunked normalise (K > 64)
+    with np.errstate(invalid='ignore'):
+        srl = float(np.nansum(np.where(R > 0, R * L, 0.)))
+    _, sc2 = engine.estep(c, b, W, entropy_split=True)
+    assert abs(sc2[1] - srl) < 1e-11 * abs(srl) and abs(sc2[2] - (lse.sum() - srl)) < 1e-9 * max(1., abs(lse.sum() - srl))
+    K2 = 70
+    c3, b3, W3 = (np.concatenate([v, v[:K2 - K]]) for v in (c, b, W))
+    with np.errstate(invalid='ignore'):
+        L3 = O.canonical_eval(Z, c3, b3, W3)
+    L3[5] = -np.inf
+    lse3 = logsumexp(L3, axis=0)
+    R3 = np.exp(L3 - lse3)
+    srl3 = float(np.nansum(np.where(R3 > 0, R3 * L3, 0.)))
+    _, sc3 = engine.estep(c3, b3, W3, entropy_split=True)
+    assert abs(sc3[0] - lse3.sum()) < 1e-11 * abs(lse3.sum()) and abs(sc3[1] - srl3) < 1e-11 * abs(srl3)
     labels, Sg = engine.gibbs_labels(c, b, W, seed=9, sweep=4)
     ref = O.sample_discrete_from_log(L, O.philox_uniforms(9, np.arange(N), 4))
     assert np.array_equal(labels, ref) and not np.any(labels == 5)

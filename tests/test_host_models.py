@@ -89,3 +89,37 @@ def test_batched_samplers_match_the_reference_law():
     # both against the exact law: cov(vec A) = E[Lambda^-1] (x) K^-1, E[Lambda^-1] = psi^-1 / (nu - dy - 1)
     exact = np.kron(np.eye(dy) / (6. - dy - 1.), np.linalg.inv(Kc))
     assert np.allclose(cf, exact, rtol=0.2, atol=0.02) and np.allclose(cr, exact, rtol=0.2, atol=0.02)
+
+
+def test_bind_sees_in_place_edits():
+    """engine.bind() keys the resident copy on address + shape + a content fingerprint: editing the bound array in
+    place (the reference re-reads its arguments on every call) uploads it again; an untouched array is not re-sent."""
+    import numpy as np
+    from mimo_amd import engine as E
+    from mimo_amd.distributions.lingauss import joint_rows
+
+    class Counting(OracleEngine):
+        uploads = 0
+
+        def upload(self, Z):
+            Counting.uploads += 1
+            super().upload(np.array(Z, copy=True))       # a device copy would not follow host edits either
+
+    rng = np.random.default_rng(0)
+    for shape in ((500, 3), (400_000, 2)):               # fully hashed / strided-sample fingerprint
+        eng, X = Counting(), rng.standard_normal(shape)
+        Counting.uploads = 0
+        E.bind(eng, X); E.bind(eng, X)
+        assert Counting.uploads == 1
+        X -= X.mean(axis=0)                               # centring in place
+        E.bind(eng, X)
+        assert Counting.uploads == 2 and np.array_equal(eng.Z, X)
+        X[len(X) // 3: 2 * len(X) // 3] = 0.              # a contiguous block overwritten
+        E.bind(eng, X)
+        assert Counting.uploads == 3 and np.array_equal(eng.Z, X)
+    x, y = rng.standard_normal((300, 2)), rng.standard_normal((300, 1))
+    z0 = joint_rows(x, y)
+    assert joint_rows(x, y) is z0
+    y *= 2.
+    z1 = joint_rows(x, y)
+    assert z1 is not z0 and np.array_equal(z1[:, 2:], y)

@@ -187,3 +187,48 @@ def test_gibbs_step_hands_the_canonical_form_to_the_likelihood():
     c3, _, _ = comp.likelihood.canonical()
     assert rel_err(c3, StackedGaussiansWithPrecision(K, D, comp.likelihood.mus, comp.likelihood.lmbdas).canonical()[0]) < 1e-14
     assert np.abs(c3 - c).max() > 1e-3
+
+
+def test_no_exception_crosses_the_c_boundary():
+    """include/mimo_hip.h: every entry point runs inside a catch-all guard.  The fault hooks throw INSIDE the guarded
+    boundary (an allocation failure, a std exception, a non-std exception); the call must come back with an error
+    code and a message instead of unwinding through ctypes (which would abort the interpreter)."""
+    lib = _lib.load()
+    assert lib.mimo_debug_fault(None, 0) == _lib.OK
+    assert lib.mimo_debug_fault(None, 1) == _lib.E_NOMEM
+    assert b"out of host memory" in lib.mimo_last_error(None)
+    assert lib.mimo_debug_fault(None, 2) == _lib.E_INTERNAL
+    assert b"mimo_debug_fault" in lib.mimo_last_error(None)
+    assert lib.mimo_debug_fault(None, 3) == _lib.E_INTERNAL
+    assert b"unknown exception" in lib.mimo_last_error(None)
+    assert lib.mimo_host_debug_fault(1) == _lib.E_NOMEM
+    assert lib.mimo_host_debug_fault(2) == _lib.E_INTERNAL
+    assert lib.mimo_host_debug_fault(3) == _lib.E_INTERNAL
+
+
+def test_a_helper_thread_that_cannot_start_does_not_lose_work():
+    """for_component_groups hands the component groups out through one counter: when a helper thread cannot be
+    created the call finishes on the threads that did start, with the same numbers."""
+    lib = _lib.load()
+    K, D = 96, 24                       # enough work for helper threads
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((K, D, D))
+    kappas = rng.uniform(0.5, 200., K)
+    mus = rng.standard_normal((K, D))
+    nat = [kappas[:, None] * mus, kappas, A @ A.transpose(0, 2, 1) + D * np.eye(D)
+           + kappas[:, None, None] * np.einsum('kd,kl->kdl', mus, mus), rng.uniform(1., 5000., K)]
+    old = composite.NATIVE_HOST
+    composite.NATIVE_HOST = True
+    try:
+        ref = StackedNormalWisharts(K, D)
+        ref.nat_param = Stats([v.copy() for v in nat])
+        assert lib.mimo_host_debug_fault(4) == _lib.OK       # the next helper-thread start throws
+        got = StackedNormalWisharts(K, D)
+        got.nat_param = Stats([v.copy() for v in nat])
+        assert 'canon' in got._memo
+        for a, b in zip(got.canonical_expected(), ref.canonical_expected()):
+            assert np.array_equal(a, b)
+        for a, b in zip(got.params, ref.params):
+            assert np.array_equal(a, b)
+    finally:
+        composite.NATIVE_HOST = old

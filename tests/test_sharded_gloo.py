@@ -48,7 +48,7 @@ def test_two_rank_vi_matches_single_process(name):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -118,7 +118,7 @@ def test_two_rank_weighted_hierarchical_vi_matches_single_process():
     procs = [ctx.Process(target=_worker_hier, args=(r, 2, port, name, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -149,3 +149,92 @@ def test_two_rank_weighted_hierarchical_vi_matches_single_process():
     assert np.max(np.abs(res[0][1] - np.array(vlb)) / np.abs(np.array(vlb))) < 1e-10
     assert np.allclose(res[0][2], c.posterior.mus, rtol=1e-9, atol=1e-12)
     assert np.allclose(res[0][3], c.hyper_posterior.wishart.psi, rtol=1e-9, atol=1e-14)
+
+
+def _worker_svi(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random
+    import numpy.random as npr
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        from mimo_amd.sharded import ShardedEngine, shard_rows
+        import model_checks as mc
+        g = load_golden(name)
+        X = g["X"][:len(g["X"]) // 2 * 2]
+        lo, hi = shard_rows(len(X), rank, world)
+        eng = ShardedEngine(OracleEngine(), row_offset=lo)
+        kind, model = mc.build_gmm(g, eng)
+        mc.load_gmm_state(model, g, kind)
+        npr.seed(11); random.seed(12)              # identical host streams on every rank
+        vlb = model.meanfield_stochastic_descent(np.ascontiguousarray(X[lo:hi]), randomize=False, maxiter=3,
+                                                 step_size=5e-2, batch_size=32, progress_bar=False)
+        # row-local prediction passes through the sharded engine (second ADVICE item): moments of this rank's rows
+        eng.upload(np.ascontiguousarray(X[lo:hi, :1]))
+        K = model.size
+        rng = np.random.default_rng(3)
+        c, b, W = rng.standard_normal(K), rng.standard_normal((K, 1)), np.abs(rng.standard_normal((K, 1, 1))) + .5
+        M, Q, Cc = rng.standard_normal((K, 1, 2)), np.stack(K * [np.eye(2)]), np.ones((K, 1, 1))
+        mu, covar, _ = eng.predict(c, b, W, M, Q, Cc)
+        q.put((rank, np.array(vlb), [p.copy() for p in model.components.posterior.params],
+               model.gating.posterior.params, mu, type(model._batch_engine).__name__))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_svi_and_predict():
+    """meanfield_stochastic_descent on a ShardedEngine (it used to build ShardedEngine(<int>) and crash): the
+    minibatch is the union of the ranks' local draws, its statistics are all-reduced, and scale = union / all rows —
+    equal to a single process that takes the same union as its minibatch.  predict() is a row-local pass-through."""
+    import random
+    import numpy.random as npr
+    name = "gmm_tail_d5_k7_stick"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_svi, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][5] == "ShardedEngine"
+    # single-process emulation: same local index draw applied to both halves
+    from oracle_engine import OracleEngine
+    from mimo_amd.utils.data import batches
+    from mimo_amd.mixtures.gmm import _component_stats
+    import model_checks as mc
+    g = load_golden(name)
+    X = g["X"][:len(g["X"]) // 2 * 2]
+    n_loc = len(X) // 2
+    eng, beng = OracleEngine(), OracleEngine()
+    kind, model = mc.build_gmm(g, eng)
+    mc.load_gmm_state(model, g, kind)
+    eng.upload(X)
+    npr.seed(11); random.seed(12)
+    scale, vlb = 2 * 32 / float(len(X)), []
+    for _ in range(3):
+        for batch in batches(32, n_loc):
+            beng.upload(np.concatenate([X[:n_loc][batch], X[n_loc:][batch]]))
+            Sb, _ = beng.estep(*model.canonical_expected())
+            model.components.meanfield_sgd(None, None, scale, 5e-2, stats=_component_stats(Sb, model.components))
+            model.gating.meanfield_sgd(None, Sb.n, scale, 5e-2)
+        _, sc = eng.estep(*model.canonical_expected(), stats=False)
+        vlb.append(model._vlb_prior_terms() + sc[0])
+    assert np.max(np.abs(res[0][1] - np.array(vlb)) / np.abs(np.array(vlb))) < 1e-10
+    for a, b in zip(res[0][2], model.components.posterior.params):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    # prediction: concatenated shards equal the unsharded call
+    K = model.size
+    rng = np.random.default_rng(3)
+    c, b, W = rng.standard_normal(K), rng.standard_normal((K, 1)), np.abs(rng.standard_normal((K, 1, 1))) + .5
+    M, Q, Cc = rng.standard_normal((K, 1, 2)), np.stack(K * [np.eye(2)]), np.ones((K, 1, 1))
+    one = OracleEngine()
+    one.upload(np.ascontiguousarray(X[:, :1]))
+    mu, _, _ = one.predict(c, b, W, M, Q, Cc)
+    assert np.allclose(np.concatenate([res[0][4], res[1][4]]), mu, rtol=1e-12, atol=1e-14)
