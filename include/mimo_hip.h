@@ -267,6 +267,22 @@ double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep);
 int mimo_profile(mimo_ctx* ctx, int enable);
 int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset);
 
+/* Per-kernel breakdown of the same measurement: one text line "name<TAB>total_ms<TAB>launches" per kernel of the
+ * passes since the last reset (mimo_profile_read with reset = 1 clears it). */
+int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
+
+/* How a pass over the resident data with K components (softmax pass: gibbs = 0, label pass: gibbs = 1) will run:
+ *   out8[0] kind (MIMO_PLAN_*), out8[1] kernels per pass (without the two small reduction kernels),
+ *   out8[2] 1 if the (K, N) responsibility table goes through HBM, out8[3] how many times it is read back,
+ *   out8[4] reads of the data Z per pass, out8[5] writes + reads of the (N,) labels per pass,
+ *   out8[6] workgroups of the dominant kernel, out8[7] compute units of the device.
+ * bench.py prices its HBM roofline block from this instead of assuming a single fused pass. */
+#define MIMO_PLAN_FUSED      1   /* one fused tile kernel (MFMA): log-densities, softmax / draw, statistics        */
+#define MIMO_PLAN_TWO_STAGE  2   /* chunked E-step + statistics launches per feature column group (Dz > 16, ...)    */
+#define MIMO_PLAN_SMALL      3   /* small-shape VALU kernel (Dz <= 4, K <= 32): bound by HBM                        */
+#define MIMO_PLAN_ROWWAVE    4   /* large-K label pass: row-owner label kernel + label-indexed statistics kernel    */
+int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
+
 /* Test hook for the no-exception contract: throws, INSIDE the guarded boundary, kind 1: std::bad_alloc,
  * 2: std::runtime_error, 3: a non-std exception; returns the code the guard maps it to (MIMO_E_NOMEM,
  * MIMO_E_INTERNAL, MIMO_E_INTERNAL) with the message in mimo_last_error(ctx) (ctx may be NULL).  kind 0: MIMO_OK.

@@ -9,7 +9,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
+LIB_PATH = os.environ.get("MIMO_HIP_LIB") or os.path.join(_HERE, "libmimo_hip.so")   # (MIMO_HIP_LIB: kernel-variant experiments)
 
 # error codes / flags (mirror include/mimo_hip.h)
 OK = 0
@@ -51,6 +51,8 @@ SIGNATURES = {
     "mimo_philox_uniform": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "mimo_profile": (C.c_int, [_vp, C.c_int]),
     "mimo_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), C.c_int]),
+    "mimo_profile_kernels": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "mimo_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "mimo_debug_fault": (C.c_int, [_vp, C.c_int]),
     "mimo_host_debug_fault": (C.c_int, [C.c_int]),
     "mimo_version": (C.c_char_p, []),

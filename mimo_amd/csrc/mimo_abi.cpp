@@ -38,6 +38,8 @@ struct mimo_ctx {
   int F = 0, F16 = 0;
   std::vector<uint8_t> feat_h;
   uint8_t* feat_d = nullptr;
+  uint8_t* feat_full_d = nullptr;   // full map of the current D (small-shape kernel under a structure hint)
+  int feat_full_D = -1;
 
   // parameter image
   double* theta_d = nullptr;  size_t theta_cap = 0;
@@ -63,12 +65,16 @@ struct mimo_ctx {
   size_t pending_slen = 0;
   bool pending_stats = false;
 
-  // profiling of the fused kernel
+  // profiling: HIP events around every kernel of a pass, on the launch stream
   bool prof = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-  double prof_ms = 0.0;
-  int64_t prof_n = 0;
+  struct ProfEvent { hipEvent_t e0, e1; int name; };
+  std::vector<ProfEvent> pending;
+  static constexpr int kProfNames = 8;
+  const char* prof_name[kProfNames] = {nullptr};
+  double prof_name_ms[kProfNames] = {0.0};
+  int64_t prof_name_n[kProfNames] = {0};
+  double prof_ms = 0.0;      // all kernels
+  int64_t prof_n = 0;        // passes (run_fused calls)
 };
 
 static char g_err[512] = {0};
@@ -180,6 +186,15 @@ static int prepare_features(mimo_ctx* ctx, int D) {
   HIP_TRY(ctx, hipMemcpy(ctx->feat_d, ctx->feat_h.data(), ctx->feat_h.size(), hipMemcpyHostToDevice));
   ctx->feat_D = D;
   ctx->feat_structure = ctx->structure;
+  if (D <= kSmallMaxD && ctx->feat_full_D != D) {
+    uint8_t full[2 * 16];
+    memset(full, D + 1, sizeof full);
+    for (int aa = 0; aa <= D; ++aa)
+      for (int bb = aa; bb <= D; ++bb) { full[2 * feat_index(D, aa, bb)] = (uint8_t)aa; full[2 * feat_index(D, aa, bb) + 1] = (uint8_t)bb; }
+    if (!ctx->feat_full_d) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->feat_full_d), sizeof full));
+    HIP_TRY(ctx, hipMemcpy(ctx->feat_full_d, full, sizeof full, hipMemcpyHostToDevice));
+    ctx->feat_full_D = D;
+  }
   return MIMO_OK;
 }
 
@@ -211,7 +226,55 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
 
 // (c, b, W) -> Theta[k][f] -> MFMA A-operand image [K16][F16/4][64] on the device.
 //   f = (D,D): c_k ; (a,D): b_k[a] ; (a,a): -W_aa/2 ; (a,b), a<b: -(W_ab + W_ba)/2
+// Does this (data, K) run on the small-shape VALU kernel (mimo_small.hip)?  Dz <= 4, K <= 32, 16-byte aligned rows.
+static bool use_small(const mimo_ctx* ctx, int K) {
+  static const bool on = [] { const char* e = getenv("MIMO_SMALL"); return !e || atoi(e) != 0; }();   // tuning knob
+  return on && small_covers(ctx->D, K) && (reinterpret_cast<uintptr_t>(ctx->Z) % 16) == 0;
+}
+
+// small-shape kernel: Theta[G KL][F] row-major over the FULL feature map (feat_index order); a structure hint only
+// decides which entries of W are read (diagonal: W_aa; linear: none — the shared quadratic term stays with the caller)
+static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  const int D = ctx->D, F = feat_count(D), Kp = small_g(D, K) * small_kl(D, K);
+  const size_t count = (size_t)Kp * F;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the staging buffer may still be in flight
+  double* img = ctx->theta_h;
+  memset(img, 0, count * sizeof(double));
+  bool finite = true;
+  auto chk = [&](double v) { finite = finite && std::fabs(v) <= 1.7976931348623157e308; return v; };
+  for (int k = 0; k < K; ++k) {
+    double* t = img + (size_t)k * F;
+    const double* bk = b + (size_t)k * D;
+    const double* Wk = W + (size_t)k * D * D;
+    if (c[k] != c[k] || c[k] > 1.7976931348623157e308) return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
+    t[F - 1] = c[k] < kPadLogDensity ? kPadLogDensity : c[k];
+    for (int a = 0; a < D; ++a) t[feat_index(D, a, D)] = chk(bk[a]);
+    if (ctx->structure == MIMO_STRUCT_LINEAR) {
+      if (k > 0 && memcmp(Wk, W, sizeof(double) * D * D) != 0)
+        return fail(ctx, MIMO_E_INVALID, "linear structure is set (mimo_set_structure) but W[%d] differs from W[0]", k);
+      continue;
+    }
+    for (int a = 0; a < D; ++a) {
+      t[feat_index(D, a, a)] = chk(-0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) {
+        if (ctx->structure == MIMO_STRUCT_FULL) t[feat_index(D, a, bb)] = chk(-0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+        else if (Wk[a * D + bb] != 0.0 || Wk[bb * D + a] != 0.0)
+          return fail(ctx, MIMO_E_INVALID, "diagonal structure is set (mimo_set_structure) but W[%d] has the "
+                      "off-diagonal entry (%d,%d)", k, a, bb);
+      }
+    }
+  }
+  if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
+  for (int k = K; k < Kp; ++k) img[(size_t)k * F + F - 1] = kPadLogDensity;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MIMO_OK;
+}
+
 static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  if (use_small(ctx, K)) return upload_theta_small(ctx, c, b, W, K);
   const int D = ctx->D, F16 = ctx->F16;
   const int K16 = ((K + 15) / 16 <= 4) ? 4 : 16;   // every wave streams 1 (K<=64) or up to 4 row blocks; unused ones are zero
   // fused kernels step through F16/4 slices per row block; the chunked E-step through whole chunks
@@ -271,22 +334,48 @@ static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const d
 static void drain_profile(mimo_ctx* ctx) {
   for (auto& pr : ctx->pending) {
     float ms = 0.f;
-    if (hipEventSynchronize(pr.second) == hipSuccess &&
-        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+    if (hipEventSynchronize(pr.e1) == hipSuccess && hipEventElapsedTime(&ms, pr.e0, pr.e1) == hipSuccess) {
       ctx->prof_ms += ms;
-      ctx->prof_n += 1;
+      ctx->prof_name_ms[pr.name] += ms;
+      ctx->prof_name_n[pr.name] += 1;
     }
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    (void)hipEventDestroy(pr.e0);
+    (void)hipEventDestroy(pr.e1);
   }
   ctx->pending.clear();
 }
 
-// run fused kernel -> reduce -> unpack; deliver S / scalars to host or device pointers
+static int prof_slot(mimo_ctx* ctx, const char* name) {
+  for (int i = 0; i < mimo_ctx::kProfNames; ++i) {
+    if (ctx->prof_name[i] == name) return i;
+    if (!ctx->prof_name[i]) { ctx->prof_name[i] = name; return i; }
+  }
+  return mimo_ctx::kProfNames - 1;
+}
+
+// launch() bracketed by two events on the context's stream when profiling is on
+template <typename L>
+static int timed_launch(mimo_ctx* ctx, const char* name, L&& launch) {
+  if (!ctx->prof) return launch();
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, MIMO_E_HIP, "hipEventCreate failed"); }
+  (void)hipEventRecord(e0, ctx->stream);
+  const int rc = launch();
+  (void)hipEventRecord(e1, ctx->stream);
+  if (rc != MIMO_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+  ctx->pending.push_back({e0, e1, prof_slot(ctx, name)});
+  return MIMO_OK;
+}
+
+// run the pass (one fused kernel, the two-stage sequence, or the small-shape kernel) -> reduce -> unpack;
+// deliver S / scalars to host or device pointers
 static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
   const int K = a.K, D = a.D;
   const int Kpad = a.K16 * 16;
-  const int grid = fused_grid(a, ctx->num_cu, src);
+  const bool small = use_small(ctx, K);
+  if (small) { a.F16_total = 16; a.F16 = 16; }
+  const int grid = small ? small_grid(a, ctx->num_cu, src) : fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
@@ -301,21 +390,25 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
     g_stamps = stamps_d; g_stamps_grid = grid;
   }
 #endif
-  struct EventPair {      // destroyed on every early return; handed to ctx->pending once both are recorded
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
-  } ev;
-  if (ctx->prof) {
-    HIP_TRY(ctx, hipEventCreate(&ev.e0));
-    HIP_TRY(ctx, hipEventCreate(&ev.e1));
-    HIP_TRY(ctx, hipEventRecord(ev.e0, ctx->stream));
-  }
   const int ncb_total = a.F16 / 16;
-  if (fused_covers(a.K16, ncb_total, src)) {
-    bool unsupported = false;
-    hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
-    if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no fused kernel for K=%d, Dz=%d", K, D);
-    HIP_TRY(ctx, he);
+  if (small) {
+    rc = timed_launch(ctx, "small_kernel", [&]() -> int {
+      bool unsupported = false;
+      hipError_t he = launch_small(a, src, grid, ctx->stream, &unsupported);
+      if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no small-shape kernel for K=%d, Dz=%d", K, D);
+      HIP_TRY(ctx, he);
+      return MIMO_OK;
+    });
+    if (rc) return rc;
+  } else if (fused_covers(a.K16, ncb_total, src)) {
+    rc = timed_launch(ctx, "fused_kernel", [&]() -> int {
+      bool unsupported = false;
+      hipError_t he = launch_fused(a, src, grid, ctx->stream, &unsupported);
+      if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no fused kernel for K=%d, Dz=%d", K, D);
+      HIP_TRY(ctx, he);
+      return MIMO_OK;
+    });
+    if (rc) return rc;
   } else {
     // two-stage path: chunked E-step writes responsibilities / labels, then the statistics kernel
     // runs once per group of <= kMaxNCB feature column blocks, all into the same partial block.
@@ -331,7 +424,11 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
       }
       if (chunked_lds_bytes(e) > 160 * 1024)
         return fail(ctx, MIMO_E_UNSUPPORTED, "K=%d, Dz=%d needs more LDS than one CU has", K, D);
-      HIP_TRY(ctx, launch_estep_chunked(e, grid, ctx->stream));
+      rc = timed_launch(ctx, "estep_chunked_kernel", [&]() -> int {
+        HIP_TRY(ctx, launch_estep_chunked(e, grid, ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
       st.resp = e.resp; st.labels = e.labels; st.write_scalars = 0;
       stats_src = e.gibbs ? kSrcLabels : kSrcWeights;
     }
@@ -343,17 +440,17 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
         g.cb0 = cb0; g.F16 = 16 * ncb; g.RS = g.F16 + 1; g.F16_total = a.F16;
         g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
         if (cb0 > 0) g.write_scalars = 0;
-        bool unsupported = false;
-        HIP_TRY(ctx, launch_fused(g, stats_src, grid, ctx->stream, &unsupported));
-        if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no statistics kernel for K=%d, Dz=%d", K, D);
+        rc = timed_launch(ctx, src == kSrcEstep ? "fused_kernel(statistics of a column group)" : "fused_kernel", [&]() -> int {
+          bool unsupported = false;
+          HIP_TRY(ctx, launch_fused(g, stats_src, grid, ctx->stream, &unsupported));
+          if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no statistics kernel for K=%d, Dz=%d", K, D);
+          return MIMO_OK;
+        });
+        if (rc) return rc;
       }
     }
   }
-  if (ctx->prof) {
-    HIP_TRY(ctx, hipEventRecord(ev.e1, ctx->stream));
-    ctx->pending.emplace_back(ev.e0, ev.e1);
-    ev.e0 = ev.e1 = nullptr;
-  }
+  if (ctx->prof) ctx->prof_n += 1;
   const bool async = (flags & MIMO_F_ASYNC) != 0;
   const bool want_stats = a.do_stats && (S || async);
   const bool device_out = (flags & MIMO_F_DEVICE_OUT) != 0;
@@ -361,14 +458,18 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
 
   HIP_TRY(ctx, launch_reduce(ctx->partials, grid, (int64_t)pstride, ctx->reduced, ctx->stream));
   const size_t slen = (size_t)K * (1 + D + (size_t)D * D);
+  // the small-shape kernel always accumulates the full feature map: under a structure hint the entries outside
+  // the structure are masked to the zeros the hint promises
+  const uint8_t* feat = small ? ctx->feat_full_d : ctx->feat_d;
+  const int F = small ? feat_count(D) : ctx->F, mask = small ? ctx->structure : 0;
   if (device_out) {
-    HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, ctx->F, a.F16, want_stats ? S : nullptr, scalars, ctx->stream));
+    HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? S : nullptr, scalars, ctx->stream, mask));
     return MIMO_OK;
   }
   if ((rc = ensure_dev(ctx, &ctx->S_d, &ctx->S_cap, slen + 4))) return rc;
   if ((rc = ensure_pinned(ctx, &ctx->S_h, &ctx->S_hcap, slen + 4))) return rc;
-  HIP_TRY(ctx, launch_unpack(ctx->reduced, ctx->feat_d, K, D, ctx->F, a.F16, want_stats ? ctx->S_d : nullptr,
-                             ctx->S_d + slen, ctx->stream));
+  HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? ctx->S_d : nullptr,
+                             ctx->S_d + slen, ctx->stream, mask));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (flags & MIMO_F_ASYNC) {
     ctx->pending_async = true; ctx->pending_slen = slen; ctx->pending_stats = want_stats;
@@ -417,7 +518,7 @@ int mimo_destroy(mimo_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   drain_profile(ctx);
-  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
+  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
                   ctx->logp, ctx->lse, ctx->labels, ctx->u_d, ctx->win, ctx->lin};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (ctx->theta_h) (void)hipHostFree(ctx->theta_h);
@@ -807,7 +908,61 @@ int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int r
   drain_profile(ctx);
   if (kernel_ms) *kernel_ms = ctx->prof_ms;
   if (launches) *launches = ctx->prof_n;
-  if (reset) { ctx->prof_ms = 0.0; ctx->prof_n = 0; }
+  if (reset) {
+    ctx->prof_ms = 0.0; ctx->prof_n = 0;
+    for (int i = 0; i < mimo_ctx::kProfNames; ++i) { ctx->prof_name_ms[i] = 0.0; ctx->prof_name_n[i] = 0; }
+  }
+  return MIMO_OK;
+  });
+}
+
+int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len) {
+  return guarded(ctx, [&]() -> int {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!buf || len < 1) return fail(ctx, MIMO_E_INVALID, "mimo_profile_kernels: no buffer");
+  drain_profile(ctx);
+  int off = 0;
+  buf[0] = 0;
+  for (int i = 0; i < mimo_ctx::kProfNames && ctx->prof_name[i]; ++i) {
+    if (!ctx->prof_name_n[i]) continue;
+    const int w = snprintf(buf + off, (size_t)(len - off), "%s\t%.6f\t%lld\n", ctx->prof_name[i], ctx->prof_name_ms[i],
+                           (long long)ctx->prof_name_n[i]);
+    if (w < 0 || w >= len - off) break;
+    off += w;
+  }
+  return MIMO_OK;
+  });
+}
+
+int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
+  return guarded(ctx, [&]() -> int {
+  int rc = bind(ctx); if (rc) return rc;
+  if (!out8) return fail(ctx, MIMO_E_INVALID, "mimo_plan: out is NULL");
+  if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "no data uploaded or attached");
+  if (K < 1 || K > 256) return fail(ctx, MIMO_E_UNSUPPORTED, "K = %d outside [1, 256]", K);
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  a.gibbs = gibbs ? 1 : 0;
+  const int ncb = a.F16 / 16;
+  memset(out8, 0, 8 * sizeof(int64_t));
+  out8[4] = 1;                           // passes over Z
+  out8[5] = gibbs ? 1 : 0;               // passes over the labels
+  if (use_small(ctx, K)) {
+    out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
+    out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
+  } else if (fused_covers(a.K16, ncb, kSrcEstep)) {
+    out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;
+    out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
+  } else {
+    const int gmax = stats_group_ncb(a.K16), groups = (ncb + gmax - 1) / gmax;
+    out8[0] = MIMO_PLAN_TWO_STAGE; out8[1] = 1 + groups;
+    out8[2] = gibbs ? 0 : 1;             // the (K, N) responsibility table goes through HBM
+    out8[3] = gibbs ? 0 : groups;        // and is read once per statistics launch
+    out8[4] = 1 + groups;                // Z: the chunked E-step + every statistics launch
+    out8[5] = gibbs ? 1 + groups : 0;
+    out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
+  }
+  out8[7] = ctx->num_cu;
   return MIMO_OK;
   });
 }

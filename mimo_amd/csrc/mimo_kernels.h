@@ -75,8 +75,21 @@ hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t strea
 bool fused_covers(int K16, int ncb, int src);
 int stats_group_ncb(int K16);   // feature column blocks one statistics launch can accumulate for this K
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
+// mask_structure: 0 = write every feature of the table; MIMO_STRUCT_DIAG / _LINEAR = the table is the FULL map but
+// only the entries of that structure are real (small-shape kernel): the others come back as zeros
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F, int F16,
-                         double* S_packed, double* scalars3, hipStream_t stream);
+                         double* S_packed, double* scalars3, hipStream_t stream, int mask_structure = 0);
+
+// Small shapes (Dz <= 4, K <= 32): float64 VALU kernel, one datum per lane (mimo_small.hip).  theta: [G KL][F]
+// row-major over the FULL feature map in feat_index order; partial blocks in the layout of the tile kernels with
+// F16_total = 16.
+constexpr int kSmallMaxD = 4;
+constexpr int kSmallMaxK = 32;
+int small_kl(int D, int K);     // components per lane
+int small_g(int D, int K);      // lanes per row
+bool small_covers(int D, int K);
+int small_grid(const KernelArgs& a, int num_cu, int src);
+hipError_t launch_small(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
 
 hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,
                                 double* out, hipStream_t stream);

@@ -424,7 +424,10 @@ def test_switched_off_component_and_far_clusters(engine):
         L3 = O.canonical_eval(Z, c3, b3, W3)
     L3[5] = -np.inf
     lse3 = logsumexp(L3, axis=0)
-    R3 = np.exp(L3 - lse3)
+    # (rows of the switched-off cluster are far from everything: |l| ~ 3e5, where exp(l - lse) loses 11 digits of the
+    # weights to the rounding of lse; the reference weights are formed from l - max like the kernel's)
+    E3 = np.exp(L3 - L3.max(axis=0))
+    R3 = E3 / E3.sum(axis=0)
     srl3 = float(np.nansum(np.where(R3 > 0, R3 * L3, 0.)))
     _, sc3 = engine.estep(c3, b3, W3, entropy_split=True)
     assert abs(sc3[0] - lse3.sum()) < 1e-11 * abs(lse3.sum()) and abs(sc3[1] - srl3) < 1e-11 * abs(srl3)
@@ -523,3 +526,99 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert rel_err(S[:, 1 + D:].reshape(K, D, D), sxx) < 1e-11 and abs(sc0 - lse.sum()) < 1e-12 * abs(lse.sum())
     assert np.array_equal(labels, O.sample_discrete_from_log(L, O.philox_uniforms(42, np.arange(N), 3)))
     assert any(l.startswith("error_message") and "K must be" in l for l in lines)
+
+
+SMALL_SHAPES = [(1, 1), (1, 3), (1, 6), (1, 13), (1, 32), (2, 1), (2, 4), (2, 6), (2, 8), (2, 16), (2, 25), (2, 32),
+                (3, 3), (3, 4), (3, 5), (3, 8), (3, 16), (3, 32), (4, 2), (4, 3), (4, 7), (4, 16), (4, 30), (4, 32)]
+
+
+@pytest.mark.parametrize("D,K", SMALL_SHAPES)
+@pytest.mark.parametrize("N", [1, 63, 5003, 3 * 1024 * 256 + 5])
+def test_small_shape_kernel_vs_oracle(engine, D, K, N):
+    """The VALU kernel for Dz <= 4, K <= 32 (mimo_small.hip) — every (Dz, lanes-per-row) geometry, ragged N down to one
+    row and N large enough for several chunks per wave: tables, statistics, scalars, both label sources, table-driven and
+    label-driven statistics, per-row weights, and run-to-run bit reproducibility, against the oracle."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    assert engine.plan is not None
+    rng = np.random.default_rng(7000 + 100 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K)["kind"] == "small"
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    tol = 1e-11
+    S, sc = engine.estep(c, b, W)                                        # fast mode
+    assert rel_err(S.n, n) < tol and rel_err(S.sx, sx) < tol and rel_err(S.sxx, sxx) < tol
+    assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    S1, sc1 = engine.estep(c, b, W)
+    assert np.array_equal(S1.sxx, S.sxx) and np.array_equal(S1.n, S.n) and sc1[0] == sc[0]
+    big = N > 100000
+    if not big:
+        Sg, scg = engine.estep(c, b, W, keep_resp=True, keep_logp=True, keep_lse=True)     # generic mode
+        assert rel_err(engine.get_logp(), L) < 1e-12 and rel_err(engine.get_lse(), lse) < 1e-12
+        assert rel_err(engine.get_resp(), R) < tol and rel_err(Sg.sxx, sxx) < tol
+        srl = float(np.sum(R * L))
+        assert abs(scg[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum())) and abs(scg[1] - srl) < 1e-11 * max(1., abs(srl))
+        Wt = rng.random((K, N))
+        S2 = engine.weighted_stats(Wt)
+        n2, sx2, sxx2 = O.packed_stats(Z, Wt)
+        assert rel_err(S2.n, n2) < tol and rel_err(S2.sx, sx2) < tol and rel_err(S2.sxx, sxx2) < tol
+        w = rng.random(N) + 0.1
+        Sw, scw = engine.estep(c, b, W, row_weights=w)
+        nw, sxw, sxxw = O.packed_stats(Z, R * w)
+        assert rel_err(Sw.n, nw) < tol and rel_err(Sw.sxx, sxxw) < tol and abs(scw[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+        u = rng.random(N)
+        lab, S3 = engine.gibbs_labels(c, b, W, u=u)
+        ref = O.sample_discrete_from_log(L, u)
+        assert np.array_equal(lab, ref) and np.array_equal(S3.n, np.bincount(ref, minlength=K))
+        S4 = engine.label_stats(ref, K)
+        n4, sx4, sxx4 = O.packed_stats(Z, O.one_hot(ref, K))
+        assert np.array_equal(S4.n, n4) and rel_err(S4.sx, sx4) < tol and rel_err(S4.sxx, sxx4) < tol
+        assert rel_err(S3.sxx, sxx4) < tol
+    lab_p, Sp = engine.gibbs_labels(c, b, W, seed=99, sweep=7)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(99, np.arange(N), 7)) if not big else None
+    if ref_p is not None:
+        assert np.array_equal(lab_p, ref_p) and np.array_equal(Sp.n, np.bincount(ref_p, minlength=K))
+    else:
+        assert np.array_equal(Sp.n, np.bincount(lab_p, minlength=K)) and Sp.n.sum() == N
+        lab_q, Sq = engine.gibbs_labels(c, b, W, seed=99, sweep=7)
+        assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx)
+
+
+@pytest.mark.parametrize("D,K", [(2, 4), (2, 25), (3, 8), (4, 16), (1, 6)])
+def test_small_shape_kernel_structures(engine, D, K):
+    """Structure hints on the small-shape kernel: diagonal blocks return zero off-diagonal second moments, tied blocks
+    ('linear') the pooled second moment and the bound with the shared quadratic term added back by the engine."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    N = 20011
+    rng = np.random.default_rng(31 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    Wd = np.stack([np.diag(np.diag(w)) for w in W])
+    engine.upload(Z)
+    engine.set_structure('diag')
+    try:
+        L = O.canonical_eval(Z, c, b, Wd)
+        lse = logsumexp(L, axis=0)
+        n, sx, sxx = O.packed_stats(Z, np.exp(L - lse))
+        S, sc = engine.estep(c, b, Wd)
+        diag = np.stack([np.diag(np.diag(m)) for m in sxx])
+        assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, diag) < 1e-11
+        assert abs(sc[0] - lse.sum()) < 1e-12 * abs(lse.sum())
+        if D > 1:
+            with pytest.raises(ValueError):
+                engine.estep(c, b, W)
+        engine.set_structure('linear')
+        Wt = np.stack(K * [W[0]])
+        L = O.canonical_eval(Z, c, b, Wt)
+        lse = logsumexp(L, axis=0)
+        n, sx, sxx = O.packed_stats(Z, np.exp(L - lse))
+        S, sc = engine.estep(c, b, Wt)
+        assert S.sxx is None and rel_err(S.sxx_total, Z.T @ Z) < 1e-11
+        assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11
+        assert abs(sc[0] - lse.sum()) < 1e-11 * abs(lse.sum())
+    finally:
+        engine.set_structure('full')
