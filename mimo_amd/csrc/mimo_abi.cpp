@@ -60,6 +60,8 @@ struct mimo_ctx {
   double* win = nullptr;   size_t win_cap = 0;    // staged host weights
   int32_t* lin = nullptr;  size_t lin_cap = 0;    // staged host labels
 
+  bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
+
   // pending asynchronous call (MIMO_F_ASYNC)
   bool pending_async = false;
   size_t pending_slen = 0;
@@ -273,6 +275,49 @@ static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, c
   return MIMO_OK;
 }
 
+// Large-K label pass on the row-owner kernels (mimo_rowwave.hip): K > 64, Dz <= 9, full structure, nothing but labels
+// (+ their statistics) requested.
+static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
+  static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE"); return !e || atoi(e) != 0; }();   // tuning knob
+  if (!on || wants_tables || ctx->structure != MIMO_STRUCT_FULL) return false;
+  const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
+  return rowwave_covers(K, ctx->F16, ZS) && label_stats_covers(K, ctx->D);
+}
+
+// Theta image of the row-owner label kernel: [NS][KB][64]; component k sits in A-row (k / V) + 4 (k % 4) of row block
+// (k % V) / 4, V = 4 KB, so that an output lane holds a contiguous quarter of the components (gibbs_rowwave_kernel)
+static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  const int D = ctx->D, NS = ctx->F16 / 4, KB = rowwave_kb(K), V = 4 * KB;
+  const size_t count = (size_t)NS * KB * 64;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  double* img = ctx->theta_h;
+  memset(img, 0, count * sizeof(double));
+  bool finite = true;
+  auto put = [&](int k, int f, double v) {
+    const int t = k % V, rb = t / 4, i = k / V + 4 * (t % 4);
+    finite = finite && std::fabs(v) <= 1.7976931348623157e308;
+    img[((size_t)(f / 4) * KB + rb) * 64 + (f % 4) * 16 + i] = v;
+  };
+  for (int k = 0; k < K; ++k) {
+    const double* bk = b + (size_t)k * D;
+    const double* Wk = W + (size_t)k * D * D;
+    if (c[k] != c[k] || c[k] > 1.7976931348623157e308) return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
+    put(k, feat_index(D, D, D), c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
+    for (int a = 0; a < D; ++a) {
+      put(k, feat_index(D, a, D), bk[a]);
+      put(k, feat_index(D, a, a), -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) put(k, feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+    }
+  }
+  if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
+  for (int k = K; k < 16 * KB; ++k) put(k, feat_index(D, D, D), kPadLogDensity);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MIMO_OK;
+}
+
 static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
   if (use_small(ctx, K)) return upload_theta_small(ctx, c, b, W, K);
   const int D = ctx->D, F16 = ctx->F16;
@@ -375,7 +420,10 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   const int Kpad = a.K16 * 16;
   const bool small = use_small(ctx, K);
   if (small) { a.F16_total = 16; a.F16 = 16; }
-  const int grid = small ? small_grid(a, ctx->num_cu, src) : fused_grid(a, ctx->num_cu, src);
+  const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
+  const bool lstats = !small && ((src == kSrcLabels && ctx->structure == MIMO_STRUCT_FULL && label_stats_covers(K, D)) || rowwave);
+  const int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
+                                                                    : fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
@@ -391,7 +439,22 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   }
 #endif
   const int ncb_total = a.F16 / 16;
-  if (small) {
+  if (lstats) {
+    if (rowwave) {
+      rc = timed_launch(ctx, "gibbs_rowwave_kernel", [&]() -> int {
+        HIP_TRY(ctx, launch_gibbs_rowwave(a, rowwave_grid(a, ctx->num_cu), ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
+    }
+    if (a.do_stats) {
+      rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
+        HIP_TRY(ctx, launch_label_stats(a, grid, ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
+    }
+  } else if (small) {
     rc = timed_launch(ctx, "small_kernel", [&]() -> int {
       bool unsupported = false;
       hipError_t he = launch_small(a, src, grid, ctx->stream, &unsupported);
@@ -707,9 +770,13 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
       a.u = ctx->u_d;
     }
   }
-  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  const bool rw = !use_small(ctx, K) && use_rowwave(ctx, K, (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0);
+  if ((rc = rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
-  if ((rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr))) return rc;
+  ctx->rowwave_call = rw;
+  rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr);
+  ctx->rowwave_call = false;
+  if (rc) return rc;
   if (labels_out && !(flags & MIMO_F_DEVICE_OUT)) {
     HIP_TRY(ctx, hipMemcpyAsync(labels_out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -950,6 +1017,11 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   if (use_small(ctx, K)) {
     out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
     out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
+  } else if (gibbs && use_rowwave(ctx, K, false)) {
+    out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 2;
+    out8[4] = 2;                         // Z: label kernel + statistics kernel
+    out8[5] = 2;                         // labels written once, read once
+    out8[6] = rowwave_grid(a, ctx->num_cu);
   } else if (fused_covers(a.K16, ncb, kSrcEstep)) {
     out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;
     out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);

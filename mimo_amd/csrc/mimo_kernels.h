@@ -91,6 +91,17 @@ bool small_covers(int D, int K);
 int small_grid(const KernelArgs& a, int num_cu, int src);
 hipError_t launch_small(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
 
+// Large-K Gibbs sweep (mimo_rowwave.hip): row-owner label kernel (Theta stationary in LDS, draw in registers) and
+// the label-indexed statistics kernel.  theta: [NS][KB][64] with the component permutation of rowwave_component().
+size_t rowwave_lds_bytes(int KB, int NS, int ZS);
+int rowwave_kb(int K);
+bool rowwave_covers(int K, int F16, int ZS);
+int rowwave_grid(const KernelArgs& a, int num_cu);
+hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
+bool label_stats_covers(int K, int D);
+int label_stats_grid(const KernelArgs& a, int num_cu);
+hipError_t launch_label_stats(const KernelArgs& a, int grid, hipStream_t stream);
+
 hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,
                                 double* out, hipStream_t stream);
 

@@ -1,0 +1,391 @@
+// gfx950 kernels of the LARGE-K Gibbs sweep (64 < K <= 256, Dz <= 9: BASELINE config C3, DP-GMM with Kmax = 256):
+//
+//   gibbs_rowwave_kernel<KB>   label pass:  l = Theta . Phi'  ->  inverse-CDF draw, nothing but the labels leaves
+//   label_stats_kernel<DZ>     statistics of the labels just drawn, bound by HBM (the data once + 4 bytes per row)
+//
+// Why not the fused tile kernel (mimo_kernels.hip, RBW = 4) for this shape: there a workgroup shares one 32-row tile,
+// the l tile goes through LDS twice (66 KB per workgroup), four barriers per tile, and the 96 accumulator registers
+// of the statistics push the kernel into scratch (C3: 8.1 ms, 42 % of the float64 matrix peak).  Here the roles are
+// swapped — "row-owner" waves:
+//
+//   * Theta (K x F16, 98 KB at K = 256, Dz = 8) is loaded into LDS ONCE per workgroup and only read afterwards;
+//   * a wave owns 16 data rows per step: B operand Phi[row j][4s + q] is built on the fly from the wave's own z rows
+//     (2 LDS reads + 1 product per contraction step, shared by the K/16 MFMAs of the step), A operand = Theta slices
+//     straight from LDS, accumulators = the l values of ALL components of the wave's 16 rows (4 K/16 doubles per lane);
+//   * the components are permuted in the operand image so that lane (q, j) ends up with a CONTIGUOUS quarter of the
+//     components of row j: max, exp, cumulative sums and the inverse-CDF count run in registers, three cross-lane
+//     steps per row, no LDS round trip and no workgroup barrier anywhere in the loop.
+//
+// The statistics of hard labels are a scatter (S[label_n] += phi(z_n)); done deterministically without float atomics:
+// per 512-row tile a bitmap per component (integer atomic OR: order-free), stable ranks by popcount, then thread k
+// walks ITS rows in ascending order and accumulates the F features in registers across all tiles of the workgroup.
+//
+// Reference behaviour reproduced: mimo/mixtures/gmm.py:227-237 (resample_labels + resample_components' statistics),
+// mimo/utils/stats.py:8-21 (label = #{k : u cum_K > cum_k}), gaussian.py:491-502, data.py:160-169.
+#include "mimo_device.h"
+
+#include <type_traits>
+
+namespace mimo {
+
+// ------------------------------------------------------------------------------------------
+// Label pass.  KB = row blocks (16 components each) the accumulators cover; K <= 16 KB.
+// Operand image (host, upload_theta_rowwave): slice e = s KB + rb, lane (i = lane & 15, kk = lane >> 4) holds
+// Theta[comp(i, rb)][4 s + kk] with comp(i, rb) = (i & 3) V + 4 rb + (i >> 2), V = 4 KB: output lane (q, j)
+// register r of row block rb (= A-row q + 4 r) is component q V + 4 rb + r of data row j.
+// ------------------------------------------------------------------------------------------
+constexpr int kRowWaveWG = 512;     // 8 wavefronts: two per SIMD (the accumulators need 8 KB VGPRs per lane)
+
+template <int KB>
+__global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const KernelArgs a) {
+  constexpr int V = 4 * KB;          // components per lane
+  constexpr int NCH = KB / 2;        // chunks of 8 components (two row blocks) for the cumulative sums
+  static_assert(KB % 2 == 0 && KB >= 2 && KB <= 16, "row blocks per wave");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int NS = a.F16 / 4;                          // contraction steps
+  const int ZS = a.ZS;
+  double* Th = reinterpret_cast<double*>(smem);      // [(NS KB + 4)][64]   (+4: the operand prefetch runs past the end)
+  double* etab = Th + (size_t)(NS * KB + 4) * 64;    // [64]
+  uint32_t* ftab = reinterpret_cast<uint32_t*>(etab + 64);                 // [4 NS] byte offsets (a | b << 16) into a z~ row
+  double* Zall = reinterpret_cast<double*>(ftab + 4 * NS + (NS & 1 ? 2 : 0));   // [8 waves][16][ZS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int D = a.D, K = a.K;
+  const int64_t N = a.N;
+  double* Zw = Zall + (size_t)wave * 16 * ZS;
+
+  for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
+  for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
+  if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+  for (int f = tid; f < 4 * NS; f += kRowWaveWG) ftab[f] = 8u * a.feat[2 * f] | (8u * a.feat[2 * f + 1]) << 16;
+  wg_sync();
+
+  // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < 3 (16 D <= 144)
+  const int64_t nsteps = (N + 15) / 16;
+  const int64_t nwaves = (int64_t)gridDim.x * (kRowWaveWG / 64), wv = (int64_t)blockIdx.x * (kRowWaveWG / 64) + wave;
+  int zoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = lane + 64 * i, r = e / D;
+    zoff[i] = e < 16 * D ? r * ZS + (e - r * D) : -1;
+  }
+  double zr[3];
+  auto load_z = [&](int64_t t) {
+    const int64_t base = t * 16 * D, total = N * D;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t gidx = base + lane + 64 * i;
+      zr[i] = (zoff[i] >= 0 && gidx < total) ? a.Z[gidx] : 0.0;
+    }
+  };
+  if (wv < nsteps) load_z(wv);
+
+  const double* zrow = Zw + j * ZS;
+  const uint32_t* ft = ftab + q;
+  const double* thl = Th + lane;
+
+  for (int64_t t = wv; t < nsteps; t += nwaves) {
+    const int64_t n = t * 16 + j;
+    const bool valid = n < N;
+    // ---- stage this step's z~ rows in the wave's own LDS block (LDS operations of one wave execute in order)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (zoff[i] >= 0) Zw[zoff[i]] = zr[i];
+    if (q == 0) {
+      Zw[j * ZS + D] = valid ? 1.0 : 0.0;     // rows past N: every feature 0, l = 0, never written
+      Zw[j * ZS + D + 1] = 0.0;               // padded features read this slot
+    }
+    if (t + nwaves < nsteps) load_z(t + nwaves);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- L (16 KB x 16) = Theta . Phi' ---------------------------------------------------------------
+    d4 acc[KB];
+#pragma unroll
+    for (int rb = 0; rb < KB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
+    auto feature = [&](int s) {
+      const uint32_t w = ft[4 * s];
+      const double za = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(zrow) + (w & 0xffffu));
+      const double zb = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(zrow) + (w >> 16));
+      return za * zb;
+    };
+    constexpr int PF = 4;              // Theta slices in flight; slice e = s KB + rb sits in slot e % PF
+    double ring[PF];
+#pragma unroll
+    for (int e = 0; e < PF; ++e) ring[e] = thl[e * 64];
+    double bq = feature(0);
+    const double* thp = thl;
+    for (int s = 0; s < NS; s += 2) {            // NS = F16 / 4 is a multiple of 4; two steps per iteration keep the
+#pragma unroll                                   // ring slots static for KB = 6, 10, 14 as well (2 KB % 4 == 0)
+      for (int par = 0; par < 2; ++par) {
+        const double bcur = bq;
+        if (s + par + 1 < NS) bq = feature(s + par + 1);
+#pragma unroll
+        for (int rb = 0; rb < KB; ++rb) {
+          const int slot = (par * KB + rb) % PF;
+          const double av = ring[slot];
+          ring[slot] = thp[(par * KB + rb + PF) * 64];     // (the last step reads the 4 zero slices behind the image)
+          acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
+        }
+      }
+      thp += 2 * KB * 64;
+    }
+
+    // ---- draw: lane (q, j) holds components q V .. q V + V - 1 of row j, x[4 rb + r] = acc[rb][r] ----------
+    __builtin_amdgcn_s_setprio(2);
+    double m;
+    {
+      double mv[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+#pragma unroll
+      for (int rb = 1; rb < KB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = fmax(mv[r], acc[rb][r]);
+      m = fmax(fmax(mv[0], mv[1]), fmax(mv[2], mv[3]));
+      m = fmax(m, __shfl_xor(m, 16));
+      m = fmax(m, __shfl_xor(m, 32));
+    }
+    // e = exp(l - max), then inclusive cumulative sums inside chunks of 8 (independent chains across the chunks)
+    double base[NCH + 1];
+    base[0] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      double x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos(acc[2 * c + (i >> 2)][i & 3] - m, etab);
+#pragma unroll
+      for (int i = 1; i < 8; ++i) x[i] += x[i - 1];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[2 * c + (i >> 2)][i & 3] = x[i];
+      base[c + 1] = x[7];
+      __builtin_amdgcn_sched_barrier(0);       // one chunk of exp chains in flight at a time (register pressure)
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) base[c + 1] += base[c];      // base[c] = sum of the chunks before c
+    const double cum = base[NCH];
+    double incl = cum;                          // inclusive scan over the four quarters of the row (lanes j, j+16, ..)
+    {
+      double v = __shfl_up(incl, 16);  if (q >= 1) incl += v;
+      v = __shfl_up(incl, 32);         if (q >= 2) incl += v;
+    }
+    double excl = __shfl_up(incl, 16);
+    if (q == 0) excl = 0.0;
+    const double ctot = __shfl(incl, 48 + j);
+    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+    const double tl = uu * ctot - excl;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const double tc = tl - base[c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cnt += tc > acc[2 * c + (i >> 2)][i & 3] ? 1 : 0;
+    }
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    const int label = cnt < K ? cnt : K - 1;
+    if (q == 0 && valid) a.labels[n] = label;
+    __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+size_t rowwave_lds_bytes(int KB, int NS, int ZS) {
+  return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + 64) + sizeof(uint32_t) * (size_t)(4 * NS + (NS & 1 ? 2 : 0)) +
+         sizeof(double) * (size_t)(kRowWaveWG / 64) * 16 * ZS;
+}
+
+int rowwave_kb(int K) {           // row blocks the kernel is instantiated for: 6, 8, .., 16
+  int kb = (K + 15) / 16;
+  kb += kb & 1;
+  return kb < 6 ? 6 : kb;
+}
+
+// K > 64 (below that the fused tile kernels hold everything in one pass), Dz <= 9 (F16 <= 64: the image fits LDS)
+bool rowwave_covers(int K, int F16, int ZS) {
+  if (K <= 64 || K > 256 || F16 > 64) return false;
+  return rowwave_lds_bytes(rowwave_kb(K), F16 / 4, ZS) <= 160 * 1024;
+}
+
+typedef void (*rowwave_fn)(const KernelArgs);
+static rowwave_fn pick_rowwave(int kb) {
+  switch (kb) {
+    case 6: return gibbs_rowwave_kernel<6>;
+    case 8: return gibbs_rowwave_kernel<8>;
+    case 10: return gibbs_rowwave_kernel<10>;
+    case 12: return gibbs_rowwave_kernel<12>;
+    case 14: return gibbs_rowwave_kernel<14>;
+    case 16: return gibbs_rowwave_kernel<16>;
+  }
+  return nullptr;
+}
+
+int rowwave_grid(const KernelArgs& a, int num_cu) {
+  const int64_t steps = (a.N + 15) / 16, need = (steps + 7) / 8;
+  int64_t g = num_cu;
+  if (g > need) g = need;
+  return (int)(g < 1 ? 1 : g);
+}
+
+hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream) {
+  const int kb = rowwave_kb(a.K);
+  rowwave_fn fn = pick_rowwave(kb);
+  if (!fn) return hipErrorInvalidValue;
+  const size_t lds = rowwave_lds_bytes(kb, a.F16 / 4, a.ZS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kRowWaveWG), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Statistics of hard labels, K <= 256, Dz <= 9, full feature map.  Workgroup = 256 threads, thread k owns
+// component k: its F accumulators (n_k, sum z, upper triangle of sum z z') live in registers across all tiles.
+// Per tile of kLsTile rows:  z tile + labels -> LDS;  bitmap[k] |= 1 << row (integer atomics: the result does not
+// depend on their order);  stable position of every row inside its component's list = popcount of the lower bits;
+// thread k adds its rows in ascending row order.  Partial block per workgroup in the tile kernels' layout.
+// ------------------------------------------------------------------------------------------
+constexpr int kLsTile = 512;
+
+template <int DZ>
+__global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
+  constexpr int ZS = DZ <= 2 ? 2 : DZ <= 6 ? 6 : 10;   // 16-byte aligned rows, odd stride in 16-byte units (random rows: no systematic bank conflicts)
+  constexpr int T = kLsTile, NW = T / 32;           // bitmap words per component
+  constexpr int ZPT = (T * DZ + kWG - 1) / kWG;     // z elements per thread
+  __shared__ __align__(16) double Zt[T * ZS];
+  __shared__ uint32_t bitmap[kWG * NW];             // [k][word] — k-major so that thread k reads 16 consecutive words
+  __shared__ uint16_t list[T];
+  __shared__ int start[kWG + 1];
+  __shared__ int wsum[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T;
+
+  double acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.0;
+
+  double zr[ZPT];
+  int lab[2];
+  auto load_tile = [&](int64_t t) {
+    const int64_t base = t * T * DZ, total = N * DZ;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + (int64_t)kWG * i;
+      zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t n = t * T + tid + kWG * h;
+      lab[h] = n < N ? a.labels[n] : -1;
+    }
+  };
+  if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    wg_sync();                        // the previous tile's readers are done
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int e = tid + kWG * i;
+      if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
+    }
+    {
+      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
+    }
+    const int l0 = lab[0], l1 = lab[1];
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+    wg_sync();
+    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+    if (l1 >= 0) atomicOr(&bitmap[l1 * NW + ((tid + kWG) >> 5)], 1u << (tid & 31));
+    wg_sync();
+    // rows of component tid, and the exclusive prefix over the components (where its list starts)
+    int cntk = 0;
+    {
+      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) {
+        const uint4 v = bm[w];
+        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    const int st = off + incl - cntk;
+    start[tid] = st;
+    wg_sync();
+    // stable position of each row in its component's list
+    auto place = [&](int l, int row) {
+      if (l < 0) return;
+      const uint32_t* bm = bitmap + l * NW;
+      const int wq = row >> 5;
+      int rank = __popc(bm[wq] & ((1u << (row & 31)) - 1u));
+      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+      list[start[l] + rank] = (uint16_t)row;
+    };
+    place(l0, tid);
+    place(l1, tid + kWG);
+    wg_sync();
+    // thread k: its rows, ascending
+    for (int p = 0; p < cntk; ++p) {
+      const int row = list[st + p];
+      const double* zp = Zt + row * ZS;
+      double z[DZ];
+#pragma unroll
+      for (int d = 0; d < DZ; ++d) z[d] = zp[d];
+      int f = 0;
+#pragma unroll
+      for (int i = 0; i < DZ; ++i) {
+#pragma unroll
+        for (int jx = i; jx < DZ; ++jx) { acc[f] = fma(z[i], z[jx], acc[f]); ++f; }
+        acc[f] += z[i]; ++f;
+      }
+      acc[F - 1] += 1.0;
+    }
+  }
+
+  // per-workgroup partial block [16 K16][F16_total] (+ 4 scalars: none from this pass)
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride;
+  if (tid < a.K16 * 16) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) P[(size_t)tid * FT + f] = tid < K ? acc[f] : 0.0;
+  }
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = P + (size_t)a.K16 * 16 * FT;
+    Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
+  }
+}
+
+bool label_stats_covers(int K, int D) { return K > 64 && K <= 256 && D >= 1 && D <= 9; }
+
+int label_stats_grid(const KernelArgs& a, int num_cu) {
+  const int64_t tiles = (a.N + kLsTile - 1) / kLsTile;
+  int64_t g = (int64_t)num_cu * 2;
+  if (g > tiles) g = tiles;
+  return (int)(g < 1 ? 1 : g);
+}
+
+hipError_t launch_label_stats(const KernelArgs& a, int grid, hipStream_t stream) {
+  typedef void (*fn_t)(const KernelArgs);
+  static const fn_t table[9] = {label_stats_kernel<1>, label_stats_kernel<2>, label_stats_kernel<3>, label_stats_kernel<4>,
+                                label_stats_kernel<5>, label_stats_kernel<6>, label_stats_kernel<7>, label_stats_kernel<8>,
+                                label_stats_kernel<9>};
+  if (a.D < 1 || a.D > 9) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(table[a.D - 1], dim3(grid), dim3(kWG), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mimo

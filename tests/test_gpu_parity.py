@@ -622,3 +622,39 @@ def test_small_shape_kernel_structures(engine, D, K):
         assert abs(sc[0] - lse.sum()) < 1e-11 * abs(lse.sum())
     finally:
         engine.set_structure('full')
+
+
+@pytest.mark.parametrize("D,K", [(8, 256), (8, 65), (8, 96), (8, 97), (5, 130), (9, 160), (9, 256), (1, 200), (3, 224),
+                                 (7, 128), (2, 255), (6, 100)])
+@pytest.mark.parametrize("N", [1, 15, 4099, 8 * 256 * 16 * 3 + 7])
+def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
+    """The row-owner label kernel (Theta in LDS, draw in registers; every instantiation KB = 6..16) and the
+    label-indexed statistics kernel (bitmap + popcount ranks, ascending rows per component) of mimo_rowwave.hip against
+    the oracle: labels bit-exact for host uniforms and the Philox stream, counts exact, statistics to 1e-11, identical bits
+    on a second launch; also with every row on ONE component and on three components (long per-component lists)."""
+    from oracle import mimo_oracle as O
+    rng = np.random.default_rng(900 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K, gibbs=True)["kind"] == "rowwave"
+    L = O.canonical_eval(Z, c, b, W)
+    u = rng.random(N)
+    lab, S = engine.gibbs_labels(c, b, W, u=u)
+    ref = O.sample_discrete_from_log(L, u)
+    assert np.array_equal(lab, ref)
+    n, sx, sxx = O.packed_stats(Z, O.one_hot(ref, K))
+    assert np.array_equal(S.n, n) and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    lab_p, Sp = engine.gibbs_labels(c, b, W, seed=5, sweep=3)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(5, np.arange(N), 3))
+    assert np.array_equal(lab_p, ref_p) and np.array_equal(Sp.n, np.bincount(ref_p, minlength=K))
+    lab_q, Sq = engine.gibbs_labels(c, b, W, seed=5, sweep=3)
+    assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx) and np.array_equal(Sq.sx, Sp.sx)
+    assert np.array_equal(engine.get_labels(), ref_p)
+    for lab_c in (np.full(N, K - 1), rng.choice([0, K // 2, K - 1], size=N)):
+        Sc = engine.label_stats(lab_c, K)
+        nc, sxc, sxxc = O.packed_stats(Z, O.one_hot(lab_c, K))
+        assert np.array_equal(Sc.n, nc) and rel_err(Sc.sx, sxc) < 1e-11 and rel_err(Sc.sxx, sxxc) < 1e-11
+    # a component switched off by its weight never receives a label
+    c2 = c.copy(); c2[K // 3] = -np.inf
+    lab_o, So = engine.gibbs_labels(c2, b, W, seed=1, sweep=1)
+    assert not np.any(lab_o == K // 3) and So.n[K // 3] == 0 and So.n.sum() == N
