@@ -180,6 +180,26 @@ int mimo_weighted_stats(mimo_ctx* ctx, const double* resp, int K, int flags, dou
  * last mimo_gibbs_labels left on the device. */
 int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, double* S);
 
+/* Categorical draw per column of a (K, N) table of (unnormalised) log-probabilities, K-major:
+ *   label_n = #{k : u_n cum_K > cum_k},  cum = cumsum_k exp(logp[k,n] - max_k),  lognorm_n = logsumexp_k logp[k,n].
+ * Replaces: mimo.utils.stats.sample_discrete_from_log (mimo/utils/stats.py:8-21; imported by the drivers at
+ *   mimo/mixtures/gmm.py:9-10, ilr.py:9-10) for a table the caller already holds — the fused label step
+ *   (mimo_gibbs_labels) never materialises that table and is what the drivers of this library use.
+ * logp: host table, or device with MIMO_F_DEVICE_IN, or NULL = the log-density table a call with MIMO_F_KEEP_LOGP left
+ *   on the device (then K and N must be its shape).  u: N uniforms in [0,1) (the values the reference's single
+ *   numpy.random.random(size=(1,N)) call returned) or NULL for the Philox stream (seed; counter (row0 + n, sweep)).
+ * labels_out: N int32 (host).  lognorms_out: N doubles (host) or NULL. */
+int mimo_sample_from_log(mimo_ctx* ctx, const double* logp, int K, int64_t N, const double* u, uint64_t seed,
+                         uint64_t sweep, int flags, int32_t* labels_out, double* lognorms_out);
+
+/* Statistics of RANDOM initial responsibilities generated on the device: r[k,n] = v_kn / sum_j v_jn, v_kn the
+ * Philox4x32-10 uniform of key `seed`, counter (row0 + n, k) — the start of the drivers with randomize=True
+ * (mimo/mixtures/gmm.py:265-267, ilr.py:200-202: resp = rand(K,N); resp /= resp.sum(0); weighted_statistics)
+ * without K N host uniforms going over PCIe (5 GB at N = 1e7, K = 64).  The table stays resident (mimo_get_resp).
+ * A stream of its own: numpy's generator cannot be continued on the device, so seeded runs that must reproduce the
+ * reference's trace keep the host draw + mimo_weighted_stats. */
+int mimo_random_resp_stats(mimo_ctx* ctx, int K, uint64_t seed, int flags, double* S);
+
 /* -sum_{k,n} t log t of a (K,N) table (entries <= 0 contribute 0, like nansum).
  * Replaces: the entropy term of variational_lowerbound_labels for caller-supplied responsibilities
  * (mimo/mixtures/gmm.py:353-355, ilr.py:310-312).  table == NULL uses the resident resp table. */

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mimo_weighted_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mimo_label_stats": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "mimo_table_entropy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _dp]),
+    "mimo_sample_from_log": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, C.c_uint64, C.c_uint64, C.c_int, _vp, _vp]),
+    "mimo_random_resp_stats": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     "mimo_host_nw_vi": (C.c_int, [C.c_int, C.c_int] + [_vp] * 13),
     "mimo_host_mnw_vi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_vp] * 15),
     "mimo_host_nw_gibbs": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),

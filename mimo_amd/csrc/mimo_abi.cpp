@@ -4,6 +4,7 @@
 // sequencing the gfx950 kernels of mimo_kernels.hip on the context's stream.
 #include "../../include/mimo_hip.h"
 #include "mimo_kernels.h"
+#include "mimo_extra.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -829,6 +830,66 @@ int mimo_label_stats(mimo_ctx* ctx, const int32_t* labels, int K, int flags, dou
     a.labels = ctx->lin;
   }
   return run_fused(ctx, a, kSrcLabels, flags, S, nullptr);
+  });
+}
+
+int mimo_sample_from_log(mimo_ctx* ctx, const double* logp, int K, int64_t N, const double* u, uint64_t seed,
+                         uint64_t sweep, int flags, int32_t* labels_out, double* lognorms_out) {
+  return guarded(ctx, [&]() -> int {
+  int rc = bind(ctx); if (rc) return rc;
+  if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
+  if (K < 1 || N < 0 || !labels_out) return fail(ctx, MIMO_E_INVALID, "mimo_sample_from_log: bad arguments");
+  const double* table = logp;
+  const size_t kn = (size_t)K * (size_t)(N > 0 ? N : 1), n1 = (size_t)(N > 0 ? N : 1);
+  if (!logp) {
+    if (!ctx->logp_valid || ctx->logp_K != K || ctx->N != N)
+      return fail(ctx, MIMO_E_STATE, "mimo_sample_from_log: logp is NULL and no (K=%d, N) log-density table is resident", K);
+    table = ctx->logp;
+  } else if (!(flags & MIMO_F_DEVICE_IN)) {
+    if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, kn))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->win, logp, (size_t)K * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    table = ctx->win;
+  }
+  const double* ud = nullptr;
+  if (u) {
+    if (flags & MIMO_F_DEVICE_IN) ud = u;
+    else {
+      if ((rc = ensure_dev(ctx, &ctx->u_d, &ctx->u_cap, n1))) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, u, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ud = ctx->u_d;
+    }
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // pageable host sources
+  if ((rc = ensure_dev(ctx, &ctx->lin, &ctx->lin_cap, n1))) return rc;
+  double* ln_d = nullptr;
+  if (lognorms_out) {
+    if ((rc = ensure_dev(ctx, &ctx->lse, &ctx->lse_cap, n1 > (size_t)(ctx->N > 0 ? ctx->N : 1) ? n1 : (size_t)(ctx->N > 0 ? ctx->N : 1)))) return rc;
+    ctx->lse_valid = false;      // (the buffer is borrowed: whatever log-normaliser it held is gone)
+    ln_d = ctx->lse;
+  }
+  HIP_TRY(ctx, launch_sample_table(table, K, N, ud, seed, sweep, ctx->row0, ctx->lin, ln_d, ctx->stream));
+  if (N > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(labels_out, ctx->lin, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (lognorms_out) HIP_TRY(ctx, hipMemcpyAsync(lognorms_out, ln_d, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIMO_OK;
+  });
+}
+
+int mimo_random_resp_stats(mimo_ctx* ctx, int K, uint64_t seed, int flags, double* S) {
+  return guarded(ctx, [&]() -> int {
+  int rc = bind(ctx); if (rc) return rc;
+  if ((rc = check_shapes(ctx, K))) return rc;
+  if (!S) return fail(ctx, MIMO_E_INVALID, "mimo_random_resp_stats: S is NULL");
+  const size_t kn = (size_t)K * (size_t)(ctx->N > 0 ? ctx->N : 1);
+  if ((rc = ensure_dev(ctx, &ctx->resp, &ctx->resp_cap, kn))) return rc;
+  ctx->resp_K = K; ctx->resp_valid = true;
+  HIP_TRY(ctx, launch_random_resp(ctx->resp, K, ctx->N, seed, ctx->row0, ctx->stream));
+  KernelArgs a;
+  fill_args(ctx, K, &a);
+  a.resp = ctx->resp;
+  return run_fused(ctx, a, kSrcWeights, flags, S, nullptr);
   });
 }
 

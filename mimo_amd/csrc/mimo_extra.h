@@ -1,0 +1,15 @@
+// Launchers of the helper kernels that are not part of the tile-kernel interface (kept out of mimo_kernels.h so that
+// adding one does not rebuild every instantiation of the tile kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mimo {
+
+// categorical draw from a (K, N) table of log-probabilities (mimo_small.hip)
+hipError_t launch_sample_table(const double* logp, int K, int64_t N, const double* u, uint64_t seed, uint64_t sweep,
+                               int64_t row0, int32_t* labels, double* lognorms, hipStream_t stream);
+// random column-normalised (K, N) table from the Philox stream (mimo_small.hip)
+hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int64_t row0, hipStream_t stream);
+
+}  // namespace mimo

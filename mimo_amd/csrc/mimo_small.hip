@@ -345,6 +345,72 @@ void small_kernel(const KernelArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Categorical draw from a caller-supplied (K, N) table of log-probabilities, one thread per column
+// (mimo/utils/stats.py:8-21 with axis = 0): label = #{k : u cum_K > cum_k}, cum = cumsum_k exp(l - max), and
+// optionally lognorm_n = logsumexp_k l.  Bound by the one-and-a-half reads of the table (pass 1: max and total,
+// pass 2: cumulative sums against the threshold); K-major rows make every read of a wave contiguous.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void sample_table_kernel(const double* __restrict__ logp, int K, int64_t N,
+                                                           const double* __restrict__ u, uint64_t seed, uint64_t sweep,
+                                                           int64_t row0, int32_t* __restrict__ labels,
+                                                           double* __restrict__ lognorms) {
+  __shared__ double etab[64];
+  if (threadIdx.x < 64) etab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+  wg_sync();
+  const int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (n >= N) return;
+  double m = logp[n];
+  for (int k = 1; k < K; ++k) m = fmax(m, logp[(int64_t)k * N + n]);
+  double tot = 0.0;
+  for (int k = 0; k < K; ++k) tot += exp_nonpos(logp[(int64_t)k * N + n] - m, etab);
+  const double uu = u ? u[n] : philox_uniform(seed, (uint64_t)(row0 + n), sweep);
+  const double thr = uu * tot;
+  double cum = 0.0;
+  int cnt = 0;
+  for (int k = 0; k < K; ++k) {
+    cum += exp_nonpos(logp[(int64_t)k * N + n] - m, etab);
+    cnt += thr > cum ? 1 : 0;
+  }
+  labels[n] = cnt < K ? cnt : K - 1;
+  if (lognorms) lognorms[n] = m + log(tot);
+}
+
+hipError_t launch_sample_table(const double* logp, int K, int64_t N, const double* u, uint64_t seed, uint64_t sweep,
+                               int64_t row0, int32_t* labels, double* lognorms, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sample_table_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, logp, K, N, u, seed,
+                     sweep, row0, labels, lognorms);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Random initial responsibilities on the device (the drivers' randomize=True start, mimo/mixtures/gmm.py:265-267:
+// resp = rand(K, N); resp /= resp.sum(0)) without drawing K N uniforms on the host and shipping them over PCIe:
+// r[k, n] = v_kn / sum_j v_jn with v_kn the Philox4x32-10 uniform of key `seed`, counter (row0 + n, k) — a stated
+// stream of its own (numpy's generator cannot be continued on the device), independent of the number of shards.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void random_resp_kernel(double* __restrict__ resp, int K, int64_t N, uint64_t seed,
+                                                          int64_t row0) {
+  const int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (n >= N) return;
+  double tot = 0.0;
+  for (int k = 0; k < K; ++k) {
+    // (0, 1]: a column of zeros cannot happen
+    const double v = philox_uniform(seed, (uint64_t)(row0 + n), (uint64_t)k) + 1.1102230246251565e-16;
+    resp[(int64_t)k * N + n] = v;
+    tot += v;
+  }
+  const double inv = 1.0 / tot;
+  for (int k = 0; k < K; ++k) resp[(int64_t)k * N + n] *= inv;
+}
+
+hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int64_t row0, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(random_resp_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, resp, K, N, seed, row0);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 // components per lane / lanes per row for (Dz, K): KL = 4 up to Dz = 3, 2 at Dz = 4 (Theta rows + accumulators of a

@@ -334,6 +334,38 @@ class HipEngine:
         S = SuffStats.from_packed(S, K, self.D)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
+    def random_resp_stats(self, K, seed=0):
+        """Statistics of random initial responsibilities drawn on the device (mimo_random_resp_stats): the
+        randomize=True start of the drivers without K N host uniforms; the table stays resident (get_resp)."""
+        K = int(K)
+        S = np.empty((K, 1 + self.D + self.D * self.D))
+        self._check(self._lib.mimo_random_resp_stats(self._ctx, K, int(seed), 0, _ptr(S)))
+        self._K = K
+        S = SuffStats.from_packed(S, K, self.D)
+        return self._linear_stats(S, self._xx_total()) if self._linear() else S
+
+    def sample_from_log(self, logp=None, K=None, u=None, seed=0, sweep=0, return_lognorms=False):
+        """Categorical draw per column of a (K, N) log-probability table (mimo_sample_from_log): a host array, or
+        None for the log-density table a call with keep_logp=True left on the device.  Returns labels (N,) int32
+        [, lognorms (N,)]."""
+        if logp is None:
+            K, N, p = int(K if K is not None else self._K), self.N, None
+        else:
+            logp = _f64(logp)
+            if logp.ndim != 2:
+                raise ValueError("log-probabilities must be (K, N)")
+            K, N = logp.shape
+            p = _ptr(logp)
+        if u is not None:
+            u = _f64(u).reshape(-1)
+            if u.shape[0] != N:
+                raise ValueError("u must hold one uniform per column")
+        labels = np.empty(N, dtype=np.int32)
+        ln = np.empty(N) if return_lognorms else None
+        self._check(self._lib.mimo_sample_from_log(self._ctx, p, K, N, _ptr(u) if u is not None else None, int(seed), int(sweep),
+                                                   0, _ptr(labels), _ptr(ln) if ln is not None else None))
+        return (labels, ln) if return_lognorms else labels
+
     def table_entropy(self, table=None):
         """-sum t log t of a (K,N) host table (None: the resident responsibilities)."""
         out = C.c_double()

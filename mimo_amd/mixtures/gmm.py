@@ -33,11 +33,47 @@ def _component_stats(S, components=None):
     return Stats([S.sx, S.n, S.sxx, S.n])
 
 
+def random_start(eng, K, init_rng='host', seed=0):
+    """Statistics of the drivers' random start (gmm.py:265-267: resp = rand(K, N); resp /= resp.sum(0)).
+    init_rng='host'  : numpy.random.rand(K, N) exactly as the reference draws it (seeded parity) — K N doubles over PCIe;
+    init_rng='philox': the table is drawn on the device from the Philox stream keyed by `seed`, counter (row, k)
+                       (HipEngine.random_resp_stats): no host draw, no upload — 5 GB less traffic at N = 1e7, K = 64."""
+    if init_rng == 'philox':
+        return eng.random_resp_stats(K, seed)
+    if init_rng != 'host':
+        raise ValueError(init_rng)
+    resp = npr.rand(K, eng.N)
+    resp /= np.sum(resp, axis=0)
+    return eng.weighted_stats(resp)
+
+
 def canonical_inner(c, b, W, S):
     """sum_kn r_kn l_kn = <Theta, S(r)>  for l = c + b.x - 1/2 x'Wx  and S the statistics of r."""
     if S.sxx is None:      # 'linear' structure: one W for all components, pooled second moment
         return float(np.sum(c * S.n) + np.sum(b * S.sx) - 0.5 * np.sum(W[0] * S.sxx_total))
     return float(np.sum(c * S.n) + np.sum(b * S.sx) - 0.5 * np.sum(W * S.sxx))
+
+
+class LazyTable:
+    """A (K, N) table that is computed on first use (np.asarray(t), t[...], arithmetic through __array__)."""
+
+    def __init__(self, compute, shape):
+        self._compute, self._value, self.shape = compute, None, tuple(shape)
+
+    def __array__(self, dtype=None, copy=None):
+        if self._value is None:
+            self._value = self._compute()
+        return self._value if dtype is None else self._value.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.__array__()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def evaluated(self):
+        return self._value is not None
 
 
 class MixtureOfGaussians:
@@ -104,16 +140,15 @@ class MixtureOfGaussians:
         return eng.get_resp(self.size)
 
     # ---- EM ------------------------------------------------------------------------------------
-    def max_likelihood(self, obs, randomize=True, weights=None, maxiter=250, progress_bar=True, process_id=0):
+    def max_likelihood(self, obs, randomize=True, weights=None, maxiter=250, progress_bar=True, process_id=0,
+                       init_rng='host', seed=0):
         """gmm.py:77-103.  Each iteration is one fused pass: the E-step under the new parameters
         also yields the statistics of the next M-step and sum_n log p(x_n)."""
         eng = self._bind(obs)
         if weights is not None:
             return self._max_likelihood_weighted(eng, randomize, weights, maxiter, progress_bar, process_id)
         if randomize:
-            resp = npr.rand(self.size, eng.N)
-            resp /= np.sum(resp, axis=0)
-            S = eng.weighted_stats(resp)
+            S = random_start(eng, self.size, init_rng, seed)
         else:
             S, _ = eng.estep(*self.canonical())
         log_lik = []
@@ -190,13 +225,11 @@ class BayesianMixtureOfGaussians:
         return c + self.gating.expected_log_gating(), b, W
 
     # ---- MAP-EM --------------------------------------------------------------------------------
-    def max_aposteriori(self, obs, randomize=True, maxiter=250, progress_bar=True, process_id=0):
+    def max_aposteriori(self, obs, randomize=True, maxiter=250, progress_bar=True, process_id=0, init_rng='host', seed=0):
         """gmm.py:176-204."""
         eng = self._bind(obs)
         if randomize:
-            resp = npr.rand(self.size, eng.N)
-            resp /= np.sum(resp, axis=0)
-            S = eng.weighted_stats(resp)
+            S = random_start(eng, self.size, init_rng, seed)
         else:
             S, _ = eng.estep(*self.likelihood.canonical())
         log_prob = []
@@ -265,12 +298,25 @@ class BayesianMixtureOfGaussians:
             return eng.gibbs_labels(c, b, W, seed=seed, sweep=sweep, stats=stats, return_labels=return_labels)
         raise ValueError(label_rng)
 
-    def resample_labels(self, obs):
-        """gmm.py:227-230 -> (log_prob (K,N), labels int32); reference-shaped (copies the table)."""
+    def resample_labels(self, obs, lazy=True):
+        """gmm.py:227-230 -> (log_prob (K, N), labels int32).  The reference returns the table it drew from; almost
+        no caller reads it, and at C3 it is 20 GB.  lazy=True (default) returns a LazyTable: the draw runs fused (no
+        table anywhere), and the table is evaluated — with the parameters captured now — only if it is converted to
+        an array or indexed; lazy=False computes and copies it eagerly like the reference."""
         eng = self._bind(obs)
         c, b, W = self.likelihood.canonical()
-        labels, _ = eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=False, keep_logp=True)
-        return eng.get_logp(self.size), labels
+        u = npr.random(size=(1, eng.N))
+        if not lazy:
+            labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False, keep_logp=True)
+            return eng.get_logp(self.size), labels
+        labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False)
+        c, b, W = np.array(c), np.array(b), np.array(W)
+
+        def table():
+            e = self._bind(obs)
+            e.estep(c, b, W, stats=False, keep_logp=True)
+            return e.get_logp(len(c))
+        return LazyTable(table, (len(c), eng.N)), labels
 
     def resample_gating(self, labels):
         self.gating.resample(np.asarray(labels).astype(int))
@@ -297,14 +343,12 @@ class BayesianMixtureOfGaussians:
         return eng.get_resp(self.size)
 
     def meanfield_coordinate_descent(self, obs, randomize=True, maxiter=250, tol=1e-8,
-                                     progress_bar=True, process_id=0, sample_likelihood=True):
+                                     progress_bar=True, process_id=0, sample_likelihood=True, init_rng='host', seed=0):
         """gmm.py:261-287.  Returns the ELBO list.  `sample_likelihood=False` drops the reference's
         per-iteration likelihood.params = posterior.rvs() (host RNG only; no effect on the ELBO)."""
         eng = self._bind(obs)
         if randomize:
-            resp = npr.rand(self.size, eng.N)
-            resp /= np.sum(resp, axis=0)
-            S = eng.weighted_stats(resp)
+            S = random_start(eng, self.size, init_rng, seed)
         else:
             S, _ = eng.estep(*self.canonical_expected())
         vlb = []

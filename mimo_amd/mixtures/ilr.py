@@ -13,7 +13,7 @@ from mimo_amd import engine as _engine
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
 from mimo_amd.distributions.lingauss import split_joint_stats, joint_rows
-from mimo_amd.mixtures.gmm import canonical_inner
+from mimo_amd.mixtures.gmm import canonical_inner, random_start, LazyTable
 
 
 class Standardizer:
@@ -206,11 +206,23 @@ class BayesianMixtureOfLinearGaussians:
             return eng.gibbs_labels(c, b, W, seed=seed, sweep=sweep, stats=stats, return_labels=return_labels)
         raise ValueError(label_rng)
 
-    def resample_labels(self, x, y):
-        eng = self._bind(*self._as2d(x, y))
+    def resample_labels(self, x, y, lazy=True):
+        """ilr.py:161-164 -> (log_prob, labels); the table is lazy by default (see gmm.py, resample_labels)."""
+        xx, yy = self._as2d(x, y)
+        eng = self._bind(xx, yy)
         c, b, W = self.likelihood.canonical()
-        labels, _ = eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=False, keep_logp=True)
-        return eng.get_logp(self.size), labels
+        u = npr.random(size=(1, eng.N))
+        if not lazy:
+            labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False, keep_logp=True)
+            return eng.get_logp(self.size), labels
+        labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False)
+        c, b, W = np.array(c), np.array(b), np.array(W)
+
+        def table():
+            e = self._bind(xx, yy)
+            e.estep(c, b, W, stats=False, keep_logp=True)
+            return e.get_logp(len(c))
+        return LazyTable(table, (len(c), eng.N)), labels
 
     def _as2d(self, x, y):
         return (np.asarray(x, dtype=float).reshape(-1, self.input_dim),
@@ -241,14 +253,12 @@ class BayesianMixtureOfLinearGaussians:
         return eng.get_resp(self.size)
 
     def meanfield_coordinate_descent(self, x, y, randomize=True, maxiter=250, tol=1e-8,
-                                     progress_bar=True, process_id=0, sample_likelihood=True):
+                                     progress_bar=True, process_id=0, sample_likelihood=True, init_rng='host', seed=0):
         """ilr.py:196-228."""
         xx, yy = self._scaled(x, y)
         eng = self._bind(xx, yy)
         if randomize:
-            resp = npr.rand(self.size, eng.N)
-            resp /= np.sum(resp, axis=0)
-            S = eng.weighted_stats(resp)
+            S = random_start(eng, self.size, init_rng, seed)
         else:
             S, _ = eng.estep(*self.canonical_expected())
         vlb = []

@@ -247,6 +247,15 @@ class ShardedEngine:
         S, _ = self._allreduce_host(self.inner.label_stats(labels, K), [])
         return S
 
+    def random_resp_stats(self, K, seed=0):
+        """Random initial responsibilities on every shard (Philox counters use the global row: the draw does not
+        depend on the number of ranks), statistics summed over the ranks."""
+        S, _ = self._allreduce_host(self.inner.random_resp_stats(K, seed), [])
+        return S
+
+    def sample_from_log(self, *args, **kwargs):
+        return self.inner.sample_from_log(*args, **kwargs)      # row-local
+
     def table_entropy(self, table=None):
         return float(self._allreduce_scalars([self.inner.table_entropy(table)])[0])
 

@@ -30,6 +30,10 @@ GMM_CASES = ["gmm_c1_d2_k4_dir", "gmm_c2_d16_k16_dir", "gmm_c2_d16_k64_dir", "gm
              "gmm_c5_d32_k16_dir", "gmm_tail_d5_k7_stick"]
 ILR_CASES = ["ilr_c4_dx8_dy4_k16_stick", "ilr_dx1_dy1_k6_dir"]
 GIBBS_CASES = ["gibbs_c1_trace", "gibbs_stick_trace"]
+# one full-K fixture per BASELINE config whose K is capped above (C3: K = 256, C4: K = 64, C5: K = 128), generated from the
+# reference by `make_golden.py fullk`
+GMM_FULLK_CASES = ["gmm_c3_d8_k256_stick", "gmm_c5_d32_k128_dir"]
+ILR_FULLK_CASES = ["ilr_c4_dx8_dy4_k64_stick"]
 
 
 def gating_of(g, prefix):

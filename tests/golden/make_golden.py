@@ -735,6 +735,12 @@ if __name__ == "__main__":
         tied_ilr_prediction_case("tied_ilr_sine_k8", N=400, K=8, seed=1350)
         tied_ilr_prediction_case("tied_ilr_dx3_dy2_k6", N=300, K=6, seed=1351, dx=3, dy=2)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullk":
+        # one full-K, N = 257 (129 at D = 32) fixture per BASELINE config whose K was capped above
+        gmm_case("gmm_c3_d8_k256_stick", N=257, D=8, K=256, kind='stick', seed=1358, vi_iters=5)
+        ilr_case("ilr_c4_dx8_dy4_k64_stick", N=257, dx=8, dy=4, K=64, kind='stick', seed=1359, vi_iters=5)
+        gmm_case("gmm_c5_d32_k128_dir", N=129, D=32, K=128, kind='dirichlet', seed=1360, vi_iters=3)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "drivers":
         driver_traces_case("drivers_d3_k5_dir", N=600, D=3, K=5, kind='dirichlet', seed=1347)
         ilr_svi_case("ilr_svi_dx2_dy1_k8", N=500, dx=2, dy=1, K=8, seed=1348)

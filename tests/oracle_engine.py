@@ -90,6 +90,19 @@ class OracleEngine:
             raise ValueError("labels out of range")
         return self._stats(O.one_hot(labels, K), getattr(self, 'structure', 'full') == 'linear')
 
+    def random_resp_stats(self, K, seed=0):
+        rows = self.row0 + np.arange(self.N)
+        V = np.stack([O.philox_uniforms(seed, rows, k) for k in range(K)]) + 1.1102230246251565e-16 if self.N else np.zeros((K, 0))
+        self._resp, self._K = V / np.sum(V, axis=0), K
+        return self._stats(self._resp, getattr(self, 'structure', 'full') == 'linear')
+
+    def sample_from_log(self, logp=None, K=None, u=None, seed=0, sweep=0, return_lognorms=False):
+        L = self._logp if logp is None else np.asarray(logp, float)
+        if u is None:
+            u = O.philox_uniforms(seed, self.row0 + np.arange(L.shape[1]), sweep)
+        labels = O.sample_discrete_from_log(L, np.asarray(u).reshape(-1))
+        return (labels, logsumexp(L, axis=0)) if return_lognorms else labels
+
     def table_entropy(self, table=None):
         t = self._resp if table is None else np.asarray(table, float)
         with np.errstate(invalid='ignore', divide='ignore'):

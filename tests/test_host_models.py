@@ -123,3 +123,26 @@ def test_bind_sees_in_place_edits():
     y *= 2.
     z1 = joint_rows(x, y)
     assert z1 is not z0 and np.array_equal(z1[:, 2:], y)
+
+
+def test_sample_discrete_from_log_and_random_start_on_the_double():
+    """Host logic of the two API additions with the oracle-backed double: axis handling / numpy.random call shape of
+    sample_discrete_from_log, and the init_rng switch of the drivers."""
+    import numpy as np
+    import numpy.random as npr
+    from oracle import mimo_oracle as O
+    from mimo_amd.utils.stats import sample_discrete_from_log
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal((6, 50, 3))
+    npr.seed(1)
+    got = sample_discrete_from_log(p, axis=0, engine=OracleEngine())
+    npr.seed(1)
+    u = npr.random(size=(1, 50, 3))
+    assert np.array_equal(got.reshape(-1), O.sample_discrete_from_log(p.reshape(6, -1), u.reshape(-1))) and got.shape == (50, 3)
+    from conftest import load_golden
+    g = load_golden("gmm_c1_d2_k4_dir")
+    kind, model = mc.build_gmm(g, OracleEngine())
+    vlb = model.meanfield_coordinate_descent(g["X"], randomize=True, maxiter=5, tol=0., progress_bar=False, init_rng='philox', seed=3)
+    assert np.all(np.diff(vlb) > -1e-8 * abs(vlb[-1]))
+    with pytest.raises(ValueError):
+        model.meanfield_coordinate_descent(g["X"], randomize=True, maxiter=1, progress_bar=False, init_rng='nope')

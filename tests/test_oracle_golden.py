@@ -4,13 +4,14 @@ import numpy as np
 import numpy.random as npr
 import pytest
 
-from conftest import (load_golden, rel_err, GMM_CASES, ILR_CASES, GIBBS_CASES, gating_of, nw_of, mnw_of)
+from conftest import (load_golden, rel_err, GMM_CASES, ILR_CASES, GIBBS_CASES, GMM_FULLK_CASES, ILR_FULLK_CASES, gating_of, nw_of,
+                      mnw_of)
 from oracle import mimo_oracle as O
 
 TOL = 1e-12
 
 
-@pytest.mark.parametrize("name", GMM_CASES)
+@pytest.mark.parametrize("name", GMM_CASES + GMM_FULLK_CASES)
 def test_gmm_tables_and_stats(name):
     g = load_golden(name)
     X, K = g["X"], int(g["K"])
@@ -58,7 +59,7 @@ def test_gmm_tables_and_stats(name):
     assert abs(ident - (g["vlb_obs"] + g["vlb_labels"])) < 1e-10 * abs(ident)
 
 
-@pytest.mark.parametrize("name", GMM_CASES)
+@pytest.mark.parametrize("name", GMM_CASES + GMM_FULLK_CASES)
 def test_gmm_labels_and_update(name):
     g = load_golden(name)
     X, K = g["X"], int(g["K"])
@@ -76,7 +77,7 @@ def test_gmm_labels_and_update(name):
         assert rel_err(a, b) < 1e-9
 
 
-@pytest.mark.parametrize("name", GMM_CASES)
+@pytest.mark.parametrize("name", GMM_CASES + GMM_FULLK_CASES)
 def test_gmm_vi_trace(name):
     g = load_golden(name)
     X = g["X"]
@@ -93,7 +94,7 @@ def test_gmm_vi_trace(name):
         assert rel_err(a, b) < 1e-7
 
 
-@pytest.mark.parametrize("name", ILR_CASES)
+@pytest.mark.parametrize("name", ILR_CASES + ILR_FULLK_CASES)
 def test_ilr_tables_stats_trace(name):
     g = load_golden(name)
     X, Y, K = g["X"], g["Y"], int(g["K"])

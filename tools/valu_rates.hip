@@ -70,6 +70,58 @@ static void run(const char* name, int cus, double* out) {
   printf("   (cycles at 2.4 GHz per instruction per SIMD)\n");
 }
 
+// co-residency: waves 0-3 of a 512-thread workgroup issue v_mfma_f64_16x16x4_f64 back to back, waves 4-7 a VALU stream
+// of one kind (0: v_fma_f64, 4: v_fma_f32, 5: integer).  Do the VALU instructions overlap the matrix instructions?
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ __launch_bounds__(512) void kmix(double* out, int mi, int vi, double a, double b) {
+  double r = 0;
+  if ((threadIdx.x >> 6) < 4) {
+    d4 acc[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+    double av = a + threadIdx.x * 1e-9;
+    for (int it = 0; it < mi; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av), "v"(b));
+    }
+    for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else {
+    double x0 = a, x1 = a * 2, x2 = a * 3, x3 = a * 4;
+    float f0 = 1, f1 = 2, f2 = 3, f3 = 4, fa = 0.999f, fb = 1e-3f;
+    int i0 = threadIdx.x, i1 = 1, i2 = 2, i3 = 3, ia = 0x7fffffff, ib = 3;
+    for (int it = 0; it < vi; ++it) {
+      if constexpr (KIND == 0)
+        asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b), "v"(a));
+      if constexpr (KIND == 4)
+        asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fa), "v"(fb));
+      if constexpr (KIND == 5)
+        asm volatile("v_lshl_add_u32 %0, %0, 1, %4\n\tv_and_b32 %1, %1, %5\n\tv_lshl_add_u32 %2, %2, 1, %4\n\tv_and_b32 %3, %3, %5"
+                     : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(ib), "v"(ia));
+    }
+    r = x0 + x1 + x2 + x3 + f0 + f1 + f2 + f3 + i0 + i1 + i2 + i3;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int KIND>
+static void runmix(const char* name, int cus, double* out) {
+  const int mi = 20000;      // 4 MFMAs per iteration: 80000 MFMAs = 5.12e6 cycles alone
+  printf("%-22s", name);
+  for (int per : {0, 4, 8, 16}) {      // VALU instructions per MFMA
+    const int vi = per * mi;             // 4 VALU per iteration
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kmix<KIND>, dim3(cus), dim3(512), 0, 0, out, mi, vi, 0.999, 1e-3);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0); hipLaunchKernelGGL(kmix<KIND>, dim3(cus), dim3(512), 0, 0, out, mi, vi, 0.999, 1e-3); hipEventRecord(e1);
+      hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+    }
+    printf("  %2d/MFMA: %6.3f ms", per, best);
+  }
+  printf("\n");
+}
+
 int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
@@ -82,5 +134,9 @@ int main() {
   run<5>("v_lshl_add_u32 / v_and_b32", cus, out);
   run<6>("f64 fma : int 1 : 1", cus, out);
   run<7>("v_fma_f64 dependent chain", cus, out);
+  printf("MFMA f64 waves + VALU waves on the same SIMDs (time of 80000 MFMAs per SIMD alone: first column)\n");
+  runmix<0>("with v_fma_f64", cus, out);
+  runmix<4>("with v_fma_f32", cus, out);
+  runmix<5>("with integer VALU", cus, out);
   return 0;
 }
