@@ -225,7 +225,45 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
                  const double* y, const double* P, const double* ld,
                  double* mu, double* covar, double* nlpd);
 
-/* ---- copy-outs of device-resident tables ----------------------------------------------- */
+/* ---- rows with missing values ------------------------------------------------------------------
+ * A data row that holds a NaN is treated the way the reference's Gaussian family treats it: it is LEFT OUT of every
+ * sufficient statistic (mimo/distributions/gaussian.py:493-494: idx = ~isnan(data).any(axis=1); also :468, :650, :796)
+ * and its log-density is the normaliser-only value, i.e. the canonical form at z = 0 (gaussian.py:512-520:
+ * nan_to_num, then the data-dependent part of those rows is set to 0) — tables, labels and the ELBO scalars carry it
+ * like any other row.  mimo_upload / mimo_attach find such rows once (one pass over the device copy; a borrowed buffer
+ * is copied before it is touched), every later call on the data set applies the row mask.
+ * The reference's GATING update counts the labels / responsibilities of those rows (bincount(labels), resp.sum(1)
+ * over all rows) while its component update drops them; the packed block returned here is the component one, and
+ * mimo_nan_info gives what the gating update needs on top:
+ *   n_bad          number of rows with a NaN (0: nothing below applies)
+ *   row_mask_out   N doubles, 1 = complete row (NULL to skip)
+ *   label_counts   K int64: labels the last label pass (mimo_gibbs_labels / mimo_label_stats) put on NaN rows, per
+ *                  component (NULL to skip).  For a softmax pass every NaN row has the responsibilities
+ *                  softmax_k(c_k): n_bad times that vector is the gating part, computed by the caller.
+ * Linear-Gaussian experts: the rule applies to the joint row z = [x, y] (a NaN anywhere drops the row from the
+ * statistics, lingauss.py:103-104); the reference's log-density only zeroes rows where x AND y hold a NaN
+ * (lingauss.py:150-151) and evaluates the others on nan_to_num'ed values — that corner is not reproduced. */
+int mimo_nan_info(mimo_ctx* ctx, int64_t* n_bad, double* row_mask_out, int K, int64_t* label_counts);
+
+/* ---- sharding over the GPUs of a node/* ---- sharding over the GPUs of a node (one process per GPU) ----------------------------------
+ * The path shards over rows: every per-datum quantity is local, the only exchange per pass is the sum of the packed
+ * statistic block [K (1 + Dz + Dz^2)] + 3 scalars over the ranks (0.14 MB at K = 64, Dz = 16).
+ * With a communicator attached, every entry point that returns statistics / scalars (mimo_estep, mimo_estep_weighted,
+ * mimo_gibbs_labels, mimo_weighted_stats, mimo_label_stats, mimo_random_resp_stats, mimo_wait) returns them SUMMED OVER
+ * THE RANKS: one RCCL all-reduce(sum, float64) on the context's stream behind the kernels, before the copy to the
+ * host (or in place in the caller's device buffer with MIMO_F_DEVICE_OUT).  Labels and tables stay with their rank.
+ * Every rank makes the same calls in the same order (collective semantics); mimo_set_row_offset gives each rank the
+ * global index of its first row so that the Philox label stream does not depend on the number of ranks.
+ * The reference has no counterpart (single process, NumPy).  mimo_amd/sharded.py is the same step through
+ * torch.distributed for Python hosts; these entry points are for hosts without it.
+ *   rank 0: mimo_comm_unique_id(id)  ->  the application hands the 128 bytes to the other ranks  ->
+ *   every rank: mimo_comm_init(ctx, id, rank, world)
+ * RCCL is opened at run time; MIMO_E_UNSUPPORTED if librccl cannot be loaded. */
+int mimo_comm_unique_id(char* id128);
+int mimo_comm_init(mimo_ctx* ctx, const char* id128, int rank, int world);
+int mimo_comm_destroy(mimo_ctx* ctx);
+
+/* ---- copy-outs of device-resident tables/* ---- copy-outs of device-resident tables ----------------------------------------------- */
 int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
 int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);
 int mimo_get_lse(mimo_ctx* ctx, double* lse_host /* N */);

@@ -18,6 +18,13 @@
 
 using namespace mimo;
 
+namespace mimo_comm {      // mimo_comm.cpp (RCCL through dlopen)
+int unique_id(char* out128, char* msg, size_t msglen);
+int init(void** comm, const char* id128, int rank, int world, char* msg, size_t msglen);
+int destroy(void* comm);
+int allreduce_sum_f64(void* comm, double* buf, size_t count, hipStream_t stream, char* msg, size_t msglen);
+}
+
 struct mimo_ctx {
   int device = 0;
   int num_cu = 256;
@@ -61,6 +68,16 @@ struct mimo_ctx {
   double* win = nullptr;   size_t win_cap = 0;    // staged host weights
   int32_t* lin = nullptr;  size_t lin_cap = 0;    // staged host labels
 
+  // rows with missing values (NaN): zeroed in the owned copy, excluded from every statistic through the mask
+  double* row_mask = nullptr;   size_t mask_cap = 0;      // (N,) 1 = complete row
+  int64_t n_bad = 0;
+  unsigned long long* cnt_d = nullptr;                    // [1 + 256]: scan count, labels drawn on NaN rows per component
+  int32_t* labels_tmp = nullptr; size_t labels_tmp_cap = 0;
+  double* table_tmp = nullptr;  size_t table_tmp_cap = 0;
+  int bad_counts_K = 0;         // > 0: cnt_d[1..K] holds the label counts of the NaN rows of the last label pass
+
+  void* comm = nullptr;         // RCCL communicator (mimo_comm_init): every pass then returns statistics summed over the ranks
+  int comm_world = 1;
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
 
   // pending asynchronous call (MIMO_F_ASYNC)
@@ -416,7 +433,7 @@ static int timed_launch(mimo_ctx* ctx, const char* name, L&& launch) {
 
 // run the pass (one fused kernel, the two-stage sequence, or the small-shape kernel) -> reduce -> unpack;
 // deliver S / scalars to host or device pointers
-static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
+static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
   const int K = a.K, D = a.D;
   const int Kpad = a.K16 * 16;
   const bool small = use_small(ctx, K);
@@ -495,6 +512,12 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
       if (rc) return rc;
       st.resp = e.resp; st.labels = e.labels; st.write_scalars = 0;
       stats_src = e.gibbs ? kSrcLabels : kSrcWeights;
+      if (ctx->n_bad > 0 && !e.gibbs && a.do_stats) {     // rows with NaN: their weights are dropped from the statistics
+        const size_t kn = (size_t)K * (size_t)ctx->N;
+        if ((rc = ensure_dev(ctx, &ctx->table_tmp, &ctx->table_tmp_cap, kn))) return rc;
+        HIP_TRY(ctx, launch_mask_table(e.resp, ctx->row_mask, ctx->table_tmp, K, ctx->N, ctx->stream));
+        st.resp = ctx->table_tmp;
+      }
     }
     if (a.do_stats) {
       const int gmax = stats_group_ncb(a.K16);
@@ -528,12 +551,22 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   const int F = small ? feat_count(D) : ctx->F, mask = small ? ctx->structure : 0;
   if (device_out) {
     HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? S : nullptr, scalars, ctx->stream, mask));
+    if (ctx->comm) {     // sharded through this library: sum over the ranks where the caller wants the block
+      char msg[256];
+      if (want_stats && (rc = mimo_comm::allreduce_sum_f64(ctx->comm, S, slen, ctx->stream, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
+      if (scalars && (rc = mimo_comm::allreduce_sum_f64(ctx->comm, scalars, 3, ctx->stream, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
+    }
     return MIMO_OK;
   }
   if ((rc = ensure_dev(ctx, &ctx->S_d, &ctx->S_cap, slen + 4))) return rc;
   if ((rc = ensure_pinned(ctx, &ctx->S_h, &ctx->S_hcap, slen + 4))) return rc;
+  if (ctx->comm && !want_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->S_d, 0, slen * sizeof(double), ctx->stream));
   HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? ctx->S_d : nullptr,
                              ctx->S_d + slen, ctx->stream, mask));
+  if (ctx->comm) {       // ONE all-reduce(sum, f64) of [K (1 + Dz + Dz^2) + 3] per pass, behind the kernels on the same stream
+    char msg[256];
+    if ((rc = mimo_comm::allreduce_sum_f64(ctx->comm, ctx->S_d, slen + 3, ctx->stream, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (flags & MIMO_F_ASYNC) {
     ctx->pending_async = true; ctx->pending_slen = slen; ctx->pending_stats = want_stats;
@@ -543,6 +576,53 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
   if (want_stats) memcpy(S, ctx->S_h, slen * sizeof(double));
   if (scalars) memcpy(scalars, ctx->S_h + slen, 3 * sizeof(double));
   return MIMO_OK;
+}
+
+// Every pass goes through here.  Data without NaN rows: straight to run_pass.  With NaN rows (zeroed in the library's
+// copy, ctx->row_mask = 0 there): the log-densities, tables, labels and ELBO scalars are those of the zeroed rows
+// (= the reference's normaliser-only log-density), the statistics leave those rows out —
+//   softmax pass : the mask becomes the per-row weight vector of the statistics (times the caller's weights, if any);
+//   label pass   : labels first (no statistics), then the statistics of the labels with the NaN rows set to -1; the
+//                  labels drawn ON the NaN rows are counted per component for the gating update (mimo_nan_info);
+//   statistics of a caller's table / labels: masked copies.
+static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
+  if (ctx->n_bad <= 0) return run_pass(ctx, a, src, flags, S, scalars);
+  int rc;
+  const int64_t N = ctx->N;
+  ctx->bad_counts_K = 0;
+  if (src == kSrcEstep && !a.gibbs) {
+    if (!a.u) {
+      a.u = ctx->row_mask;
+    } else {       // caller's row weights x mask (one column of a "table")
+      if ((rc = ensure_dev(ctx, &ctx->table_tmp, &ctx->table_tmp_cap, (size_t)N))) return rc;
+      HIP_TRY(ctx, launch_mask_table(a.u, ctx->row_mask, ctx->table_tmp, 1, N, ctx->stream));
+      a.u = ctx->table_tmp;
+    }
+    return run_pass(ctx, a, src, flags, S, scalars);
+  }
+  if ((src == kSrcEstep && a.gibbs) || src == kSrcLabels) {
+    const bool want = a.do_stats != 0;
+    if (src == kSrcEstep) {
+      if (flags & MIMO_F_ASYNC) return fail(ctx, MIMO_E_UNSUPPORTED, "asynchronous label pass on data with NaN rows");
+      a.do_stats = 0;
+      if ((rc = run_pass(ctx, a, kSrcEstep, flags & ~(MIMO_F_DEVICE_OUT), nullptr, nullptr))) return rc;
+      ctx->rowwave_call = false;
+    }
+    if ((rc = ensure_dev(ctx, &ctx->labels_tmp, &ctx->labels_tmp_cap, (size_t)N))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d + 1, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_mask_labels(a.labels, ctx->row_mask, ctx->labels_tmp, N, a.K, ctx->cnt_d + 1, ctx->stream));
+    ctx->bad_counts_K = a.K;
+    if (!want) return MIMO_OK;
+    KernelArgs b = a;
+    b.labels = ctx->labels_tmp; b.gibbs = 0; b.do_stats = 1; b.u = nullptr; b.logp = nullptr; b.lse = nullptr; b.resp = nullptr;
+    return run_pass(ctx, b, kSrcLabels, flags, S, scalars);
+  }
+  // kSrcWeights: statistics of a (K, N) table
+  const size_t kn = (size_t)a.K * (size_t)N;
+  if ((rc = ensure_dev(ctx, &ctx->table_tmp, &ctx->table_tmp_cap, kn))) return rc;
+  HIP_TRY(ctx, launch_mask_table(a.resp, ctx->row_mask, ctx->table_tmp, a.K, N, ctx->stream));
+  a.resp = ctx->table_tmp;
+  return run_pass(ctx, a, src, flags, S, scalars);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -582,7 +662,8 @@ int mimo_destroy(mimo_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   drain_profile(ctx);
-  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
+  if (ctx->comm) { (void)mimo_comm::destroy(ctx->comm); ctx->comm = nullptr; }
+  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->row_mask, ctx->cnt_d, ctx->labels_tmp, ctx->table_tmp, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
                   ctx->logp, ctx->lse, ctx->labels, ctx->u_d, ctx->win, ctx->lin};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (ctx->theta_h) (void)hipHostFree(ctx->theta_h);
@@ -613,6 +694,33 @@ static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
   return prepare_features(ctx, Dz);
 }
 
+// Find the rows that hold a NaN.  `owned`: Z is the library's copy — such rows are zeroed in place and the mask written;
+// otherwise (borrowed device buffer) they are only counted, and if there are any the data is copied first.
+static int scan_nan_rows(mimo_ctx* ctx) {
+  ctx->n_bad = 0; ctx->bad_counts_K = 0;
+  if (ctx->N <= 0) return MIMO_OK;
+  int rc;
+  if (!ctx->cnt_d) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->cnt_d), 257 * sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, launch_nan_scan(const_cast<double*>(ctx->Z), ctx->N, ctx->D, nullptr, ctx->cnt_d, false, ctx->stream));
+  unsigned long long nb = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&nb, ctx->cnt_d, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (nb == 0) return MIMO_OK;
+  if (ctx->Z != ctx->Z_owned) {        // borrowed buffer: never written — work on a copy
+    const size_t bytes = (size_t)ctx->N * ctx->D * sizeof(double);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->Z_owned), bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->Z_owned, ctx->Z, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->Z = ctx->Z_owned;
+  }
+  if ((rc = ensure_dev(ctx, &ctx->row_mask, &ctx->mask_cap, (size_t)ctx->N))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, launch_nan_scan(ctx->Z_owned, ctx->N, ctx->D, ctx->row_mask, ctx->cnt_d, true, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_bad = (int64_t)nb;
+  return MIMO_OK;
+}
+
 int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
   return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
@@ -624,7 +732,7 @@ int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->Z_owned), bytes));
   if (N > 0) HIP_TRY(ctx, hipMemcpy(ctx->Z_owned, Z_host, (size_t)N * Dz * sizeof(double), hipMemcpyHostToDevice));
   ctx->Z = ctx->Z_owned;
-  return MIMO_OK;
+  return scan_nan_rows(ctx);
   });
 }
 
@@ -636,7 +744,7 @@ int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
   ctx->Z = Z_dev;
-  return MIMO_OK;
+  return scan_nan_rows(ctx);
   });
 }
 
@@ -1006,6 +1114,65 @@ int mimo_get_labels(mimo_ctx* ctx, int32_t* out) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
   return copy_out(ctx, out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), ctx->labels_valid, "mimo_get_labels");
+  });
+}
+
+int mimo_nan_info(mimo_ctx* ctx, int64_t* n_bad, double* row_mask_out, int K, int64_t* label_counts) {
+  return guarded(ctx, [&]() -> int {
+    int rc = bind(ctx); if (rc) return rc;
+    if (n_bad) *n_bad = ctx->n_bad;
+    if (row_mask_out && ctx->N > 0) {
+      if (ctx->n_bad > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(row_mask_out, ctx->row_mask, (size_t)ctx->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        for (int64_t i = 0; i < ctx->N; ++i) row_mask_out[i] = 1.0;
+      }
+    }
+    if (label_counts) {
+      if (K < 1 || K > 256) return fail(ctx, MIMO_E_INVALID, "mimo_nan_info: K = %d outside [1, 256]", K);
+      for (int k = 0; k < K; ++k) label_counts[k] = 0;
+      if (ctx->n_bad > 0) {
+        if (ctx->bad_counts_K != K) return fail(ctx, MIMO_E_STATE, "mimo_nan_info: no label pass with K = %d has run on this data", K);
+        unsigned long long h[256];
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->cnt_d + 1, (size_t)K * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < K; ++k) label_counts[k] = (int64_t)h[k];
+      }
+    }
+    return MIMO_OK;
+  });
+}
+
+int mimo_comm_unique_id(char* id128) {
+  return guarded(nullptr, [&]() -> int {
+    if (!id128) return fail(nullptr, MIMO_E_INVALID, "mimo_comm_unique_id: id is NULL");
+    char msg[256];
+    const int rc = mimo_comm::unique_id(id128, msg, sizeof msg);
+    return rc ? fail(nullptr, rc, "%s", msg) : MIMO_OK;
+  });
+}
+
+int mimo_comm_init(mimo_ctx* ctx, const char* id128, int rank, int world) {
+  return guarded(ctx, [&]() -> int {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, MIMO_E_INVALID, "mimo_comm_init: bad arguments");
+    if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
+    if (ctx->comm) { (void)mimo_comm::destroy(ctx->comm); ctx->comm = nullptr; }
+    char msg[256];
+    void* c = nullptr;
+    if ((rc = mimo_comm::init(&c, id128, rank, world, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
+    ctx->comm = c; ctx->comm_world = world;
+    return MIMO_OK;
+  });
+}
+
+int mimo_comm_destroy(mimo_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
+    int rc = bind(ctx); if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm) { (void)mimo_comm::destroy(ctx->comm); ctx->comm = nullptr; ctx->comm_world = 1; }
+    return MIMO_OK;
   });
 }
 

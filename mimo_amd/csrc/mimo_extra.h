@@ -12,4 +12,10 @@ hipError_t launch_sample_table(const double* logp, int K, int64_t N, const doubl
 // random column-normalised (K, N) table from the Philox stream (mimo_small.hip)
 hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int64_t row0, hipStream_t stream);
 
+// rows with missing values (mimo_small.hip): scan (+ zero the rows and write the mask when `write`), masked labels / tables
+hipError_t launch_nan_scan(double* Z, int64_t N, int D, double* mask, unsigned long long* count, bool write, hipStream_t stream);
+hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t* out, int64_t N, int K,
+                              unsigned long long* bad_counts, hipStream_t stream);
+hipError_t launch_mask_table(const double* table, const double* mask, double* out, int K, int64_t N, hipStream_t stream);
+
 }  // namespace mimo

@@ -36,18 +36,36 @@ namespace mimo {
 // ------------------------------------------------------------------------------------------
 constexpr int kRowWaveWG = 512;     // 8 wavefronts: two per SIMD (the accumulators need 8 KB VGPRs per lane)
 
-template <int KB>
+// exp(x), x <= 0, with a 2048-entry table of 2^(i/2048) (16 KB of LDS, which this kernel has to spare): the reduced
+// argument is <= ln2/4096, a cubic is enough (r^4/24 < 4e-17) — 13 instructions instead of the 15 of exp_nonpos, and
+// this kernel issues 64 of them per lane and step.  Same argument clamp, same single-constant reduction (relative
+// error 1.1e-16 |x|, an absolute error below 4e-17 for every x <= 0).
+constexpr int kExpTab = 2048;
+__device__ __forceinline__ double exp_nonpos_t2048(double x, const double* __restrict__ tab) {
+  x = fmax(x, -707.0);
+  const double t = fma(x, 2954.639443740597, 6755399441055744.0);          // 2048 / ln2, 1.5 * 2^52
+  const int n = __double2loint(t);
+  const double nf = t - 6755399441055744.0;
+  const double r = fma(nf, -3.3845077175778103e-04, x);                    // ln2 / 2048
+  double q = fma(r, 1.0 / 6.0, 0.5);
+  q = fma(r, q, 1.0);
+  const double e = tab[n & (kExpTab - 1)] * fma(r, q, 1.0);
+  int nh;
+  asm("v_ashrrev_i32 %0, 11, %1" : "=v"(nh) : "v"(n));
+  return __hiloint2double(__double2hiint(e) + (nh << 20), __double2loint(e));
+}
+
+template <int KB, int NS4>
 __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const KernelArgs a) {
   constexpr int V = 4 * KB;          // components per lane
   constexpr int NCH = KB / 2;        // chunks of 8 components (two row blocks) for the cumulative sums
   static_assert(KB % 2 == 0 && KB >= 2 && KB <= 16, "row blocks per wave");
   extern __shared__ __align__(16) unsigned char smem[];
-  const int NS = a.F16 / 4;                          // contraction steps
+  constexpr int NS = 4 * NS4;                        // contraction steps (F16 / 4): compile-time, the step loop is straight-line
   const int ZS = a.ZS;
   double* Th = reinterpret_cast<double*>(smem);      // [(NS KB + 4)][64]   (+4: the operand prefetch runs past the end)
-  double* etab = Th + (size_t)(NS * KB + 4) * 64;    // [64]
-  uint32_t* ftab = reinterpret_cast<uint32_t*>(etab + 64);                 // [4 NS] byte offsets (a | b << 16) into a z~ row
-  double* Zall = reinterpret_cast<double*>(ftab + 4 * NS + (NS & 1 ? 2 : 0));   // [8 waves][16][ZS]
+  double* etab = Th + (size_t)(NS * KB + 4) * 64;    // [kExpTab]
+  double* Zall = etab + kExpTab;                     // [8 waves][16][ZS]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,8 +76,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
 
   for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
   for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
-  if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
-  for (int f = tid; f < 4 * NS; f += kRowWaveWG) ftab[f] = 8u * a.feat[2 * f] | (8u * a.feat[2 * f + 1]) << 16;
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
   wg_sync();
 
   // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < 3 (16 D <= 144)
@@ -83,8 +100,19 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   if (wv < nsteps) load_z(wv);
 
   const double* zrow = Zw + j * ZS;
-  const uint32_t* ft = ftab + q;
   const double* thl = Th + lane;
+  // B operand of step s, lane (q, j): feature 4 s + q of row j = z~[a] z~[b]; the two LDS addresses are fixed for the
+  // whole kernel (2 NS registers), so a step costs two LDS reads and one product
+  const double* fpa[NS];
+  const double* fpb[NS];
+#pragma unroll
+  for (int s2 = 0; s2 < NS; ++s2) {
+    fpa[s2] = zrow + a.feat[2 * (4 * s2 + q)];
+    fpb[s2] = zrow + a.feat[2 * (4 * s2 + q) + 1];
+  }
+  // Philox uniforms four steps at a time: lane (q, j) draws the uniform of row j of this wave's step t + q nwaves
+  double ubatch = 0.0;
+  int uphase = 0;
 
   for (int64_t t = wv; t < nsteps; t += nwaves) {
     const int64_t n = t * 16 + j;
@@ -104,32 +132,22 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     d4 acc[KB];
 #pragma unroll
     for (int rb = 0; rb < KB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
-    auto feature = [&](int s) {
-      const uint32_t w = ft[4 * s];
-      const double za = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(zrow) + (w & 0xffffu));
-      const double zb = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(zrow) + (w >> 16));
-      return za * zb;
-    };
     constexpr int PF = 4;              // Theta slices in flight; slice e = s KB + rb sits in slot e % PF
     double ring[PF];
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = thl[e * 64];
-    double bq = feature(0);
-    const double* thp = thl;
-    for (int s = 0; s < NS; s += 2) {            // NS = F16 / 4 is a multiple of 4; two steps per iteration keep the
-#pragma unroll                                   // ring slots static for KB = 6, 10, 14 as well (2 KB % 4 == 0)
-      for (int par = 0; par < 2; ++par) {
-        const double bcur = bq;
-        if (s + par + 1 < NS) bq = feature(s + par + 1);
+    double bq = *fpa[0] * *fpb[0];
 #pragma unroll
-        for (int rb = 0; rb < KB; ++rb) {
-          const int slot = (par * KB + rb) % PF;
-          const double av = ring[slot];
-          ring[slot] = thp[(par * KB + rb + PF) * 64];     // (the last step reads the 4 zero slices behind the image)
-          acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
-        }
+    for (int s2 = 0; s2 < NS; ++s2) {            // NS is a multiple of 4: slot (s2 KB + rb) % PF is static
+      const double bcur = bq;
+      if (s2 + 1 < NS) bq = *fpa[s2 + 1] * *fpb[s2 + 1];
+#pragma unroll
+      for (int rb = 0; rb < KB; ++rb) {
+        const int e = s2 * KB + rb;
+        const double av = ring[e % PF];
+        ring[e % PF] = thl[(e + PF) * 64];       // (the last step reads the 4 zero slices behind the image)
+        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
       }
-      thp += 2 * KB * 64;
     }
 
     // ---- draw: lane (q, j) holds components q V .. q V + V - 1 of row j, x[4 rb + r] = acc[rb][r] ----------
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     for (int c = 0; c < NCH; ++c) {
       double x[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos(acc[2 * c + (i >> 2)][i & 3] - m, etab);
+      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048(acc[2 * c + (i >> 2)][i & 3] - m, etab);
 #pragma unroll
       for (int i = 1; i < 8; ++i) x[i] += x[i - 1];
 #pragma unroll
@@ -171,7 +189,15 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     double excl = __shfl_up(incl, 16);
     if (q == 0) excl = 0.0;
     const double ctot = __shfl(incl, 48 + j);
-    const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+    double uu;
+    if (a.u) {
+      uu = valid ? a.u[n] : 0.0;
+    } else {
+      if (uphase == 0)        // (wave-uniform) the same counters as one draw per step: the labels are the same labels
+        ubatch = philox_uniform(a.seed, (uint64_t)(a.row0 + (t + (int64_t)q * nwaves) * 16 + j), a.sweep);
+      uu = __shfl(ubatch, uphase * 16 + j);
+      uphase = (uphase + 1) & 3;
+    }
     const double tl = uu * ctot - excl;
     int cnt = 0;
 #pragma unroll
@@ -189,8 +215,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
 }
 
 size_t rowwave_lds_bytes(int KB, int NS, int ZS) {
-  return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + 64) + sizeof(uint32_t) * (size_t)(4 * NS + (NS & 1 ? 2 : 0)) +
-         sizeof(double) * (size_t)(kRowWaveWG / 64) * 16 * ZS;
+  return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + kExpTab + (size_t)(kRowWaveWG / 64) * 16 * ZS);
 }
 
 int rowwave_kb(int K) {           // row blocks the kernel is instantiated for: 6, 8, .., 16
@@ -206,14 +231,24 @@ bool rowwave_covers(int K, int F16, int ZS) {
 }
 
 typedef void (*rowwave_fn)(const KernelArgs);
-static rowwave_fn pick_rowwave(int kb) {
+template <int NS4>
+static rowwave_fn pick_rowwave_kb(int kb) {
   switch (kb) {
-    case 6: return gibbs_rowwave_kernel<6>;
-    case 8: return gibbs_rowwave_kernel<8>;
-    case 10: return gibbs_rowwave_kernel<10>;
-    case 12: return gibbs_rowwave_kernel<12>;
-    case 14: return gibbs_rowwave_kernel<14>;
-    case 16: return gibbs_rowwave_kernel<16>;
+    case 6: return gibbs_rowwave_kernel<6, NS4>;
+    case 8: return gibbs_rowwave_kernel<8, NS4>;
+    case 10: return gibbs_rowwave_kernel<10, NS4>;
+    case 12: return gibbs_rowwave_kernel<12, NS4>;
+    case 14: return gibbs_rowwave_kernel<14, NS4>;
+    case 16: return gibbs_rowwave_kernel<16, NS4>;
+  }
+  return nullptr;
+}
+static rowwave_fn pick_rowwave(int kb, int F16) {
+  switch (F16 / 16) {
+    case 1: return pick_rowwave_kb<1>(kb);
+    case 2: return pick_rowwave_kb<2>(kb);
+    case 3: return pick_rowwave_kb<3>(kb);
+    case 4: return pick_rowwave_kb<4>(kb);
   }
   return nullptr;
 }
@@ -227,7 +262,7 @@ int rowwave_grid(const KernelArgs& a, int num_cu) {
 
 hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream) {
   const int kb = rowwave_kb(a.K);
-  rowwave_fn fn = pick_rowwave(kb);
+  rowwave_fn fn = pick_rowwave(kb, a.F16);
   if (!fn) return hipErrorInvalidValue;
   const size_t lds = rowwave_lds_bytes(kb, a.F16 / 4, a.ZS);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

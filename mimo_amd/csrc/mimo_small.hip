@@ -411,6 +411,68 @@ hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int
 }
 
 // ------------------------------------------------------------------------------------------
+// Rows with missing values.  The reference drops rows that hold a NaN from every statistic
+// (mimo/distributions/gaussian.py:493-494: idx = ~isnan(data).any(axis=1)) and gives them the normaliser-only
+// log-density (gaussian.py:512-520: nan_to_num, then the data-dependent part of the row is set to 0) — which is the
+// canonical form at z = 0.  nan_scan zeroes such rows in the library's OWN copy of the data and writes the row mask
+// (1 = complete row) that the passes then use as per-row weights of the statistics; the helpers below apply the mask to
+// label vectors and weight tables.  NaN is tested on the bit pattern (this file is built with -fno-honor-nans).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_nan_bits(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;
+  return b > 0x7ff0000000000000ull;
+}
+
+__global__ __launch_bounds__(kWG) void nan_scan_kernel(double* __restrict__ Z, int64_t N, int D, double* __restrict__ mask,
+                                                       unsigned long long* __restrict__ count, int write) {
+  const int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (n >= N) return;
+  bool bad = false;
+  for (int d = 0; d < D; ++d) bad = bad || is_nan_bits(Z[n * D + d]);
+  if (bad) {
+    atomicAdd(count, 1ull);
+    if (write) for (int d = 0; d < D; ++d) Z[n * D + d] = 0.0;
+  }
+  if (write) mask[n] = bad ? 0.0 : 1.0;
+}
+
+__global__ __launch_bounds__(kWG) void mask_labels_kernel(const int32_t* __restrict__ labels, const double* __restrict__ mask,
+                                                          int32_t* __restrict__ out, int64_t N, int K,
+                                                          unsigned long long* __restrict__ bad_counts) {
+  const int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (n >= N) return;
+  const int32_t l = labels[n];
+  const bool keep = mask[n] != 0.0;
+  out[n] = keep ? l : -1;
+  if (!keep && bad_counts && l >= 0 && l < K) atomicAdd(&bad_counts[l], 1ull);     // integer: order-free
+}
+
+__global__ __launch_bounds__(kWG) void mask_table_kernel(const double* __restrict__ table, const double* __restrict__ mask,
+                                                         double* __restrict__ out, int K, int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (n >= N) return;
+  const double m = mask[n];
+  for (int k = 0; k < K; ++k) out[(int64_t)k * N + n] = table[(int64_t)k * N + n] * m;
+}
+
+hipError_t launch_nan_scan(double* Z, int64_t N, int D, double* mask, unsigned long long* count, bool write, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(nan_scan_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, Z, N, D, mask, count, write ? 1 : 0);
+  return hipGetLastError();
+}
+hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t* out, int64_t N, int K,
+                              unsigned long long* bad_counts, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mask_labels_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, labels, mask, out, N, K, bad_counts);
+  return hipGetLastError();
+}
+hipError_t launch_mask_table(const double* table, const double* mask, double* out, int K, int64_t N, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mask_table_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, table, mask, out, K, N);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 // components per lane / lanes per row for (Dz, K): KL = 4 up to Dz = 3, 2 at Dz = 4 (Theta rows + accumulators of a

@@ -15,7 +15,8 @@ import scipy.linalg as sla
 from scipy.special import gammaln, digamma
 
 from mimo_amd.utils.abstraction import Statistics as Stats
-from mimo_amd.distributions.wishart import (wishart_log_partition, wishart_expected_logdet, wishart_rvs,
+from mimo_amd.distributions.wishart import (bartlett_variates_in_reference_order, wishart_from_bartlett,
+                                            wishart_log_partition, wishart_expected_logdet, wishart_rvs,
                                             wishart_rvs_batched, sum_log_diag_chol)
 
 
@@ -152,13 +153,14 @@ class StackedNormalWisharts:
             L = np.linalg.cholesky(self.kappas[:, None, None] * lmbdas)
             eps = rng.standard_normal((self.size, self.dim, 1))
             return self.mus + np.linalg.solve(np.swapaxes(L, 1, 2), eps)[..., 0], lmbdas
-        mus, lmbdas = [], []
-        for k in range(self.size):
-            lmbda = wishart_rvs(self.psis[k], self.nus[k])
-            chol_inv = sla.inv(sla.cholesky(self.kappas[k] * lmbda, lower=False))
-            mus.append(self.mus[k] + npr.normal(size=self.dim).dot(chol_inv.T))
-            lmbdas.append(lmbda)
-        return np.stack(mus, axis=0), np.stack(lmbdas, axis=0)
+        # numpy.random in the reference's order per component; the O(K D^3) algebra after the draws is batched
+        # (it used to be K Python iterations of cholesky + inv: 2.6 ms at K = 64, D = 16 on the critical path of
+        # every mean-field iteration of the reference-shaped driver)
+        lower, diag, eps = bartlett_variates_in_reference_order(self.nus, self.dim, self.dim)
+        lmbdas = wishart_from_bartlett(self.psis, lower, diag)
+        # mu = m + eps . U^-T with kappa Lambda = U'U (upper factor), i.e. U mu_c = eps
+        U = np.swapaxes(np.linalg.cholesky(self.kappas[:, None, None] * lmbdas), 1, 2)
+        return self.mus + np.linalg.solve(U, eps[..., None])[..., 0], lmbdas
 
     def _rvs_native(self, rng):
         """mimo_host_nw_gibbs: the K Bartlett draws, the K conditional Gaussian draws and the canonical (c, b, W) of
@@ -327,15 +329,18 @@ class StackedMatrixNormalWisharts:
             X = np.linalg.solve(np.swapaxes(Ll, 1, 2), E)                       # Ll^-T E
             X = np.swapaxes(np.linalg.solve(Lk, np.swapaxes(X, 1, 2)), 1, 2)    # ... Lk^-1
             return self.Ms + X, lmbdas
-        As, lmbdas = [], []
+        # numpy.random in the reference's order per component, algebra batched.  The reference factorises the
+        # (dy dx) x (dy dx) matrix kron(K, Lambda) per component; its upper Cholesky factor is kron(Uk, Ul) with
+        # K = Uk'Uk, Lambda = Ul'Ul, so  vec_F(aux) = kron(Uk, Ul)^-1 z  is  aux = Ul^-1 Z Uk^-T  with z = vec_F(Z).
         dy, dx = self.row_dim, self.column_dim
-        for k in range(self.size):
-            lmbda = wishart_rvs(self.psis[k], self.nus[k])
-            chol_inv = sla.inv(sla.cholesky(np.kron(self.Ks[k], lmbda), lower=False))
-            aux = npr.normal(size=dy * dx).dot(chol_inv.T)
-            As.append(self.Ms[k] + np.reshape(aux, (dy, dx), order='F'))
-            lmbdas.append(lmbda)
-        return np.stack(As, axis=0), np.stack(lmbdas, axis=0)
+        lower, diag, eps = bartlett_variates_in_reference_order(self.nus, dy, dy * dx)
+        lmbdas = wishart_from_bartlett(self.psis, lower, diag)
+        Z = np.swapaxes(eps.reshape(self.size, dx, dy), 1, 2)                 # order='F' reshape to (dy, dx)
+        Ul = np.swapaxes(np.linalg.cholesky(lmbdas), 1, 2)
+        Uk = np.swapaxes(np.linalg.cholesky(self.Ks), 1, 2)
+        X = np.linalg.solve(Ul, Z)                                              # Ul^-1 Z
+        X = np.swapaxes(np.linalg.solve(Uk, np.swapaxes(X, 1, 2)), 1, 2)       # ... Uk^-T
+        return self.Ms + X, lmbdas
 
     @property
     def base(self):

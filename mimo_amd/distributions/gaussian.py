@@ -138,10 +138,9 @@ class StackedGaussiansWithPrecision:
         return 'diag' if self.diagonal else 'linear' if self.tied else 'full'
 
     def _bind(self, data):
+        # rows with NaN: the library drops them from the statistics and gives them the normaliser-only log-density,
+        # as the reference does (gaussian.py:493-494, 512-520; include/mimo_hip.h, mimo_nan_info)
         data = np.asarray(data, dtype=float)
-        if np.isnan(data).any():
-            raise ValueError("NaN rows are not supported by the HIP engine (reference drops them: "
-                             "gaussian.py:493-494); filter them before calling")
         return _engine.bind(self.engine, data.reshape(-1, self.dim), self.structure)
 
     def log_likelihood(self, x):

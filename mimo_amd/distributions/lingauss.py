@@ -134,8 +134,9 @@ class StackedLinearGaussiansWithPrecision:
     def _bind(self, x, y):
         x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
         y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
-        if np.isnan(x).any() or np.isnan(y).any():
-            raise ValueError("NaN rows are not supported by the HIP engine")
+        # rows with a NaN in x or y are dropped from the statistics like in the reference (lingauss.py:103-104); their
+        # log-density is the normaliser-only value (the reference does that only when x AND y hold a NaN,
+        # lingauss.py:150-151, and evaluates the other rows on nan_to_num'ed values: that corner is not reproduced)
         return _engine.bind(self.engine, joint_rows(x, y))
 
     def log_likelihood(self, x, y):

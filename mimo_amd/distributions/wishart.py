@@ -43,6 +43,33 @@ def wishart_rvs(psi, nu):
     return T @ T.T
 
 
+def bartlett_variates_in_reference_order(nus, D, extra):
+    """The variates of K Bartlett draws, each followed by `extra` standard normals, taken from numpy.random in the
+    order the reference consumes them per component (wishart.py:72-92, then the caller's normal(size=extra)):
+    normal(D(D-1)/2), chisquare(nu - i) for i < D, normal(extra).  The D chi-square draws of a component are ONE
+    vector call: the legacy generator walks a vector of degrees of freedom in order, so the stream is the stream of D
+    scalar calls (tests/test_host_native.py holds that).  Returns (lower (K, n_tril), diag (K, D), eps (K, extra))."""
+    K, n_tril = len(nus), D * (D - 1) // 2
+    lower, diag, eps = np.empty((K, n_tril)), np.empty((K, D)), np.empty((K, extra))
+    dof_off = np.arange(D)
+    for k in range(K):
+        lower[k] = npr.normal(size=n_tril)
+        diag[k] = npr.chisquare(nus[k] - dof_off)
+        eps[k] = npr.normal(size=extra)
+    return lower, np.sqrt(diag), eps
+
+
+def wishart_from_bartlett(psis, lower, diag):
+    """Lambda_k = T T', T = chol(psi_k) A_k, for a stack of Bartlett factors given by their variates."""
+    K, D = diag.shape
+    A = np.zeros((K, D, D))
+    ti = np.tril_indices(D, k=-1)
+    A[:, ti[0], ti[1]] = lower
+    A[:, np.arange(D), np.arange(D)] = diag
+    T = np.linalg.cholesky(psis) @ A
+    return T @ np.swapaxes(T, 1, 2)
+
+
 def wishart_rvs_batched(psis, nus, rng):
     """K Wishart draws in one shot (Bartlett), from a numpy Generator.  Same distribution as
     wishart_rvs but NOT the reference's numpy.random call order — used by the fast Gibbs path."""

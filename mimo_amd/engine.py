@@ -19,12 +19,19 @@ from . import _lib
 class SuffStats:
     """Packed per-component statistics  n_k, sum_n r z, sum_n r z z'  (float64)."""
 
-    __slots__ = ("n", "sx", "sxx", "sxx_total")
+    __slots__ = ("n", "sx", "sxx", "sxx_total", "n_rows")
 
-    def __init__(self, n, sx, sxx, sxx_total=None):
+    def __init__(self, n, sx, sxx, sxx_total=None, n_rows=None):
         # sxx is None under the 'linear' structure (one precision shared by all components): only
         # sxx_total = sum_k sum_n r_kn z z' (= sum_n w_n z_n z_n') exists, which is all a tied update uses
-        self.n, self.sx, self.sxx, self.sxx_total = n, sx, sxx, sxx_total
+        # n_rows: sum_n r_kn over ALL rows when the data holds rows with NaN (they are left out of n / sx / sxx, but
+        # the reference's gating update counts them: categorical.py:35-46 on the full label / responsibility table)
+        self.n, self.sx, self.sxx, self.sxx_total, self.n_rows = n, sx, sxx, sxx_total, n_rows
+
+    @property
+    def gating_counts(self):
+        """What the gating update consumes: n, plus the share of the rows with NaN when there are any."""
+        return self.n if self.n_rows is None else self.n_rows
 
     @staticmethod
     def from_packed(S, K, D):
@@ -85,6 +92,25 @@ class HipEngine:
     def global_rows(self, n_local):
         """Rows over all shards for `n_local` rows here (one GPU: itself; ShardedEngine sums over the ranks)."""
         return int(n_local)
+
+    # -- sharding through the library's own RCCL communicator (hosts without torch.distributed) ----------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte id of a new communicator (rank 0 creates it, the application hands it to the other ranks)."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.mimo_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.MimoHipError(f"mimo_comm_unique_id failed ({rc}): {lib.mimo_last_error(None).decode()}")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Attach this engine to the communicator: every later pass returns statistics summed over the ranks
+        (one RCCL all-reduce of the packed block per pass, mimo_comm_init)."""
+        self._check(self._lib.mimo_comm_init(self._ctx, bytes(unique_id), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.mimo_comm_destroy(self._ctx))
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.mimo_set_stream(self._ctx, C.c_void_p(stream_ptr or 0)))
@@ -179,6 +205,7 @@ class HipEngine:
             self._keepalive = Z
             self.N, self.D = int(Z.shape[0]), int(Z.shape[1])
             self._check(self._lib.mimo_attach(self._ctx, C.c_void_p(Z.data_ptr()), self.N, self.D))
+            self._after_upload()
             return
         Z = _f64(Z)
         if Z.ndim != 2:
@@ -186,6 +213,38 @@ class HipEngine:
         self.N, self.D = int(Z.shape[0]), int(Z.shape[1])
         self._keepalive = None
         self._check(self._lib.mimo_upload(self._ctx, _ptr(Z), self.N, self.D))
+        self._after_upload()
+
+    # -- rows with NaN (dropped from the statistics, normaliser-only log-density: mimo_nan_info) -------------
+    def _after_upload(self):
+        nb = C.c_int64()
+        self._check(self._lib.mimo_nan_info(self._ctx, C.byref(nb), None, 0, None))
+        self.n_bad, self._bad_rows = int(nb.value), None
+
+    def nan_rows(self):
+        """Indices of the resident rows that hold a NaN."""
+        if self._bad_rows is None:
+            if not getattr(self, 'n_bad', 0):
+                self._bad_rows = np.zeros(0, dtype=np.int64)
+            else:
+                m = np.empty(self.N)
+                self._check(self._lib.mimo_nan_info(self._ctx, None, _ptr(m), 0, None))
+                self._bad_rows = np.flatnonzero(m == 0.)
+        return self._bad_rows
+
+    def _nan_label_counts(self, K):
+        out = np.zeros(K, dtype=np.int64)
+        self._check(self._lib.mimo_nan_info(self._ctx, None, None, int(K), _ptr(out)))
+        return out.astype(float)
+
+    def _nan_softmax_share(self, S, c):
+        """softmax pass on data with NaN rows: each of them carries the responsibilities softmax_k(c_k)."""
+        if S is not None and getattr(self, 'n_bad', 0):
+            c = np.asarray(c, dtype=float)
+            m = np.max(c)
+            e = np.exp(c - m) if np.isfinite(m) else np.zeros_like(c)
+            S.n_rows = S.n + self.n_bad * e / max(np.sum(e), 1e-300)
+        return S
 
     # -- hot path -------------------------------------------------------------------------
     def _params(self, c, b, W):
@@ -228,13 +287,13 @@ class HipEngine:
                 self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K,
                                                  flags | _lib.F_KEEP_RESP | _lib.F_NO_STATS, None, _ptr(sc)))
                 self._K = K
-                return self.weighted_stats(self.get_resp(K) * w[None, :]), sc
+                return self._nan_softmax_share(self.weighted_stats(self.get_resp(K) * w[None, :]), c), sc
             self._check(rc)
         else:
             self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, flags,
                                              _ptr(S) if stats else None, _ptr(sc)))
         self._K = K
-        return (SuffStats.from_packed(S, K, self.D) if stats else None), sc
+        return (self._nan_softmax_share(SuffStats.from_packed(S, K, self.D), c) if stats else None), sc
 
     def estep_async(self, c, b, W):
         """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
@@ -250,6 +309,7 @@ class HipEngine:
         self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
         self._K = K
         self._async_K = K
+        self._async_c = np.array(c) if getattr(self, 'n_bad', 0) else None
 
     def estep_wait(self):
         K = self._async_K
@@ -257,6 +317,8 @@ class HipEngine:
         sc = np.empty(3)
         self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
         S = SuffStats.from_packed(S, K, self.D)
+        if getattr(self, '_async_c', None) is not None:
+            self._nan_softmax_share(S, self._async_c)
         if getattr(self, '_async_W0', None) is not None:
             return self._linear_stats(S, self._xx_total()), self._linear_scalars(sc, self._async_W0)
         return S, sc
@@ -288,6 +350,8 @@ class HipEngine:
             _ptr(labels) if return_labels else None, _ptr(S) if stats else None))
         self._K = K
         S = SuffStats.from_packed(S, K, self.D) if stats else None
+        if stats and getattr(self, 'n_bad', 0):
+            S.n_rows = S.n + self._nan_label_counts(K)
         if self._linear() and stats:      # every row carries exactly one label: the second moments add up to XX
             S = self._linear_stats(S, self._xx_total())
         return labels, S
@@ -313,6 +377,9 @@ class HipEngine:
         S = np.empty((K, 1 + self.D + self.D * self.D))
         self._check(self._lib.mimo_weighted_stats(self._ctx, p, K, 0, _ptr(S)))
         S = SuffStats.from_packed(S, K, self.D)
+        if getattr(self, 'n_bad', 0):
+            bad = self.nan_rows()
+            S.n_rows = S.n + (np.sum(resp[:, bad], axis=1) if resp is not None else np.sum(self.get_resp(K)[:, bad], axis=1))
         if self._linear():     # sum_k r_kn is the weight of row n in the pooled second moment (1 for responsibilities)
             S = self._linear_stats(S, self._xx_total() if resp is None else self._xx(np.sum(resp, axis=0)))
         return S
@@ -332,6 +399,8 @@ class HipEngine:
         S = np.empty((K, 1 + self.D + self.D * self.D))
         self._check(self._lib.mimo_label_stats(self._ctx, p, K, 0, _ptr(S)))
         S = SuffStats.from_packed(S, K, self.D)
+        if getattr(self, 'n_bad', 0):
+            S.n_rows = S.n + self._nan_label_counts(K)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
     def random_resp_stats(self, K, seed=0):
@@ -342,6 +411,8 @@ class HipEngine:
         self._check(self._lib.mimo_random_resp_stats(self._ctx, K, int(seed), 0, _ptr(S)))
         self._K = K
         S = SuffStats.from_packed(S, K, self.D)
+        if getattr(self, 'n_bad', 0):
+            S.n_rows = S.n + self._nan_label_counts(K)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
     def sample_from_log(self, logp=None, K=None, u=None, seed=0, sweep=0, return_lognorms=False):

@@ -156,7 +156,7 @@ class MixtureOfGaussians:
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
                 self.components.max_likelihood(None, stats=_component_stats(S, self.components))
-                self.gating.max_likelihood(None, S.n)
+                self.gating.max_likelihood(None, S.gating_counts)
                 S, sc = eng.estep(*self.canonical())
                 log_lik.append(sc[0])
                 pbar.update(1)
@@ -176,7 +176,7 @@ class MixtureOfGaussians:
             for _ in range(maxiter):
                 S = eng.weighted_stats(resp * weights)
                 self.components.max_likelihood(None, stats=_component_stats(S, self.components))
-                self.gating.max_likelihood(None, S.n)
+                self.gating.max_likelihood(None, S.gating_counts)
                 _, sc = eng.estep(*self.canonical(), stats=False, keep_resp=True)
                 resp = eng.get_resp(self.size)
                 log_lik.append(sc[0])
@@ -237,7 +237,7 @@ class BayesianMixtureOfGaussians:
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
                 self.components.max_aposteriori(None, stats=_component_stats(S, self.components))
-                self.gating.max_aposteriori(None, S.n)
+                self.gating.max_aposteriori(None, S.gating_counts)
                 S, sc = eng.estep(*self.likelihood.canonical())
                 log_prior = self.gating.prior.log_likelihood(self.gating.likelihood.params)\
                     + np.sum(self.components.prior.log_likelihood(self.components.likelihood.params))
@@ -286,7 +286,7 @@ class BayesianMixtureOfGaussians:
         """One sweep of `resample` (gmm.py:217-223): components and gating from the statistics `S` of the labels
         drawn last, then the label pass.  Returns (labels | None, S' | None)."""
         self.components.resample(None, stats=_component_stats(S, self.components), rng=param_rng)
-        self.gating.resample(None, counts=S.n)
+        self.gating.resample(None, counts=S.gating_counts)
         return self._draw_labels(eng, label_rng, seed, sweep, stats=stats, return_labels=return_labels)
 
     def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
@@ -390,7 +390,7 @@ class BayesianMixtureOfGaussians:
 
     def _update_from_stats(self, S, sample=True):
         self.components.meanfield_update(None, stats=_component_stats(S, self.components), sample=sample)
-        self.gating.meanfield_update(None, S.n, sample=sample)
+        self.gating.meanfield_update(None, S.gating_counts, sample=sample)
 
     def _vlb_prior_terms(self):
         return self.gating.variational_lowerbound() + np.sum(self.components.variational_lowerbound())
@@ -435,7 +435,7 @@ class BayesianMixtureOfGaussians:
                         Sb, _ = beng.estep(*self.canonical_expected())
                     self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb, self.components),
                                                   sample=sample_likelihood)
-                    self.gating.meanfield_sgd(None, Sb.n, scale, step_size, sample=sample_likelihood)
+                    self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
                 _, sc = eng.estep(*self.canonical_expected(), stats=False)
                 vlb.append(self._vlb_prior_terms() + sc[0])
                 pbar.update(1)
@@ -445,7 +445,7 @@ class BayesianMixtureOfGaussians:
         eng = self._bind(obs)
         S = eng.weighted_stats(resp)
         self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(S, self.components))
-        self.gating.meanfield_sgd(None, S.n, scale, step_size)
+        self.gating.meanfield_sgd(None, S.gating_counts, scale, step_size)
 
     # ---- ELBO with explicit responsibilities (reference-shaped) ----------------------------------
     def variational_lowerbound_obs(self, obs, resp):

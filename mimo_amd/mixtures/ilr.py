@@ -189,7 +189,7 @@ class BayesianMixtureOfLinearGaussians:
                 bstats, mstats = self._block_stats(S)
                 self.basis.resample(None, stats=bstats, rng=param_rng)
                 self.models.resample(None, None, stats=mstats, rng=param_rng)
-                self.gating.resample(None, counts=S.n)
+                self.gating.resample(None, counts=S.gating_counts)
                 last = it == maxiter - 1
                 z, S = self._draw_labels(eng, label_rng, seed, it + 1, stats=not last, return_labels=last)
                 pbar.update(1)
@@ -299,7 +299,7 @@ class BayesianMixtureOfLinearGaussians:
         bstats, mstats = self._block_stats(S)
         self.basis.meanfield_update(None, stats=bstats, sample=sample)
         self.models.meanfield_update(None, None, stats=mstats, sample=sample)
-        self.gating.meanfield_update(None, S.n, sample=sample)
+        self.gating.meanfield_update(None, S.gating_counts, sample=sample)
 
     def _vlb_prior_terms(self):
         return self.gating.variational_lowerbound() + np.sum(self.basis.variational_lowerbound())\
@@ -347,7 +347,7 @@ class BayesianMixtureOfLinearGaussians:
                     self.basis.meanfield_sgd(None, None, scale, step_size, stats=bstats, sample=sample_likelihood)
                     self.models.meanfield_sgd(None, None, None, scale, step_size, stats=mstats,
                                               sample=sample_likelihood)
-                    self.gating.meanfield_sgd(None, Sb.n, scale, step_size, sample=sample_likelihood)
+                    self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
                 _, sc = eng.estep(*self.canonical_expected(), stats=False)
                 vlb.append(self._vlb_prior_terms() + sc[0])
                 pbar.update(1)

@@ -186,17 +186,23 @@ def gauss_log_base(K, D):
 
 
 def gauss_log_likelihood(x, mus, lmbdas):
-    """gaussian.py:510-521 (no NaN rows)."""
+    """gaussian.py:510-521.  Rows that hold a NaN: nan_to_num (on a copy here; the reference edits the caller's array
+    in place), then the data-dependent part of those rows is set to 0 — they keep the normaliser-only value."""
     K, D = mus.shape
+    bads = np.isnan(np.atleast_2d(x)).any(axis=1)
+    x = np.nan_to_num(np.array(x, dtype=float)).reshape((-1, D))
     log_lik = np.einsum('kd,kdl,nl->kn', mus, lmbdas, x, optimize=True)\
         - 0.5 * np.einsum('nd,kdl,nl->kn', x, lmbdas, x, optimize=True)
+    log_lik[:, bads] = 0.
     log_lik += - np.expand_dims(gauss_log_partition(mus, lmbdas), axis=1)\
         + np.expand_dims(gauss_log_base(K, D), axis=1)
     return log_lik
 
 
 def gauss_weighted_statistics(data, weights):
-    """gaussian.py:491-502 -> (xk, nk, xxTk, nk)."""
+    """gaussian.py:491-502 -> (xk, nk, xxTk, nk); rows that hold a NaN are dropped together with their weights."""
+    idx = ~np.isnan(data).any(axis=1)
+    data, weights = data[idx], weights[:, idx]
     xk = np.einsum('kn,nd->kd', weights, data, optimize=True)
     xxTk = np.einsum('nd,kn,nl->kdl', data, weights, data, optimize=True)
     nk = np.sum(weights, axis=1)

@@ -717,7 +717,53 @@ def hier_ilr_case(name, N, dx, dy, K, seed, iters=4, sub=3):
     print(name, "ok")
 
 
+def nan_rows_case(name, N, D, K, seed, n_bad=9):
+    """Method-level behaviour of the reference on rows that hold a NaN (fresh copies per call: the reference edits
+    the caller's array in place, gaussian.py:513): log-density tables, responsibilities, statistics, counts."""
+    npr.seed(seed)
+    X = make_data(N, D)
+    bad = np.sort(npr.choice(N, size=n_bad, replace=False))
+    Xn = X.copy()
+    for i, r in enumerate(bad):
+        Xn[r, i % D] = np.nan
+        if i % 3 == 0:
+            Xn[r, :] = np.nan
+    gating = make_gating(K, 'dirichlet')
+    prior = StackedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones((K,)),
+                                  psis=np.stack(K * [np.eye(D)]), nus=(D + 1.) * np.ones((K,)) + 1e-8)
+    comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior)
+    model = BayesianMixtureOfGaussians(gating=gating, components=comps)
+    resp0 = npr.rand(K, N)
+    resp0 /= np.sum(resp0, axis=0)
+    model.meanfield_update_parameters(X.copy(), resp0)            # a sensible point estimate (from the complete data)
+    out = dict(X=Xn, bad=bad, K=np.array(K), D=np.array(D), resp0=resp0,
+               lik_mus=model.components.likelihood.mus, lik_lmbdas=model.components.likelihood.lmbdas,
+               lik_probs=model.gating.likelihood.probs)
+    out["A1_loglik"] = model.components.likelihood.log_likelihood(Xn.copy())
+    out["A2_lcl"] = model.likelihood.log_complete_likelihood(Xn.copy())
+    out["A2_resp"] = model.likelihood.responsibilities(Xn.copy())
+    out["A2_ll"] = model.likelihood.log_likelihood(Xn.copy())
+    st = model.components.likelihood.weighted_statistics(Xn.copy(), out["A2_resp"])
+    put(out, "stats", dict(xk=st[0], nk=st[1], xxTk=st[2]))
+    out["counts"] = model.gating.likelihood.weighted_statistics(None, out["A2_resp"])
+    st0 = model.components.likelihood.weighted_statistics(Xn.copy(), resp0)
+    put(out, "stats0", dict(xk=st0[0], nk=st0[1], xxTk=st0[2]))
+    u = npr.random(size=(1, N))
+    with FixedUniforms(u):
+        _, labels = model.resample_labels(Xn.copy())
+    out["u"], out["labels"] = u, labels
+    ls = model.components.likelihood.weighted_statistics(Xn.copy(), one_hot(labels, K))
+    put(out, "lstats", dict(xk=ls[0], nk=ls[1], xxTk=ls[2]))
+    out["lcounts"] = model.gating.likelihood.statistics(labels)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "nan":
+        nan_rows_case("nan_rows_gmm_d3_k5", N=400, D=3, K=5, seed=1361)
+        nan_rows_case("nan_rows_gmm_d16_k70", N=300, D=16, K=70, seed=1362, n_bad=20)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hilr":
         hier_ilr_case("hier_ilr_dx1_dy1_k3", N=300, dx=1, dy=1, K=3, seed=1356)
         hier_ilr_case("hier_ilr_dx2_dy2_k4", N=400, dx=2, dy=2, K=4, seed=1357)

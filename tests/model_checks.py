@@ -626,3 +626,45 @@ def check_prediction(ilr, g, tol):
         pass
     else:
         raise AssertionError("studentt must be rejected")
+
+
+def check_nan_rows(name, engine, tol=1e-9):
+    """Rows that hold a NaN, through the reference-shaped methods, against the reference's outputs: normaliser-only
+    log-density (tables, responsibilities, labels carry the row), no contribution to the component statistics, full
+    contribution to the gating counts (S.gating_counts)."""
+    from mimo_amd.distributions import (Dirichlet, CategoricalWithDirichlet, StackedNormalWisharts,
+                                        StackedGaussiansWithNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfGaussians
+    g = load_golden(name)
+    X, K, D = g["X"], int(g["K"]), int(g["D"])
+    gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones(K)))
+    prior = StackedNormalWisharts(size=K, dim=D, mus=np.zeros((K, D)), kappas=1e-2 * np.ones(K),
+                                  psis=np.stack(K * [np.eye(D)]), nus=(D + 1.) * np.ones(K) + 1e-8)
+    comps = StackedGaussiansWithNormalWisharts(size=K, dim=D, prior=prior, engine=engine)
+    model = BayesianMixtureOfGaussians(gating=gating, components=comps, engine=engine)
+    model.components.likelihood.params = (g["lik_mus"], g["lik_lmbdas"])
+    model.gating.likelihood.params = g["lik_probs"].copy()
+    lik = model.components.likelihood
+    assert rel_err(lik.log_likelihood(X.copy()), g["A1_loglik"]) < tol
+    assert rel_err(model.likelihood.log_complete_likelihood(X.copy()), g["A2_lcl"]) < tol
+    assert rel_err(model.likelihood.responsibilities(X.copy()), g["A2_resp"]) < tol
+    assert rel_err(model.likelihood.log_likelihood(X.copy()), g["A2_ll"]) < tol
+    for resp, pre in ((g["A2_resp"], "stats"), (g["resp0"], "stats0")):
+        st = lik.weighted_statistics(X.copy(), resp)
+        assert rel_err(st[0], g[pre + "_xk"]) < tol and rel_err(st[1], g[pre + "_nk"]) < tol and rel_err(st[2], g[pre + "_xxTk"]) < tol
+    # the fused passes: statistics of the E-step's own responsibilities / labels, gating counts over all rows
+    eng = model.likelihood._bind(X.copy())
+    assert eng.n_bad == len(g["bad"]) and np.array_equal(eng.nan_rows(), g["bad"])
+    S, sc = eng.estep(*model.likelihood.canonical())
+    assert rel_err(S.sx, g["stats_xk"]) < tol and rel_err(S.n, g["stats_nk"]) < tol and rel_err(S.sxx, g["stats_xxTk"]) < tol
+    assert rel_err(S.gating_counts, g["counts"]) < tol and abs(sc[0] - g["A2_ll"].sum()) < tol * abs(g["A2_ll"].sum())
+    labels, Sl = eng.gibbs_labels(*model.likelihood.canonical(), u=g["u"])
+    assert np.array_equal(labels, g["labels"])
+    assert rel_err(Sl.sx, g["lstats_xk"]) < tol and np.array_equal(Sl.n, g["lstats_nk"]) and rel_err(Sl.sxx, g["lstats_xxTk"]) < tol
+    assert np.array_equal(Sl.gating_counts, g["lcounts"])
+    Sl2 = eng.label_stats(g["labels"], K)
+    assert np.array_equal(Sl2.n, g["lstats_nk"]) and rel_err(Sl2.sxx, g["lstats_xxTk"]) < tol and np.array_equal(Sl2.gating_counts, g["lcounts"])
+    # a driver runs end to end on such data (the reference's own drivers do not: its mean-field table drops the rows,
+    # bayesian.py:296 with gaussian.py:468-469, and the statistics call then fails on the shapes)
+    vlb = model.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=5, tol=0., progress_bar=False)
+    assert np.all(np.isfinite(vlb)) and np.all(np.diff(vlb) > -1e-8 * abs(vlb[-1]))

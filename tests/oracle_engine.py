@@ -30,6 +30,16 @@ class OracleEngine:
     def upload(self, Z):
         self.Z = np.ascontiguousarray(Z, dtype=float)
         self.N, self.D = self.Z.shape
+        bad = np.isnan(self.Z).any(axis=1)          # rows with NaN: zeroed here, dropped from every statistic (mimo_nan_info)
+        self._bad = np.flatnonzero(bad)
+        self.n_bad = len(self._bad)
+        if self.n_bad:
+            self.Z = self.Z.copy()
+            self.Z[bad] = 0.
+        self._mask = (~bad).astype(float)
+
+    def nan_rows(self):
+        return self._bad
 
     def set_row_offset(self, row0):
         self.row0 = int(row0)
@@ -50,8 +60,12 @@ class OracleEngine:
         return self.Z.T @ self.Z
 
     def _stats(self, R, pooled=False):
-        n, sx, sxx = O.packed_stats(self.Z, R)
-        return SuffStats(n, sx, None, np.sum(sxx, axis=0)) if pooled else SuffStats(n, sx, sxx)
+        R = np.asarray(R, float)
+        n, sx, sxx = O.packed_stats(self.Z, R * self._mask if self.n_bad else R)
+        S = SuffStats(n, sx, None, np.sum(sxx, axis=0)) if pooled else SuffStats(n, sx, sxx)
+        if self.n_bad:
+            S.n_rows = n + np.sum(R[:, self._bad], axis=1)
+        return S
 
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):

@@ -735,3 +735,45 @@ def test_lazy_log_prob_table(engine):
     assert np.array_equal(labels, labels_eager)
     assert np.array_equal(np.asarray(lp), lp_eager) and lp.evaluated and np.array_equal(lp[1], lp_eager[1])
     assert rel_err(lp_eager, model.likelihood.log_complete_likelihood(X)) < 1e-14
+
+
+def test_native_rccl_communicator_one_rank(engine):
+    """mimo_comm_init: the library's own RCCL communicator (no torch.distributed).  One rank is all a one-GPU box can
+    run: the collective is issued on the context's stream behind the kernels, so every entry point must return the very
+    numbers it returns without it — synchronous, asynchronous, device-out, Gibbs and the small-shape kernel."""
+    from mimo_amd.engine import HipEngine
+    rng = np.random.default_rng(5)
+    eng = HipEngine(0)
+    try:
+        for (N, D, K) in ((30011, 16, 64), (20000, 2, 4), (9000, 8, 200)):
+            Z, c, b, W = _random_problem(rng, N, D, K)
+            eng.upload(Z)
+            S0, sc0 = eng.estep(c, b, W)
+            lab0, G0 = eng.gibbs_labels(c, b, W, seed=3, sweep=1)
+            eng.comm_init(HipEngine.comm_unique_id(), 0, 1)
+            S1, sc1 = eng.estep(c, b, W)
+            assert np.array_equal(S1.sxx, S0.sxx) and np.array_equal(S1.n, S0.n) and np.array_equal(sc1[:1], sc0[:1])
+            eng.estep_async(c, b, W)
+            S2, sc2 = eng.estep_wait()
+            assert np.array_equal(S2.sxx, S0.sxx) and sc2[0] == sc0[0]
+            lab1, G1 = eng.gibbs_labels(c, b, W, seed=3, sweep=1)
+            assert np.array_equal(lab1, lab0) and np.array_equal(G1.sxx, G0.sxx)
+            _, sc3 = eng.estep(c, b, W, stats=False)
+            assert sc3[0] == sc0[0]
+            eng.comm_destroy()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["nan_rows_gmm_d3_k5", "nan_rows_gmm_d16_k70"])
+def test_rows_with_nan(engine, name):
+    """NaN rows on the HIP path (small-shape kernel at D = 3, K = 5; tile kernels + row-owner label kernels at
+    D = 16 / K = 70) against the reference's outputs; a borrowed device buffer is not modified."""
+    mc.check_nan_rows(name, engine)
+    import torch
+    g = load_golden(name)
+    t = torch.tensor(g["X"], device="cuda:0")
+    engine.upload(t)
+    assert engine.n_bad == len(g["bad"]) and torch.isnan(t).any()
+    engine.upload(np.nan_to_num(g["X"]))
+    assert engine.n_bad == 0

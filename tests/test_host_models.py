@@ -146,3 +146,8 @@ def test_sample_discrete_from_log_and_random_start_on_the_double():
     assert np.all(np.diff(vlb) > -1e-8 * abs(vlb[-1]))
     with pytest.raises(ValueError):
         model.meanfield_coordinate_descent(g["X"], randomize=True, maxiter=1, progress_bar=False, init_rng='nope')
+
+
+@pytest.mark.parametrize("name", ["nan_rows_gmm_d3_k5", "nan_rows_gmm_d16_k70"])
+def test_rows_with_nan(name):
+    mc.check_nan_rows(name, OracleEngine())

@@ -232,3 +232,42 @@ def test_a_helper_thread_that_cannot_start_does_not_lose_work():
             assert np.array_equal(a, b)
     finally:
         composite.NATIVE_HOST = old
+
+
+def test_batched_rvs_consumes_numpy_random_like_the_component_loop():
+    """The reference-order posterior draws (likelihood.params = posterior.rvs() of every mean-field iteration) batch
+    their O(K D^3) algebra but take the variates from numpy.random in the reference's per-component order: same stream
+    position afterwards and the same draws as the per-component formulas of the reference (wishart.py:72-92,
+    composite.py:82-86, 607-611 — Cholesky of kron(K, Lambda) included)."""
+    import numpy.random as npr
+    import scipy.linalg as sla
+    from mimo_amd.distributions.wishart import wishart_rvs
+    rng = np.random.default_rng(2)
+    K, D = 7, 5
+    A = rng.standard_normal((K, D, D))
+    nw = StackedNormalWisharts(K, D, rng.standard_normal((K, D)), rng.uniform(0.5, 3., K),
+                               A @ A.transpose(0, 2, 1) / D + np.eye(D), rng.uniform(D + 1., 40., K))
+    npr.seed(11)
+    mus, lmbdas = nw.rvs()
+    after = npr.random()
+    npr.seed(11)
+    for k in range(K):
+        lm = wishart_rvs(nw.psis[k], nw.nus[k])
+        ci = sla.inv(sla.cholesky(nw.kappas[k] * lm, lower=False))
+        mu = nw.mus[k] + npr.normal(size=D).dot(ci.T)
+        assert rel_err(lmbdas[k], lm) < 1e-12 and rel_err(mus[k], mu) < 1e-11
+    assert npr.random() == after
+    dy, dx = 3, 4
+    A = rng.standard_normal((K, dx, dx)); B = rng.standard_normal((K, dy, dy))
+    mnw = StackedMatrixNormalWisharts(K, dx, dy, rng.standard_normal((K, dy, dx)), A @ A.transpose(0, 2, 1) + np.eye(dx),
+                                      B @ B.transpose(0, 2, 1) / dy + np.eye(dy), rng.uniform(dy + 1., 30., K))
+    npr.seed(12)
+    As, lmbdas = mnw.rvs()
+    after = npr.random()
+    npr.seed(12)
+    for k in range(K):
+        lm = wishart_rvs(mnw.psis[k], mnw.nus[k])
+        ci = sla.inv(sla.cholesky(np.kron(mnw.Ks[k], lm), lower=False))
+        aux = npr.normal(size=dy * dx).dot(ci.T)
+        assert rel_err(lmbdas[k], lm) < 1e-12 and rel_err(As[k], mnw.Ms[k] + np.reshape(aux, (dy, dx), order='F')) < 1e-11
+    assert npr.random() == after

@@ -250,3 +250,21 @@ def test_diagonal_restatement(name, tied):
     ell = O.diag_gauss_ng_expected_log_likelihood(X, upd)
     assert np.all(np.isfinite(ell)) and ell.shape == g["vi_ell_table"].shape
     assert np.all(np.isfinite(O.ng_vlb(upd, prior)))
+
+
+@pytest.mark.parametrize("name", ["nan_rows_gmm_d3_k5", "nan_rows_gmm_d16_k70"])
+def test_rows_with_nan_follow_the_reference(name):
+    """gaussian.py:493-494, 512-520: rows that hold a NaN keep the normaliser-only log-density and are dropped from the
+    statistics; the gating counts keep them.  The oracle's restatement against outputs of the reference."""
+    g = load_golden(name)
+    X, K = g["X"], int(g["K"])
+    L = O.gauss_log_likelihood(X, g["lik_mus"], g["lik_lmbdas"])
+    assert rel_err(L, g["A1_loglik"]) < TOL and np.isnan(X).any()
+    lcl = O.gmm_log_complete_likelihood(X, g["lik_mus"], g["lik_lmbdas"], g["lik_probs"])
+    assert rel_err(lcl, g["A2_lcl"]) < TOL and rel_err(O.responsibilities(lcl), g["A2_resp"]) < TOL
+    for resp, pre in ((g["A2_resp"], "stats"), (g["resp0"], "stats0"), (O.one_hot(g["labels"], K), "lstats")):
+        xk, nk, xxTk, _ = O.gauss_weighted_statistics(X, resp)
+        assert rel_err(xk, g[pre + "_xk"]) < TOL and rel_err(nk, g[pre + "_nk"]) < TOL and rel_err(xxTk, g[pre + "_xxTk"]) < TOL
+    assert np.array_equal(O.sample_discrete_from_log(lcl, g["u"]), g["labels"])
+    assert rel_err(O.categorical_weighted_statistics(g["A2_resp"]), g["counts"]) < TOL
+    assert np.array_equal(O.categorical_statistics(g["labels"], K), g["lcounts"])

@@ -1,22 +1,22 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/: kernel-trace stats, then PMC counters in separate passes
-# (never combined with sys/hip tracing).  Usage on the GPU box: bash tools/profile.sh <tag> [bench args]
+# (never combined with sys/hip tracing).  Usage on the GPU box: bash tools/profile.sh <tag> <config> [bench args]
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; CFG=${2:-c2}; shift; shift || true
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+OUT=$REPO/gpurun_out/prof_${TAG}_$CFG
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+ARGS="--config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-sustained $*"
 # the kernel-trace pass runs bench.py with its DEFAULT step / warm-up counts (what the driver runs), so that the
 # average duration in kernel_stats.csv is the average bench.py itself reports (only the CPU baseline leg is skipped)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --no-cpu-baseline $* > $OUT/trace_bench.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --config $CFG --no-cpu-baseline $* > $OUT/trace_bench.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.log
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_lds.log
-rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ|TCC|TCP|GRBM)_[A-Z0-9_]+" | sort -u > $OUT/counters_available.txt
 cd $REPO
-python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+python3 tools/summarize_profile.py $OUT $CFG > $OUT/summary.txt 2>&1
+tail -1 $OUT/trace_bench.json > $OUT/bench_line.json
+echo "--- $CFG"; head -8 $OUT/summary.txt; tail -2 $OUT/summary.txt
