@@ -354,6 +354,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
             "allreduce_bytes_per_step": (8 * (K * (1 + D + D * D) + 4)) if dist is not None else 0,
+            "allreduce_route": (("libmimo_hip RCCL communicator" if getattr(engine, "_native", False) else
+                                 "torch.distributed all_reduce (" + dist.get_backend() + ")") if dist is not None else None),
             "config": {"workload": desc, "rows_per_gpu": N, "Dz": D, "K": K,
                        "step": "one iteration of the public driver loop ("
                                + ("gibbs_iteration" if mode == "gibbs" else "meanfield_iteration, sample_likelihood=%s" % sample)

@@ -5,7 +5,16 @@ only exchange per sweep is ONE all-reduce(sum, float64) of the packed statistic 
 [K x (1 + Dz + Dz^2)] + 3 ELBO scalars (0.14 MB at K=64, Dz=16) — latency-bound on xGMI, issued as a
 single fused call through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in CPU tests).
 After it every rank holds the global statistics and performs the identical O(K D^3) host update, so
-no broadcast is needed.  Labels / responsibilities stay on the owning rank; the Philox counter uses
+no broadcast is needed.
+
+Two routes for that all-reduce on GPUs: torch.distributed's all_reduce on a stream this object owns (default, and
+the only one for the CPU test double over gloo); or, with MIMO_SHARDED_NATIVE=1, the library's OWN communicator
+(mimo_comm_init: RCCL opened by libmimo_hip.so — inside a PyTorch process the very copy PyTorch loaded — the
+collective is enqueued by the C library on the stream of its kernels, right behind them: no second stream, no
+cross-stream events, no Python in the path; the unique id travels over torch.distributed once at set-up).  Measured
+with one rank at C2 (40 steps, alternating): 6.90 ms per step without a collective, 6.95 / 6.96 ms through torch,
+6.93 / 6.99 ms native — the route is not what bounds the step, so the default is the one every PyTorch-ROCm
+installation exercises; the native one exists for hosts without PyTorch (include/mimo_hip.h).  Labels / responsibilities stay on the owning rank; the Philox counter uses
 the global row index, so labels do not depend on the number of ranks.
 
 ShardedEngine has the HipEngine interface, so the mixture drivers run unchanged on top of it.
@@ -30,7 +39,16 @@ class ShardedEngine:
         self._structure = 'full'
         self._xx_global = None
         self._nccl = dist.get_backend(group) == "nccl"
-        self._device_path = hasattr(inner, "estep_device") and self._nccl
+        self._native = False
+        import os
+        if self._nccl and hasattr(inner, "comm_init") and os.environ.get("MIMO_SHARDED_NATIVE", "0") == "1":
+            try:
+                self._attach_native(inner)
+            except Exception as exc:          # librccl not loadable, communicator refused: the torch route still works
+                import warnings
+                warnings.warn(f"native RCCL communicator unavailable ({exc}); using torch.distributed")
+                self._native = False
+        self._device_path = hasattr(inner, "estep_device") and self._nccl and not self._native
         if self._device_path:
             # kernel -> all-reduce -> copy to pinned memory are ordered by ONE stream of this object's own: torch's
             # current stream may be the null stream, whose handle (0) means "the context's private stream" to
@@ -38,6 +56,28 @@ class ShardedEngine:
             import torch
             self._stream = torch.cuda.Stream(device=self.device)
             inner.set_stream(self._stream.cuda_stream)
+
+    def _attach_native(self, engine):
+        """rank 0 creates the RCCL unique id, torch.distributed carries the 128 bytes to the other ranks, every rank
+        attaches its context: from here on every statistics call of `engine` returns sums over the ranks."""
+        box = [type(engine).comm_unique_id() if self.rank == 0 else None]
+        self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                         group=self.group)
+        engine.comm_init(box[0], self.rank, self.world)
+        self._native = True
+
+    def _nan_share(self, S):
+        """(native route) the NaN rows' share of the gating counts is a host-side sum over THIS rank's rows."""
+        if S is None or not self._any_nan():       # (one cached scalar all-reduce per data set)
+            return S
+        local = np.zeros_like(S.n) if getattr(S, 'n_rows', None) is None else S.n_rows - S.n
+        S.n_rows = S.n + self._allreduce_array(local)     # every rank joins, with or without NaN rows of its own
+        return S
+
+    def _any_nan(self):
+        if getattr(self, '_any_nan_cache', None) is None:
+            self._any_nan_cache = bool(self._allreduce_array(np.array([float(getattr(self.inner, 'n_bad', 0))]))[0] > 0)
+        return self._any_nan_cache
 
     # ---- pass-throughs ---------------------------------------------------------------------------
     @property
@@ -53,6 +93,7 @@ class ShardedEngine:
         self.inner.upload(Z_local)
         self.inner.set_row_offset(self._row0)
         self._xx_global = None
+        self._any_nan_cache = None
 
     def set_row_offset(self, row0):
         self._row0 = int(row0)
@@ -61,7 +102,7 @@ class ShardedEngine:
     def spawn(self):
         """A second sharded engine over the same ranks (the SVI minibatch engine): its statistics are all-reduced
         like the main one's, so a minibatch is the union of the ranks' local draws."""
-        return ShardedEngine(self.inner.spawn(), self.group, self._row0)
+        return ShardedEngine(self.inner.spawn(), self.group, self._row0)      # (attaches its own communicator)
 
     def global_rows(self, n_local):
         """sum over the ranks of `n_local` (cached per value: one scalar all-reduce)."""
@@ -161,11 +202,15 @@ class ShardedEngine:
         engine returns for its rows, the device route adds them after the all-reduce (`_linear_finish`)."""
         self._structure = structure
         if hasattr(self.inner, 'set_structure'):
-            self.inner.set_structure(structure)
+            self.inner.set_structure(structure)        # (native route: the inner engine's pooled moment is already global)
 
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):
         """`row_weights` are the weights of THIS rank's rows (hierarchical drivers)."""
+        if self._native:        # the library already summed the block and the scalars over the ranks
+            S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
+                                     entropy_split=entropy_split, row_weights=row_weights)
+            return self._nan_share(S), sc
         if row_weights is not None:
             S, sc = self.inner.estep(c, b, W, stats=stats, keep_resp=keep_resp, keep_logp=keep_logp, keep_lse=keep_lse,
                                      entropy_split=entropy_split, row_weights=row_weights)
@@ -192,6 +237,10 @@ class ShardedEngine:
     def estep_async(self, c, b, W):
         """Enqueue the fused pass, the RCCL all-reduce of the statistic block and its copy to pinned host
         memory on the shared stream; estep_wait() synchronises.  Host work in between overlaps all three."""
+        if self._native:
+            self.inner.estep_async(c, b, W)
+            self._pending, self._pending_sync = 'native', False
+            return
         if not self._device_path or (self._linear() and not self._tied(W)):
             self._pending = self.estep(c, b, W)
             self._pending_sync = True
@@ -210,6 +259,9 @@ class ShardedEngine:
 
     def estep_wait(self):
         p, self._pending = self._pending, None
+        if p == 'native':
+            S, sc = self.inner.estep_wait()
+            return self._nan_share(S), sc
         if self._pending_sync:
             return p
         K, slen, stream, W0 = p
@@ -222,6 +274,10 @@ class ShardedEngine:
         return self._allreduce_array(np.array(sc, dtype=float))
 
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True, keep_logp=False):
+        if self._native:
+            labels, S = self.inner.gibbs_labels(c, b, W, seed=seed, sweep=sweep, u=u, stats=stats,
+                                                return_labels=return_labels, keep_logp=keep_logp)
+            return labels, self._nan_share(S)
         linear = self._linear()
         if self._device_path and stats and u is None and not return_labels and not keep_logp \
                 and (not linear or self._tied(W)):
@@ -240,16 +296,22 @@ class ShardedEngine:
         return labels, S
 
     def weighted_stats(self, resp=None, K=None):
+        if self._native:
+            return self._nan_share(self.inner.weighted_stats(resp, K))
         S, _ = self._allreduce_host(self.inner.weighted_stats(resp, K), [])
         return S
 
     def label_stats(self, labels, K):
+        if self._native:
+            return self._nan_share(self.inner.label_stats(labels, K))
         S, _ = self._allreduce_host(self.inner.label_stats(labels, K), [])
         return S
 
     def random_resp_stats(self, K, seed=0):
         """Random initial responsibilities on every shard (Philox counters use the global row: the draw does not
         depend on the number of ranks), statistics summed over the ranks."""
+        if self._native:
+            return self.inner.random_resp_stats(K, seed)
         S, _ = self._allreduce_host(self.inner.random_resp_stats(K, seed), [])
         return S
 

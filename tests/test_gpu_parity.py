@@ -332,10 +332,14 @@ def test_linear_structure_for_tied_blocks(engine, D, K, N):
         engine.set_structure('full')
 
 
-def test_sharded_device_route_over_one_rank_rccl(engine):
-    """ShardedEngine on the GPU: the statistic block goes kernel -> device buffer -> RCCL all-reduce -> pinned host
-    memory.  With a one-rank group the result must equal the plain engine's, for the full and the 'linear' structure,
-    synchronous, asynchronous and for the Gibbs step (the two-rank arithmetic is covered on CPU in test_sharded_gloo)."""
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_sharded_device_route_over_one_rank_rccl(engine, native, monkeypatch):
+    """ShardedEngine on the GPU, both routes of the all-reduce: native = the library's own RCCL communicator (the
+    collective is enqueued by libmimo_hip.so behind its kernels), otherwise kernel -> device buffer -> torch.distributed
+    all_reduce -> pinned host memory.  With a one-rank group the result must equal the plain engine's, for the full and
+    the 'linear' structure, synchronous, asynchronous and for the Gibbs step (the two-rank arithmetic is covered on CPU in
+    test_sharded_gloo)."""
+    monkeypatch.setenv("MIMO_SHARDED_NATIVE", native)
     import torch
     import torch.distributed as dist
     from mimo_amd.sharded import ShardedEngine
@@ -351,7 +355,7 @@ def test_sharded_device_route_over_one_rank_rccl(engine):
                                 device_id=torch.device("cuda:0"))
     try:
         sh = ShardedEngine(HipEngine(0), row_offset=0)
-        assert sh._device_path
+        assert sh._native == (native == "1") and sh._device_path == (native == "0")
         sh.upload(Z)
         for structure, W in (("full", Wf), ("linear", Wt), ("linear", Wf)):
             try:
