@@ -68,7 +68,9 @@ report("full-covariance GMM, mean-field VI, sample_likelihood=False (no per-iter
 prior = TiedNormalWisharts(K, D, np.zeros((K, D)), 1e-2 * np.ones(K), np.stack(K * [np.eye(D)]), (D + 2.) * np.ones(K))
 tied = BayesianMixtureOfGaussians(gd(), TiedGaussiansWithNormalWisharts(K, D, prior, engine=eng), engine=eng)
 t = per_iter(lambda it: tied.meanfield_coordinate_descent(X, randomize=False, maxiter=it, tol=0., progress_bar=False))
-report("tied-covariance GMM, mean-field VI", t, N * K, N * K * (FE + FS))
+FEl, FSl = 2 * (D + 1) + 8, 2 * (D + 1) + 1              # 'linear' structure: both products over the D+1 features z_a, 1
+report("tied-covariance GMM, mean-field VI (MIMO_STRUCT_LINEAR: D+1 feature kernels)", t, N * K, N * K * (FEl + FSl),
+       "flops of the linear form (the shared quadratic term never reaches the kernels): 2(D+1)+8 and 2(D+1)+1 per evaluation")
 
 prior = StackedNormalGammas(K, D, np.zeros((K, D)), 1e-2 * np.ones((K, D)), (D + 1.) / 2. * np.ones((K, D)), 0.5 * np.ones((K, D)))
 diag = BayesianMixtureOfGaussians(gd(), StackedGaussiansWithNormalGammas(K, D, prior, engine=eng), engine=eng)
@@ -86,12 +88,13 @@ hier = BayesianMixtureOfGaussiansWithHierarchicalPrior(
     K, D, gd(), TiedGaussiansWithHierarchicalNormalWisharts(K, D, hyper, hp, engine=eng), engine=eng)
 t = per_iter(lambda it: hier.meanfield_coordinate_descent(X, randomize=False, maxiter=it, maxsubiter=5, tol=0.,
                                                           progress_bar=False))
-report("hierarchical (Normal-Wishart hyper-prior) GMM, mean-field VI, 5 sub-iterations", t, N * K, N * K * (FE + FS))
+report("hierarchical (Normal-Wishart hyper-prior) GMM, mean-field VI, 5 sub-iterations (linear structure)", t, N * K,
+       N * K * (FEl + FSl), "flops of the linear form")
 w = np.linspace(0.5, 1., N)
 t = per_iter(lambda it: hier.meanfield_coordinate_descent(X, randomize=False, weights=w, maxiter=it, maxsubiter=5, tol=0.,
                                                           progress_bar=False))
-report("hierarchical GMM, mean-field VI with per-row weights (mimo_estep_weighted, generic kernel)", t, N * K,
-       N * K * (FE + FS))
+report("hierarchical GMM, mean-field VI with per-row weights (mimo_estep_weighted, generic kernel, linear structure)", t, N * K,
+       N * K * (FEl + FSl), "flops of the linear form")
 
 t = per_iter(lambda it: full.meanfield_stochastic_descent(X, randomize=False, maxiter=it, batch_size=4096, progress_bar=False))
 report("full-covariance GMM, SVI outer iteration (4096-row natural-gradient step + full-data bound)", t, N * K,
