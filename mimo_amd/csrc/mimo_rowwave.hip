@@ -313,7 +313,8 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int64_t n = t * T + tid + kWG * h;
-      lab[h] = n < N ? a.labels[n] : -1;
+      const int l = n < N ? a.labels[n] : -1;
+      lab[h] = l < K ? l : -1;            // a label outside [0, K) (a caller's vector) is skipped, never an index
     }
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
