@@ -1,4 +1,4 @@
-// gfx950 kernels of the LARGE-K Gibbs sweep (64 < K <= 256, Dz <= 9: BASELINE config C3, DP-GMM with Kmax = 256):
+// gfx950 kernels of the Gibbs sweep for 17 <= K <= 256 at Dz <= 9 (BASELINE config C3: DP-GMM with Kmax = 256, D = 8):
 //
 //   gibbs_rowwave_kernel<KB>   label pass:  l = Theta . Phi'  ->  inverse-CDF draw, nothing but the labels leaves
 //   label_stats_kernel<DZ>     statistics of the labels just drawn, bound by HBM (the data once + 4 bytes per row)
@@ -24,6 +24,7 @@
 // mimo/utils/stats.py:8-21 (label = #{k : u cum_K > cum_k}), gaussian.py:491-502, data.py:160-169.
 #include "mimo_device.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace mimo {
@@ -218,15 +219,24 @@ size_t rowwave_lds_bytes(int KB, int NS, int ZS) {
   return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + kExpTab + (size_t)(kRowWaveWG / 64) * 16 * ZS);
 }
 
-int rowwave_kb(int K) {           // row blocks the kernel is instantiated for: 6, 8, .., 16
+int rowwave_kb(int K) {           // row blocks the kernel is instantiated for: 2, 4, .., 16
   int kb = (K + 15) / 16;
   kb += kb & 1;
-  return kb < 6 ? 6 : kb;
+  return kb < 2 ? 2 : kb;
 }
 
-// K > 64 (below that the fused tile kernels hold everything in one pass), Dz <= 9 (F16 <= 64: the image fits LDS)
+// Smallest K that takes the row-owner route (tuning knob).  Measured crossover against the fused tile kernels, N = 1e7
+// (tools/midk_time.py): K = 64, D = 8 sweep 2.50 -> 1.93 ms, K = 32: 1.99 -> 1.24, K = 17: 1.94 -> 1.36, K = 24: 1.91 -> 1.25,
+// D = 5, K = 40: 2.07 -> 1.42; at K <= 16 the label-statistics pass (one thread per component) has too few workers:
+// K = 8: 1.49 -> 1.53, K = 4: 1.39 -> 1.94, so those stay on the tile kernels.
+static int rowwave_min_k() {
+  static const int v = [] { const char* e = getenv("MIMO_ROWWAVE_MIN_K"); return e ? atoi(e) : 17; }();
+  return v;
+}
+
+// 17 <= K <= 256 (rowwave_min_k), Dz <= 9 (F16 <= 64: the operand image fits LDS)
 bool rowwave_covers(int K, int F16, int ZS) {
-  if (K <= 64 || K > 256 || F16 > 64) return false;
+  if (K < rowwave_min_k() || K > 256 || F16 > 64) return false;
   return rowwave_lds_bytes(rowwave_kb(K), F16 / 4, ZS) <= 160 * 1024;
 }
 
@@ -234,6 +244,8 @@ typedef void (*rowwave_fn)(const KernelArgs);
 template <int NS4>
 static rowwave_fn pick_rowwave_kb(int kb) {
   switch (kb) {
+    case 2: return gibbs_rowwave_kernel<2, NS4>;
+    case 4: return gibbs_rowwave_kernel<4, NS4>;
     case 6: return gibbs_rowwave_kernel<6, NS4>;
     case 8: return gibbs_rowwave_kernel<8, NS4>;
     case 10: return gibbs_rowwave_kernel<10, NS4>;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   }
 }
 
-bool label_stats_covers(int K, int D) { return K > 64 && K <= 256 && D >= 1 && D <= 9; }
+bool label_stats_covers(int K, int D) { return K >= rowwave_min_k() && K <= 256 && D >= 1 && D <= 9; }
 
 int label_stats_grid(const KernelArgs& a, int num_cu) {
   const int64_t tiles = (a.N + kLsTile - 1) / kLsTile;
