@@ -293,7 +293,7 @@ static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, c
   return MIMO_OK;
 }
 
-// Label pass on the row-owner kernels (mimo_rowwave.hip): 17 <= K <= 256, Dz <= 9, full structure, nothing but labels
+// Label pass on the row-owner kernels (mimo_rowwave.hip): Dz <= 9 (beyond the small-shape kernel's range), full structure, nothing but labels
 // (+ their statistics) requested.
 static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
   static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE"); return !e || atoi(e) != 0; }();   // tuning knob

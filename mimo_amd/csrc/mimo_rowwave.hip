@@ -1,4 +1,4 @@
-// gfx950 kernels of the Gibbs sweep for 17 <= K <= 256 at Dz <= 9 (BASELINE config C3: DP-GMM with Kmax = 256, D = 8):
+// gfx950 kernels of the Gibbs sweep at Dz <= 9, K <= 256 (BASELINE config C3: DP-GMM with Kmax = 256, D = 8):
 //
 //   gibbs_rowwave_kernel<KB>   label pass:  l = Theta . Phi'  ->  inverse-CDF draw, nothing but the labels leaves
 //   label_stats_kernel<DZ>     statistics of the labels just drawn, bound by HBM (the data once + 4 bytes per row)
@@ -225,16 +225,17 @@ int rowwave_kb(int K) {           // row blocks the kernel is instantiated for: 
   return kb < 2 ? 2 : kb;
 }
 
-// Smallest K that takes the row-owner route (tuning knob).  Measured crossover against the fused tile kernels, N = 1e7
-// (tools/midk_time.py): K = 64, D = 8 sweep 2.50 -> 1.93 ms, K = 32: 1.99 -> 1.24, K = 17: 1.94 -> 1.36, K = 24: 1.91 -> 1.25,
-// D = 5, K = 40: 2.07 -> 1.42; at K <= 16 the label-statistics pass (one thread per component) has too few workers:
-// K = 8: 1.49 -> 1.53, K = 4: 1.39 -> 1.94, so those stay on the tile kernels.
+// Smallest K that takes the row-owner route (tuning knob; default: every K).  Measured against the fused tile kernels,
+// N = 1e7 (tools/midk_time.py, labels + statistics): K = 64, D = 8 sweep 2.50 -> 1.69 ms, K = 32: 1.99 -> 1.05, K = 17: 1.94 ->
+// 1.07, K = 16: 1.54 -> 1.05, K = 8: 1.52 -> 1.00, D = 5, K = 16: 1.52 -> 0.82, D = 7, K = 4: 1.43 -> 0.98 (the last three
+// only since the label-statistics pass spreads a component's rows over 256 / Kp threads: with one thread per
+// component they lost).
 static int rowwave_min_k() {
-  static const int v = [] { const char* e = getenv("MIMO_ROWWAVE_MIN_K"); return e ? atoi(e) : 17; }();
+  static const int v = [] { const char* e = getenv("MIMO_ROWWAVE_MIN_K"); return e ? atoi(e) : 1; }();
   return v;
 }
 
-// 17 <= K <= 256 (rowwave_min_k), Dz <= 9 (F16 <= 64: the operand image fits LDS)
+// K <= 256 (from rowwave_min_k), Dz <= 9 (F16 <= 64: the operand image fits LDS)
 bool rowwave_covers(int K, int F16, int ZS) {
   if (K < rowwave_min_k() || K > 256 || F16 > 64) return false;
   return rowwave_lds_bytes(rowwave_kb(K), F16 / 4, ZS) <= 160 * 1024;
@@ -284,8 +285,11 @@ hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t strea
 }
 
 // ------------------------------------------------------------------------------------------
-// Statistics of hard labels, K <= 256, Dz <= 9, full feature map.  Workgroup = 256 threads, thread k owns
-// component k: its F accumulators (n_k, sum z, upper triangle of sum z z') live in registers across all tiles.
+// Statistics of hard labels, K <= 256, Dz <= 9, full feature map.  Workgroup = 256 threads; with Kp = the power of two
+// >= K, thread t works for component t % Kp as part t / Kp of P = 256 / Kp: it takes every P-th row of that component's
+// list (K > 128: one thread per component; K = 32: eight threads share a component, so all four waves accumulate).
+// Its F accumulators (n_k, sum z, upper triangle of sum z z') live in registers across all tiles; the parts of a
+// component are added in part order at the end (fixed association).
 // Per tile of kLsTile rows:  z tile + labels -> LDS;  bitmap[k] |= 1 << row (integer atomics: the result does not
 // depend on their order);  stable position of every row inside its component's list = popcount of the lower bits;
 // thread k adds its rows in ascending row order.  Partial block per workgroup in the tile kernels' layout.
@@ -299,15 +303,19 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   constexpr int T = kLsTile, NW = T / 32;           // bitmap words per component
   constexpr int ZPT = (T * DZ + kWG - 1) / kWG;     // z elements per thread
   __shared__ __align__(16) double Zt[T * ZS];
-  __shared__ uint32_t bitmap[kWG * NW];             // [k][word] — k-major so that thread k reads 16 consecutive words
+  __shared__ __align__(16) uint32_t bitmap[kWG * NW];   // [k][word] — k-major so that thread k reads 16 consecutive words
   __shared__ uint16_t list[T];
   __shared__ int start[kWG + 1];
+  __shared__ int cnts[kWG];
   __shared__ int wsum[4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
   const int64_t N = a.N;
   const int64_t ntiles = (N + T - 1) / T;
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;
+  const int P = kWG / Kp, myk = tid & (Kp - 1), mypart = tid / Kp;      // (Kp <= 256: K <= 256)
 
   double acc[F];
 #pragma unroll
@@ -370,8 +378,8 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     int off = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
-    const int st = off + incl - cntk;
-    start[tid] = st;
+    start[tid] = off + incl - cntk;
+    cnts[tid] = cntk;
     wg_sync();
     // stable position of each row in its component's list
     auto place = [&](int l, int row) {
@@ -385,8 +393,9 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     place(l0, tid);
     place(l1, tid + kWG);
     wg_sync();
-    // thread k: its rows, ascending
-    for (int p = 0; p < cntk; ++p) {
+    // thread (component myk, part mypart): every P-th row of the component's list, ascending
+    const int st = start[myk], cmine = cnts[myk];
+    for (int p = mypart; p < cmine; p += P) {
       const int row = list[st + p];
       const double* zp = Zt + row * ZS;
       double z[DZ];
@@ -406,13 +415,40 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   // per-workgroup partial block [16 K16][F16_total] (+ 4 scalars: none from this pass)
   const int FT = a.F16_total;
   const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
-  double* P = a.partials + (size_t)blockIdx.x * pstride;
-  if (tid < a.K16 * 16) {
+  double* P_out = a.partials + (size_t)blockIdx.x * pstride;
+  if (P > 1) {
+    // add the parts of every component in part order, eight features at a time through LDS
+    double* red = reinterpret_cast<double*>(bitmap);   // [kWG][8]  (the bitmap is free now)
+    static_assert(sizeof(uint32_t) * kWG * NW >= sizeof(double) * kWG * 8, "reduction scratch fits the bitmap");
 #pragma unroll
-    for (int f = 0; f < F; ++f) P[(size_t)tid * FT + f] = tid < K ? acc[f] : 0.0;
+    for (int f0 = 0; f0 < F; f0 += 8) {
+      wg_sync();
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (f0 + i < F) red[tid * 8 + i] = acc[f0 + i];
+      wg_sync();
+      if (mypart == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (f0 + i < F) {
+            double s = acc[f0 + i];
+            for (int q = 1; q < P; ++q) s += red[(q * Kp + myk) * 8 + i];
+            acc[f0 + i] = s;
+          }
+        }
+      }
+    }
+  }
+  if (mypart == 0 && myk < a.K16 * 16) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) P_out[(size_t)myk * FT + f] = myk < K ? acc[f] : 0.0;
+  }
+  if (P > 1 && Kp < a.K16 * 16) {       // rows of the partial block between Kp and 16 K16 (K = 17 .. 31 -> Kp = 32 covers them; K <= 16 -> Kp = 16 = 16 K16)
+    for (int k = Kp + tid; k < a.K16 * 16; k += kWG)
+      for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
   }
   if (tid == 0 && a.write_scalars) {
-    double* Ps = P + (size_t)a.K16 * 16 * FT;
+    double* Ps = P_out + (size_t)a.K16 * 16 * FT;
     Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
   }
 }
