@@ -65,6 +65,9 @@ typedef struct mimo_ctx mimo_ctx;
 #define MIMO_F_DEVICE_IN      0x20  /* `resp` / `labels` / `u` inputs are device pointers          */
 #define MIMO_F_ENTROPY_SPLIT  0x40  /* also produce scalars[1], scalars[2] (see above)             */
 #define MIMO_F_ASYNC          0x80  /* enqueue only; fetch the host results with mimo_wait()       */
+#define MIMO_F_WEIGHTS_RESIDENT 0x100 /* mimo_estep_weighted: reuse the row weights the previous weighted call uploaded
+                                         (the hierarchical drivers pass the same vector every iteration: N doubles less
+                                         over PCIe per call); `row_weights` is ignored                                */
 
 /* ---- lifetime -------------------------------------------------------------------------- */
 

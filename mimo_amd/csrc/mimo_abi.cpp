@@ -65,6 +65,7 @@ struct mimo_ctx {
   double* lse = nullptr;   size_t lse_cap = 0;   bool lse_valid = false;
   int32_t* labels = nullptr; size_t labels_cap = 0; bool labels_valid = false;
   double* u_d = nullptr;   size_t u_cap = 0;
+  bool weights_resident = false;     // u_d holds the row weights of the last mimo_estep_weighted (not uniforms of a label pass)
   double* win = nullptr;   size_t win_cap = 0;    // staged host weights
   int32_t* lin = nullptr;  size_t lin_cap = 0;    // staged host labels
 
@@ -691,6 +692,7 @@ static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
     return fail(ctx, MIMO_E_UNSUPPORTED, "Dz = %d outside [1, %d]", Dz, kMaxD);
   ctx->N = N; ctx->D = Dz;
   ctx->resp_valid = ctx->logp_valid = ctx->lse_valid = ctx->labels_valid = false;
+  ctx->weights_resident = false;
   return prepare_features(ctx, Dz);
 }
 
@@ -812,7 +814,8 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
   return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
   if ((rc = check_shapes(ctx, K))) return rc;
-  if (!c || !b || !W || !row_weights) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: c, b, W, row_weights must be non-NULL");
+  if (!c || !b || !W || (!row_weights && !(flags & MIMO_F_WEIGHTS_RESIDENT)))
+    return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: c, b, W, row_weights must be non-NULL");
   if (flags & MIMO_F_NO_STATS) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: the weights only enter the statistics");
   if (!S && !(flags & MIMO_F_ASYNC)) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: S is NULL");
   KernelArgs a;
@@ -822,7 +825,10 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
                 "its weights as a table (mimo_estep + mimo_weighted_stats)", K, ctx->D);
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
-  if (flags & MIMO_F_DEVICE_IN) {
+  if (flags & MIMO_F_WEIGHTS_RESIDENT) {
+    if (!ctx->weights_resident) return fail(ctx, MIMO_E_STATE, "mimo_estep_weighted: no row weights are resident on the device");
+    a.u = ctx->u_d;
+  } else if (flags & MIMO_F_DEVICE_IN) {
     a.u = row_weights;
   } else {
     const size_t n1 = (size_t)(ctx->N > 0 ? ctx->N : 1);
@@ -830,6 +836,7 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
     HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, row_weights, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // pageable host memory
     a.u = ctx->u_d;
+    ctx->weights_resident = true;
   }
   if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
@@ -877,6 +884,7 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
       HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, u, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // u is pageable host memory
       a.u = ctx->u_d;
+      ctx->weights_resident = false;
     }
   }
   const bool rw = !use_small(ctx, K) && use_rowwave(ctx, K, (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0);
@@ -965,6 +973,7 @@ int mimo_sample_from_log(mimo_ctx* ctx, const double* logp, int K, int64_t N, co
       if ((rc = ensure_dev(ctx, &ctx->u_d, &ctx->u_cap, n1))) return rc;
       HIP_TRY(ctx, hipMemcpyAsync(ctx->u_d, u, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       ud = ctx->u_d;
+      ctx->weights_resident = false;
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // pageable host sources

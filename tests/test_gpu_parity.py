@@ -783,3 +783,32 @@ def test_rows_with_nan(engine, name):
     assert engine.n_bad == len(g["bad"]) and torch.isnan(t).any()
     engine.upload(np.nan_to_num(g["X"]))
     assert engine.n_bad == 0
+
+
+def test_row_weights_stay_resident(engine):
+    """mimo_estep_weighted with MIMO_F_WEIGHTS_RESIDENT: the engine re-sends a weight vector only when its content changed;
+    a label pass with host uniforms (which takes the same device buffer) or a new data set invalidates the resident copy."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(8)
+    N, D, K = 30011, 7, 20
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    R = np.exp(L - logsumexp(L, axis=0))
+    w = rng.random(N) + 0.1
+
+    def check(w):
+        S, _ = engine.estep(c, b, W, row_weights=w)
+        n, sx, sxx = O.packed_stats(Z, R * w)
+        assert rel_err(S.n, n) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    check(w)
+    assert engine._w_key is not None
+    check(w)                                            # resident copy
+    w *= 0.5                                            # edited in place: new fingerprint, re-sent
+    check(w)
+    engine.gibbs_labels(c, b, W, u=rng.random(N), stats=False)
+    assert engine._w_key is None
+    check(w)
+    engine.upload(Z[:20000]); engine.upload(Z)
+    check(w)
