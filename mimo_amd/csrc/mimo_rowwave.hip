@@ -80,20 +80,21 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
   wg_sync();
 
-  // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < 3 (16 D <= 144)
+  // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < ZI (16 D <= 144 up to Dz = 9, <= 256 up to 16)
+  constexpr int ZI = NS4 <= 4 ? 3 : 4;
   const int64_t nsteps = (N + 15) / 16;
   const int64_t nwaves = (int64_t)gridDim.x * (kRowWaveWG / 64), wv = (int64_t)blockIdx.x * (kRowWaveWG / 64) + wave;
-  int zoff[3];
+  int zoff[ZI];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < ZI; ++i) {
     const int e = lane + 64 * i, r = e / D;
     zoff[i] = e < 16 * D ? r * ZS + (e - r * D) : -1;
   }
-  double zr[3];
+  double zr[ZI];
   auto load_z = [&](int64_t t) {
     const int64_t base = t * 16 * D, total = N * D;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < ZI; ++i) {
       const int64_t gidx = base + lane + 64 * i;
       zr[i] = (zoff[i] >= 0 && gidx < total) ? a.Z[gidx] : 0.0;
     }
@@ -103,14 +104,29 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   const double* zrow = Zw + j * ZS;
   const double* thl = Th + lane;
   // B operand of step s, lane (q, j): feature 4 s + q of row j = z~[a] z~[b]; the two LDS addresses are fixed for the
-  // whole kernel (2 NS registers), so a step costs two LDS reads and one product
-  const double* fpa[NS];
-  const double* fpb[NS];
+  // whole kernel (2 NS registers), so a step costs two LDS reads and one product; beyond 16 steps (Dz > 9) the two
+  // byte offsets share one register per step (two more integer instructions per step)
+  constexpr bool kPacked = NS > 16;
+  const double* fpa[kPacked ? 1 : NS];
+  const double* fpb[kPacked ? 1 : NS];
+  uint32_t fo[kPacked ? NS : 1];
 #pragma unroll
   for (int s2 = 0; s2 < NS; ++s2) {
-    fpa[s2] = zrow + a.feat[2 * (4 * s2 + q)];
-    fpb[s2] = zrow + a.feat[2 * (4 * s2 + q) + 1];
+    if constexpr (kPacked) {
+      fo[s2] = 8u * a.feat[2 * (4 * s2 + q)] | (8u * a.feat[2 * (4 * s2 + q) + 1]) << 16;
+    } else {
+      fpa[s2] = zrow + a.feat[2 * (4 * s2 + q)];
+      fpb[s2] = zrow + a.feat[2 * (4 * s2 + q) + 1];
+    }
   }
+  auto feature = [&](int s2) -> double {
+    if constexpr (kPacked) {
+      const char* zb = reinterpret_cast<const char*>(zrow);
+      return *reinterpret_cast<const double*>(zb + (fo[s2] & 0xffffu)) * *reinterpret_cast<const double*>(zb + (fo[s2] >> 16));
+    } else {
+      return *fpa[s2] * *fpb[s2];
+    }
+  };
   // Philox uniforms four steps at a time: lane (q, j) draws the uniform of row j of this wave's step t + q nwaves
   double ubatch = 0.0;
   int uphase = 0;
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     const bool valid = n < N;
     // ---- stage this step's z~ rows in the wave's own LDS block (LDS operations of one wave execute in order)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < ZI; ++i)
       if (zoff[i] >= 0) Zw[zoff[i]] = zr[i];
     if (q == 0) {
       Zw[j * ZS + D] = valid ? 1.0 : 0.0;     // rows past N: every feature 0, l = 0, never written
@@ -137,11 +153,11 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     double ring[PF];
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = thl[e * 64];
-    double bq = *fpa[0] * *fpb[0];
+    double bq = feature(0);
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {            // NS is a multiple of 4: slot (s2 KB + rb) % PF is static
       const double bcur = bq;
-      if (s2 + 1 < NS) bq = *fpa[s2 + 1] * *fpb[s2 + 1];
+      if (s2 + 1 < NS) bq = feature(s2 + 1);
 #pragma unroll
       for (int rb = 0; rb < KB; ++rb) {
         const int e = s2 * KB + rb;
@@ -235,10 +251,13 @@ static int rowwave_min_k() {
   return v;
 }
 
-// K <= 256 (from rowwave_min_k), Dz <= 9 (F16 <= 64: the operand image fits LDS)
+// K <= 256 (from rowwave_min_k) at Dz <= 9 (F16 <= 64); Dz 10 .. 16 (F16 <= 160) while the operand image fits LDS next to
+// the exp table: K <= 64, and K <= 128 up to Dz = 12 (the instantiations below)
 bool rowwave_covers(int K, int F16, int ZS) {
-  if (K < rowwave_min_k() || K > 256 || F16 > 64) return false;
-  return rowwave_lds_bytes(rowwave_kb(K), F16 / 4, ZS) <= 160 * 1024;
+  if (K < rowwave_min_k() || K > 256 || F16 > 160) return false;
+  const int kb = rowwave_kb(K);
+  if (F16 > 64 && !(kb <= 4 || (kb <= 8 && F16 <= 96))) return false;
+  return rowwave_lds_bytes(kb, F16 / 4, ZS) <= 160 * 1024;
 }
 
 typedef void (*rowwave_fn)(const KernelArgs);
@@ -256,12 +275,28 @@ static rowwave_fn pick_rowwave_kb(int kb) {
   }
   return nullptr;
 }
+template <int NS4>
+static rowwave_fn pick_rowwave_wide(int kb) {      // Dz 10 .. 16: K <= 64 (and K <= 128 while F16 <= 96)
+  switch (kb) {
+    case 2: return gibbs_rowwave_kernel<2, NS4>;
+    case 4: return gibbs_rowwave_kernel<4, NS4>;
+    case 6: if constexpr (NS4 <= 6) return gibbs_rowwave_kernel<6, NS4>; else return nullptr;
+    case 8: if constexpr (NS4 <= 6) return gibbs_rowwave_kernel<8, NS4>; else return nullptr;
+  }
+  return nullptr;
+}
 static rowwave_fn pick_rowwave(int kb, int F16) {
   switch (F16 / 16) {
     case 1: return pick_rowwave_kb<1>(kb);
     case 2: return pick_rowwave_kb<2>(kb);
     case 3: return pick_rowwave_kb<3>(kb);
     case 4: return pick_rowwave_kb<4>(kb);
+    case 5: return pick_rowwave_wide<5>(kb);
+    case 6: return pick_rowwave_wide<6>(kb);
+    case 7: return pick_rowwave_wide<7>(kb);
+    case 8: return pick_rowwave_wide<8>(kb);
+    case 9: return pick_rowwave_wide<9>(kb);
+    case 10: return pick_rowwave_wide<10>(kb);
   }
   return nullptr;
 }
@@ -453,10 +488,204 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   }
 }
 
-bool label_stats_covers(int K, int D) { return K >= rowwave_min_k() && K <= 256 && D >= 1 && D <= 9; }
+// ------------------------------------------------------------------------------------------
+// The same pass for Dz = 10 .. 16 (F = 66 .. 153 features: too many accumulators for one thread).  The 256 / Kp threads of
+// a component split the FEATURES first — thread slice s takes the rows i = s, s + FP, ... of the upper triangle
+// (sum z_i z_j for j >= i, and sum z_i; slice 0 also the count) — and, if threads are left (Kp < 256 / FP), the rows of
+// the component's list as in label_stats_kernel.  FP = 4 for K <= 64, 2 for K <= 128 (Dz <= 12).  Tiles of 256 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int kLsWideTile = 256;
+constexpr int slice_count(int DZ, int FP, int S) {
+  int n = S == 0 ? 1 : 0;
+  for (int i = S; i < DZ; i += FP) n += DZ - i + 1;
+  return n;
+}
+
+template <int DZ, int FP, int S, int MAXA>
+__device__ __forceinline__ void slice_accumulate(double (&acc)[MAXA], const double (&z)[DZ]) {
+  int a = 0;
+#pragma unroll
+  for (int i = S; i < DZ; i += FP) {
+#pragma unroll
+    for (int j = i; j < DZ; ++j) { acc[a] = fma(z[i], z[j], acc[a]); ++a; }
+    acc[a] += z[i]; ++a;
+  }
+  if constexpr (S == 0) acc[a] += 1.0;
+}
+
+template <int DZ, int FP, int S, int MAXA>
+__device__ __forceinline__ void slice_store(const double (&acc)[MAXA], double* __restrict__ Pk) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
+  int a = 0;
+#pragma unroll
+  for (int i = S; i < DZ; i += FP) {
+    const int f0 = i * (DZ + 1) - i * (i - 1) / 2;       // feature (i, i); (i, j) follows at f0 + j - i, (i, DZ) at f0 + DZ - i
+#pragma unroll
+    for (int j = i; j < DZ; ++j) { Pk[f0 + j - i] = acc[a]; ++a; }
+    Pk[f0 + DZ - i] = acc[a]; ++a;
+  }
+  if constexpr (S == 0) Pk[F - 1] = acc[a];
+}
+
+template <int DZ, int FP>
+__global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelArgs a) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
+  constexpr int ZS = DZ <= 10 ? 10 : DZ <= 14 ? 14 : 18;     // 16-byte aligned rows, odd stride in 16-byte units
+  constexpr int T = kLsWideTile, NW = T / 32;
+  constexpr int ZPT = (T * DZ + kWG - 1) / kWG;
+  constexpr int MAXA = slice_count(DZ, FP, 0);                // slice 0 is the largest
+  static_assert(FP == 2 || FP == 4, "feature slices per component");
+  __shared__ __align__(16) double Zt[T * ZS];
+  __shared__ __align__(16) uint32_t bitmap[kWG * NW];
+  __shared__ uint16_t list[T];
+  __shared__ int start[kWG + 1];
+  __shared__ int cnts[kWG];
+  __shared__ int wsum[4];
+  __shared__ double red[kWG * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T;
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;
+  if (Kp * FP > kWG) Kp = kWG / FP;                           // (the host only routes K <= 256 / FP here)
+  const int P = kWG / Kp, RP = P / FP;
+  const int myk = tid & (Kp - 1), part = tid / Kp, fslice = part % FP, rpart = part / FP;
+
+  double acc[MAXA];
+#pragma unroll
+  for (int i = 0; i < MAXA; ++i) acc[i] = 0.0;
+
+  double zr[ZPT];
+  int lab;
+  auto load_tile = [&](int64_t t) {
+    const int64_t base = t * T * DZ, total = N * DZ;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + (int64_t)kWG * i;
+      zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+    }
+    const int64_t n = t * T + tid;
+    const int l = n < N ? a.labels[n] : -1;
+    lab = l < K ? l : -1;
+  };
+  if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    wg_sync();
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int e = tid + kWG * i;
+      if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
+    }
+    {
+      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
+    }
+    const int l0 = lab;
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+    wg_sync();
+    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+    wg_sync();
+    int cntk = 0;
+    {
+      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) {
+        const uint4 v = bm[w];
+        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    start[tid] = off + incl - cntk;
+    cnts[tid] = cntk;
+    wg_sync();
+    if (l0 >= 0) {
+      const uint32_t* bm = bitmap + l0 * NW;
+      const int wq = tid >> 5;
+      int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
+      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+      list[start[l0] + rank] = (uint16_t)tid;
+    }
+    wg_sync();
+    const int st = start[myk], cmine = cnts[myk];
+    for (int p = rpart; p < cmine; p += RP) {
+      const int row = list[st + p];
+      const double* zp = Zt + row * ZS;
+      double z[DZ];
+#pragma unroll
+      for (int d = 0; d < DZ; ++d) z[d] = zp[d];
+      switch (fslice) {      // (uniform per wave when Kp >= 64)
+        case 0: slice_accumulate<DZ, FP, 0, MAXA>(acc, z); break;
+        case 1: slice_accumulate<DZ, FP, 1, MAXA>(acc, z); break;
+        case 2: if constexpr (FP == 4) slice_accumulate<DZ, FP, 2, MAXA>(acc, z); break;
+        default: if constexpr (FP == 4) slice_accumulate<DZ, FP, 3, MAXA>(acc, z); break;
+      }
+    }
+  }
+
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P_out = a.partials + (size_t)blockIdx.x * pstride;
+  if (RP > 1) {          // add the row parts of every (component, slice) in part order, eight accumulators at a time
+#pragma unroll
+    for (int f0 = 0; f0 < MAXA; f0 += 8) {
+      wg_sync();
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (f0 + i < MAXA) red[tid * 8 + i] = acc[f0 + i];
+      wg_sync();
+      if (rpart == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (f0 + i < MAXA) {
+            double s = acc[f0 + i];
+            for (int qq = 1; qq < RP; ++qq) s += red[((qq * FP + fslice) * Kp + myk) * 8 + i];
+            acc[f0 + i] = s;
+          }
+        }
+      }
+    }
+  }
+  // rows of the partial block without a component
+  for (int k = K + tid; k < a.K16 * 16; k += kWG)
+    for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
+  if (rpart == 0 && myk < K) {
+    double* Pk = P_out + (size_t)myk * FT;
+    switch (fslice) {
+      case 0: slice_store<DZ, FP, 0, MAXA>(acc, Pk); break;
+      case 1: slice_store<DZ, FP, 1, MAXA>(acc, Pk); break;
+      case 2: if constexpr (FP == 4) slice_store<DZ, FP, 2, MAXA>(acc, Pk); break;
+      default: if constexpr (FP == 4) slice_store<DZ, FP, 3, MAXA>(acc, Pk); break;
+    }
+  }
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = P_out + (size_t)a.K16 * 16 * FT;
+    Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
+  }
+}
+
+bool label_stats_covers(int K, int D) {
+  if (K < rowwave_min_k() || K > 256 || D < 1 || D > 16) return false;
+  if (D <= 9) return true;
+  return K <= 64 || (K <= 128 && D <= 12);      // wide kernel: 4 feature slices up to K = 64, 2 up to K = 128 (Dz <= 12)
+}
 
 int label_stats_grid(const KernelArgs& a, int num_cu) {
-  const int64_t tiles = (a.N + kLsTile - 1) / kLsTile;
+  const int tile = a.D <= 9 ? kLsTile : kLsWideTile;
+  const int64_t tiles = (a.N + tile - 1) / tile;
   int64_t g = (int64_t)num_cu * 2;
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
@@ -467,8 +696,18 @@ hipError_t launch_label_stats(const KernelArgs& a, int grid, hipStream_t stream)
   static const fn_t table[9] = {label_stats_kernel<1>, label_stats_kernel<2>, label_stats_kernel<3>, label_stats_kernel<4>,
                                 label_stats_kernel<5>, label_stats_kernel<6>, label_stats_kernel<7>, label_stats_kernel<8>,
                                 label_stats_kernel<9>};
-  if (a.D < 1 || a.D > 9) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(table[a.D - 1], dim3(grid), dim3(kWG), 0, stream, a);
+  if (a.D < 1 || a.D > 16) return hipErrorInvalidValue;
+  if (a.D <= 9) {
+    hipLaunchKernelGGL(table[a.D - 1], dim3(grid), dim3(kWG), 0, stream, a);
+    return hipGetLastError();
+  }
+  static const fn_t wide4[7] = {label_stats_wide_kernel<10, 4>, label_stats_wide_kernel<11, 4>, label_stats_wide_kernel<12, 4>,
+                                label_stats_wide_kernel<13, 4>, label_stats_wide_kernel<14, 4>, label_stats_wide_kernel<15, 4>,
+                                label_stats_wide_kernel<16, 4>};
+  static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
+  fn_t fn = a.K <= 64 ? wide4[a.D - 10] : (a.K <= 128 && a.D <= 12) ? wide2[a.D - 10] : nullptr;
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -630,7 +630,8 @@ def test_small_shape_kernel_structures(engine, D, K):
 
 @pytest.mark.parametrize("D,K", [(8, 256), (8, 65), (8, 96), (8, 97), (5, 130), (9, 160), (9, 256), (1, 200), (3, 224),
                                  (7, 128), (2, 255), (6, 100), (8, 17), (8, 32), (5, 40), (9, 64), (3, 64), (7, 33), (6, 48),
-                                 (8, 1), (8, 5), (7, 16), (5, 2), (9, 10), (6, 13)])
+                                 (8, 1), (8, 5), (7, 16), (5, 2), (9, 10), (6, 13),
+                                 (16, 64), (12, 100), (10, 17), (16, 5), (13, 40), (12, 128), (11, 70), (15, 33), (14, 64), (10, 128)])
 @pytest.mark.parametrize("N", [1, 15, 4099, 8 * 256 * 16 * 3 + 7])
 def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     """The row-owner label kernel (Theta in LDS, draw in registers; every instantiation KB = 6..16) and the

@@ -3,7 +3,7 @@ import os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SHAPES = [(8, 16), (8, 8), (5, 16), (5, 7), (9, 10), (7, 4), (6, 16), (8, 24)]
+SHAPES = [(16, 64), (16, 32), (16, 16), (12, 64), (12, 128), (10, 64), (13, 40), (16, 4)]
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     from mimo_amd.engine import HipEngine
     N = int(float(sys.argv[1])); eng = HipEngine(0)
@@ -20,6 +20,6 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
         print(f"D={D} K={K:3d} {eng.plan(K, gibbs=True)['kind']:8s} sweep kernels {ms / n:.3f} ms", flush=True)
 else:
     N = sys.argv[1] if len(sys.argv) > 1 else "1e7"
-    for mk in ("65", "1"):
+    for mk in ("300", "1"):
         print(f"--- MIMO_ROWWAVE_MIN_K={mk}", flush=True)
         subprocess.run([sys.executable, __file__, N, "child"], env=dict(os.environ, MIMO_ROWWAVE_MIN_K=mk), check=True)

@@ -11,7 +11,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 eng = HipEngine(0)
 bad = 0
 for (N, D, K) in ((3 * 1024 * 256 + 5, 2, 4), (400003, 2, 25), (300007, 4, 16), (3 * 8 * 256 * 16 + 9, 8, 256), (500009, 8, 64),
-                  (400001, 5, 16), (350003, 9, 130), (200003, 1, 32)):
+                  (400001, 5, 16), (350003, 9, 130), (200003, 1, 32), (300011, 16, 64), (250007, 12, 128), (200009, 13, 20)):
     rng = np.random.default_rng(N % 1000 + D + K)
     Z = rng.standard_normal((N, D)) * 1.5; A = rng.standard_normal((K, D, D))
     W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D); mu = rng.standard_normal((K, D)) * 2
