@@ -341,7 +341,8 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_FUSED      1   /* one fused tile kernel (MFMA): log-densities, softmax / draw, statistics        */
 #define MIMO_PLAN_TWO_STAGE  2   /* chunked E-step + statistics launches per feature column group (Dz > 16, ...)    */
 #define MIMO_PLAN_SMALL      3   /* small-shape VALU kernel (Dz <= 4, K <= 32): bound by HBM                        */
-#define MIMO_PLAN_ROWWAVE    4   /* large-K label pass: row-owner label kernel + label-indexed statistics kernel    */
+#define MIMO_PLAN_ROWWAVE    4   /* label pass: row-owner label kernel + label-indexed statistics kernel            */
+#define MIMO_PLAN_ROWWAVE_VI 5   /* softmax pass at K <= 64, Dz <= 9: row-owner kernel for both matrix products     */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
 
 /* Test hook for the no-exception contract: throws, INSIDE the guarded boundary, kind 1: std::bad_alloc,

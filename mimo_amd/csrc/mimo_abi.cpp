@@ -79,6 +79,7 @@ struct mimo_ctx {
 
   void* comm = nullptr;         // RCCL communicator (mimo_comm_init): every pass then returns statistics summed over the ranks
   int comm_world = 1;
+  bool rowwave_vi_call = false; // set by mimo_estep for the call in progress: row-owner softmax + statistics kernel
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
 
   // pending asynchronous call (MIMO_F_ASYNC)
@@ -440,9 +441,10 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const bool small = use_small(ctx, K);
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
+  const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
   const bool lstats = !small && ((src == kSrcLabels && ctx->structure == MIMO_STRUCT_FULL && label_stats_covers(K, D)) || rowwave);
   const int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
-                                                                    : fused_grid(a, ctx->num_cu, src);
+                   : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
@@ -473,6 +475,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       });
       if (rc) return rc;
     }
+  } else if (rowvi) {
+    rc = timed_launch(ctx, "vi_rowwave_kernel", [&]() -> int {
+      HIP_TRY(ctx, launch_vi_rowwave(a, grid, ctx->stream));
+      return MIMO_OK;
+    });
+    if (rc) return rc;
   } else if (small) {
     rc = timed_launch(ctx, "small_kernel", [&]() -> int {
       bool unsupported = false;
@@ -803,9 +811,16 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   a.do_stats = no_stats ? 0 : 1;
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
-  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
+  const bool rv = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) &&
+                  ctx->n_bad == 0 && ctx->structure == MIMO_STRUCT_FULL && !use_small(ctx, K) &&
+                  vi_rowwave_covers(K, ctx->F16, a.ZS);
+  if ((rc = rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
-  return run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
+  ctx->rowwave_vi_call = rv;
+  rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
+  ctx->rowwave_vi_call = false;
+  return rc;
   });
 }
 
@@ -1254,6 +1269,9 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   if (use_small(ctx, K)) {
     out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
     out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
+  } else if (!gibbs && ctx->n_bad == 0 && ctx->structure == MIMO_STRUCT_FULL && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
+    out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
+    out8[6] = rowwave_grid(a, ctx->num_cu);
   } else if (gibbs && use_rowwave(ctx, K, false)) {
     out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 2;
     out8[4] = 2;                         // Z: label kernel + statistics kernel

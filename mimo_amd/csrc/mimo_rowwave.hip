@@ -320,6 +320,270 @@ hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t strea
 }
 
 // ------------------------------------------------------------------------------------------
+// Mean-field / EM pass (softmax + weighted statistics) on row-owner waves: K <= 64, Dz <= 9.
+// Through the tile kernels this regime runs at 44 - 60 % of its MFMA time (N = 1e7, D = 8: K = 64 2.58 ms against a
+// floor of 1.56 ms, K = 32 1.90 ms): one 32-row tile per workgroup, four barriers per tile, the l / r tile through LDS
+// for all four waves.  Here a wave owns 16 rows for BOTH products:
+//   L = Theta . Phi'   exactly as in gibbs_rowwave_kernel (Theta in LDS, B operand built on the fly);
+//   softmax over the lane's contiguous quarter of the components in registers;
+//   the wave's r values go to a wave-private LDS block Rt[row][slot] (slot = 16 rb + 4 r + q: the A-operand order of
+//   the second product), then  S += R . Phi :  A = Rt[row 4t + kk][16 rb + i], B = Phi[row 4t + kk][16 cb + j] built
+//   on the fly from the same z rows; the wave keeps its OWN K x F16 statistic block in registers (KB NCB accumulator
+//   quads: 96 VGPRs at K = 64, Dz = 8) across all its steps.  No workgroup barrier in the loop.
+// At the end the 8 waves of the workgroup add their blocks through LDS in wave order, one accumulator quad at a time.
+// S-row i of row block rb holds component (i & 3) V + 4 rb + (i >> 2) (the permutation of the operand image).
+// ------------------------------------------------------------------------------------------
+template <int KB, int NS4>
+__global__ __launch_bounds__(kRowWaveWG, 1) void vi_rowwave_kernel(const KernelArgs a) {
+  constexpr int V = 4 * KB, NS = 4 * NS4, NCB = NS4;
+  constexpr int RS2 = 16 * KB + 8;                    // row stride of the wave's r block (doubles)
+  static_assert(KB == 2 || KB == 4, "K <= 64");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int ZS = a.ZS;
+  double* Th = reinterpret_cast<double*>(smem);       // [(NS KB + 4)][64]
+  double* etab = Th + (size_t)(NS * KB + 4) * 64;     // [kExpTab]
+  double* Zall = etab + kExpTab;                      // [8][16][ZS]
+  double* Rall = Zall + (size_t)(kRowWaveWG / 64) * 16 * ZS;   // [8][16][RS2]
+  double* sred = Rall + (size_t)(kRowWaveWG / 64) * 16 * RS2;  // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int D = a.D, K = a.K;
+  const int64_t N = a.N;
+  double* Zw = Zall + (size_t)wave * 16 * ZS;
+  double* Rt = Rall + (size_t)wave * 16 * RS2;
+
+  for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
+  for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  wg_sync();
+
+  const int64_t nsteps = (N + 15) / 16;
+  const int64_t nwaves = (int64_t)gridDim.x * (kRowWaveWG / 64), wv = (int64_t)blockIdx.x * (kRowWaveWG / 64) + wave;
+  int zoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = lane + 64 * i, r = e / D;
+    zoff[i] = e < 16 * D ? r * ZS + (e - r * D) : -1;
+  }
+  double zr[3];
+  auto load_z = [&](int64_t t) {
+    const int64_t base = t * 16 * D, total = N * D;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t gidx = base + lane + 64 * i;
+      zr[i] = (zoff[i] >= 0 && gidx < total) ? a.Z[gidx] : 0.0;
+    }
+  };
+  if (wv < nsteps) load_z(wv);
+
+  const double* zrow = Zw + j * ZS;
+  const double* thl = Th + lane;
+  constexpr bool kPacked = KB == 4 && NS > 12;        // (K > 32 at Dz = 9: the two offsets of a step share a register)
+  const double* fpa[kPacked ? 1 : NS];
+  const double* fpb[kPacked ? 1 : NS];
+  uint32_t fo[kPacked ? NS : 1];
+#pragma unroll
+  for (int s2 = 0; s2 < NS; ++s2) {
+    if constexpr (kPacked) {
+      fo[s2] = 8u * a.feat[2 * (4 * s2 + q)] | (8u * a.feat[2 * (4 * s2 + q) + 1]) << 16;
+    } else {
+      fpa[s2] = zrow + a.feat[2 * (4 * s2 + q)];
+      fpb[s2] = zrow + a.feat[2 * (4 * s2 + q) + 1];
+    }
+  }
+  auto feature = [&](int s2) -> double {
+    if constexpr (kPacked) {
+      const char* zb = reinterpret_cast<const char*>(zrow);
+      return *reinterpret_cast<const double*>(zb + (fo[s2] & 0xffffu)) * *reinterpret_cast<const double*>(zb + (fo[s2] >> 16));
+    } else {
+      return *fpa[s2] * *fpb[s2];
+    }
+  };
+  // second product: lane (kk = q, col j) builds feature 16 cb + j of row 4 t + kk; A operand = Rt[4 t + kk][16 rb + i], i = j
+  const double* zk = Zw + q * ZS;                     // row kk of the step's block; row 4 t + kk is 4 t ZS doubles further
+  int spa[NCB], spb[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    spa[cb] = a.feat[2 * (16 * cb + j)];
+    spb[cb] = a.feat[2 * (16 * cb + j) + 1];
+  }
+  const double* rk = Rt + q * RS2 + j;
+  double* rw = Rt + j * RS2 + q;                      // this lane's r values: slot 16 rb + 4 r + q of row j
+
+  d4 sacc[KB][NCB];
+#pragma unroll
+  for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) sacc[rb][cb] = d4{0.0, 0.0, 0.0, 0.0};
+  double sc_lse = 0.0, sc_prod = 1.0;
+  int since_flush = 0;
+
+  for (int64_t t = wv; t < nsteps; t += nwaves) {
+    const int64_t n = t * 16 + j;
+    const bool valid = n < N;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (zoff[i] >= 0) Zw[zoff[i]] = zr[i];
+    if (q == 0) {
+      Zw[j * ZS + D] = valid ? 1.0 : 0.0;     // rows past N: every feature 0 — l = 0, and nothing reaches the statistics
+      Zw[j * ZS + D + 1] = 0.0;
+    }
+    if (t + nwaves < nsteps) load_z(t + nwaves);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- L = Theta . Phi' ------------------------------------------------------------------------
+    d4 acc[KB];
+#pragma unroll
+    for (int rb = 0; rb < KB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
+    {
+      constexpr int PF = 4;
+      double ring[PF];
+#pragma unroll
+      for (int e = 0; e < PF; ++e) ring[e] = thl[e * 64];
+      double bq = feature(0);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const double bcur = bq;
+        if (s2 + 1 < NS) bq = feature(s2 + 1);
+#pragma unroll
+        for (int rb = 0; rb < KB; ++rb) {
+          const int e = s2 * KB + rb;
+          const double av = ring[e % PF];
+          ring[e % PF] = thl[(e + PF) * 64];
+          acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- softmax over the row's components (this lane: components q V .. q V + V - 1) ------------------
+    __builtin_amdgcn_s_setprio(2);
+    double m;
+    {
+      double mv[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+#pragma unroll
+      for (int rb = 1; rb < KB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = fmax(mv[r], acc[rb][r]);
+      m = fmax(fmax(mv[0], mv[1]), fmax(mv[2], mv[3]));
+      m = fmax(m, __shfl_xor(m, 16));
+      m = fmax(m, __shfl_xor(m, 32));
+    }
+    double sv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[rb][r] = exp_nonpos_t2048(acc[rb][r] - m, etab);
+        sv[r] += acc[rb][r];
+      }
+    double ssum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+    ssum += __shfl_xor(ssum, 16);
+    ssum += __shfl_xor(ssum, 32);
+    double inv = __builtin_amdgcn_rcp(ssum);
+    inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+    inv = fma(fma(-ssum, inv, 1.0), inv, inv);
+    if (q == 0 && valid) { sc_lse += m; sc_prod *= ssum; }
+    // (rows past N need no masking of r: all their features are 0, they add nothing to S)
+#pragma unroll
+    for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rw[16 * rb + 4 * r] = acc[rb][r] * inv;
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- S += R . Phi: four rows per MFMA step -------------------------------------------------------
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const double* zt = zk + (size_t)(4 * t4) * ZS;
+      double bv[NCB], av[KB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[cb] = zt[spa[cb]] * zt[spb[cb]];
+#pragma unroll
+      for (int rb = 0; rb < KB; ++rb) av[rb] = rk[4 * t4 * RS2 + 16 * rb];
+#pragma unroll
+      for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          sacc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rb], bv[cb], sacc[rb][cb], 0, 0, 0);
+    }
+    if (++since_flush == 64) {         // K^64 <= 64^64 = 2^384 stays inside the float64 range
+      sc_lse += log(sc_prod);
+      sc_prod = 1.0;
+      since_flush = 0;
+    }
+  }
+
+  // ---- per-workgroup partial block: the eight waves' blocks added in wave order, one accumulator quad at a time ----
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride;
+  double* red = Th;                                    // [8 waves][4][64] per quad: 16 KB of the (now idle) operand image
+#pragma unroll
+  for (int rb = 0; rb < KB; ++rb) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      wg_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = sacc[rb][cb][r];
+      wg_sync();
+      if (wave < 4) {                                  // wave r adds register r of the eight waves
+        double s2 = red[(0 * 4 + wave) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kRowWaveWG / 64; ++w) s2 += red[(w * 4 + wave) * 64 + lane];
+        const int i = q + 4 * wave;                    // S-row of register `wave` in lane (q, j)
+        const int k = (i & 3) * V + 4 * rb + (i >> 2);
+        if (k < a.K16 * 16) P[(size_t)k * FT + 16 * cb + j] = k < K ? s2 : 0.0;
+      }
+    }
+  }
+  sc_lse += log(sc_prod);
+  sc_lse = wave_sum(sc_lse);
+  wg_sync();
+  if (lane == 0) sred[wave] = sc_lse;
+  wg_sync();
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = P + (size_t)a.K16 * 16 * FT;
+    double s2 = 0.0;
+    for (int w = 0; w < kRowWaveWG / 64; ++w) s2 += sred[w];
+    Ps[0] = s2; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
+  }
+}
+
+size_t vi_rowwave_lds_bytes(int KB, int NS, int ZS) {
+  return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + kExpTab + (size_t)(kRowWaveWG / 64) * 16 * (ZS + 16 * KB + 8) + 8);
+}
+
+// K <= 64, Dz <= 9 (F16 <= 64), from the same K as the label route
+bool vi_rowwave_covers(int K, int F16, int ZS) {
+  static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE_VI"); return !e || atoi(e) != 0; }();   // tuning knob
+  if (!on || K < rowwave_min_k() || K > 64 || F16 > 64) return false;
+  if (K > 32 && F16 > 48) return false;       // Dz = 9 with four row blocks: 128 + 32 accumulator registers spill (136 B)
+  // measured against the tile kernels (tools/vi_route_time.py, N = 1e7, pass kernels): K <= 32 wins (D = 8: K = 32 1.87 -> 1.37 ms,
+  // K = 24 1.80 -> 1.38, K = 16 1.39 -> 1.33; D = 5, K = 32 1.39 -> 1.03; D = 3, K = 24 1.04 -> 0.75) except Dz = 9 at K <= 16
+  // (1.47 -> 1.58); 33 <= K <= 48 pays for 64 component slots (D = 7, K = 33: 2.07 -> 2.33); 49 <= K <= 64 wins a little at
+  // Dz = 5 .. 8 (D = 8: 2.53 -> 2.41) and loses at Dz <= 4 (D = 1: 1.18 -> 1.32)
+  if (K <= 32) { if (F16 == 64 && K <= 16) return false; }
+  else if (K < 49 || F16 < 32) return false;
+  return vi_rowwave_lds_bytes(K <= 32 ? 2 : 4, F16 / 4, ZS) <= 160 * 1024;
+}
+
+hipError_t launch_vi_rowwave(const KernelArgs& a, int grid, hipStream_t stream) {
+  typedef void (*fn_t)(const KernelArgs);
+  static const fn_t t2[4] = {vi_rowwave_kernel<2, 1>, vi_rowwave_kernel<2, 2>, vi_rowwave_kernel<2, 3>, vi_rowwave_kernel<2, 4>};
+  static const fn_t t4[4] = {vi_rowwave_kernel<4, 1>, vi_rowwave_kernel<4, 2>, vi_rowwave_kernel<4, 3>, vi_rowwave_kernel<4, 4>};
+  const int kb = a.K <= 32 ? 2 : 4, ns4 = a.F16 / 16;
+  if (ns4 < 1 || ns4 > 4 || a.K > 64) return hipErrorInvalidValue;
+  fn_t fn = kb == 2 ? t2[ns4 - 1] : t4[ns4 - 1];
+  const size_t lds = vi_rowwave_lds_bytes(kb, a.F16 / 4, a.ZS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kRowWaveWG), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Statistics of hard labels, K <= 256, Dz <= 9, full feature map.  Workgroup = 256 threads; with Kp = the power of two
 // >= K, thread t works for component t % Kp as part t / Kp of P = 256 / Kp: it takes every P-th row of that component's
 // list (K > 128: one thread per component; K = 32: eight threads share a component, so all four waves accumulate).

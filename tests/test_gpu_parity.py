@@ -813,3 +813,40 @@ def test_row_weights_stay_resident(engine):
     check(w)
     engine.upload(Z[:20000]); engine.upload(Z)
     check(w)
+
+
+@pytest.mark.parametrize("D,K", [(8, 64), (8, 49), (8, 32), (8, 17), (8, 16), (8, 3), (5, 64), (5, 7), (7, 50), (9, 32), (9, 20),
+                                 (6, 1), (3, 24), (4, 20), (2, 33), (1, 33)])
+@pytest.mark.parametrize("N", [1, 17, 5003, 8 * 256 * 16 * 2 + 11])
+def test_row_owner_softmax_pass(engine, D, K, N):
+    """vi_rowwave_kernel (K <= 64, Dz <= 9: both matrix products on row-owner waves, r through a wave-private LDS block):
+    statistics and sum_n lse_n against the oracle, identical bits on a second launch, asynchronous form; the generic
+    requests (tables, entropy split, row weights) of the same shape still go through the tile kernels and agree."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(4000 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K)["kind"] == ("rowwave-vi" if (D, K) not in ((2, 33), (1, 33)) else "fused")
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    S, sc = engine.estep(c, b, W)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    S1, sc1 = engine.estep(c, b, W)
+    assert np.array_equal(S1.sxx, S.sxx) and np.array_equal(S1.sx, S.sx) and np.array_equal(S1.n, S.n) and sc1[0] == sc[0]
+    engine.estep_async(c, b, W)
+    S2, sc2 = engine.estep_wait()
+    assert np.array_equal(S2.sxx, S.sxx) and sc2[0] == sc[0]
+    if N <= 6000:
+        Sg, scg = engine.estep(c, b, W, keep_resp=True, entropy_split=True)
+        assert rel_err(Sg.sxx, sxx) < 1e-11 and rel_err(engine.get_resp(), R) < 1e-11 and abs(scg[0] - sc[0]) < 1e-11 * max(1., abs(sc[0]))
+        c2 = c.copy(); c2[K // 2] = -np.inf                          # a switched-off component
+        if K > 1:
+            L2 = L.copy(); L2[K // 2] = -np.inf
+            lse2 = logsumexp(L2, axis=0)
+            n2, _, sxx2 = O.packed_stats(Z, np.exp(L2 - lse2))
+            So, sco = engine.estep(c2, b, W)
+            assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * max(1., abs(lse2.sum()))
