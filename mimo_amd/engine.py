@@ -541,9 +541,15 @@ def content_fingerprint(Z):
     Z = np.asarray(Z)
     if Z.nbytes <= _FULL_HASH_BYTES:
         return zlib.crc32(np.ascontiguousarray(Z).view(np.uint8).reshape(-1))
-    flat = Z.reshape(-1) if Z.flags.c_contiguous else Z.ravel()
-    step = max(1, flat.shape[0] // _SAMPLE_ELEMS)
-    h = zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8))
+    if Z.flags.c_contiguous:
+        flat = Z.reshape(-1)
+        step = max(1, flat.shape[0] // _SAMPLE_ELEMS)
+        h = zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8))
+    else:           # a strided view (a column block of a wider matrix): whole rows at even spacing, never a full copy
+        n = Z.shape[0]
+        per_row = max(1, int(np.prod(Z.shape[1:])))
+        idx = np.unique(np.linspace(0, n - 1, num=min(n, max(2, _SAMPLE_ELEMS // per_row))).astype(np.int64))
+        h = zlib.crc32(np.ascontiguousarray(Z[idx]).view(np.uint8).reshape(-1))
     h = zlib.crc32(np.ascontiguousarray(Z[0]).view(np.uint8).reshape(-1), h)
     return zlib.crc32(np.ascontiguousarray(Z[-1]).view(np.uint8).reshape(-1), h)
 
