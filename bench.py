@@ -293,10 +293,13 @@ def main():
                 torch.cuda.synchronize()
 
     def prof(on):
+        """(total kernel ms, passes, per-kernel breakdown) since the last call; resets the counters."""
         if hasattr(hip, "profile"):
             hip.profile(on)
-            return hip.profile_read(reset=True)
-        return 0.0, 0
+            kin = hip.profile_kernels() if hasattr(hip, "profile_kernels") else {}
+            ms, n = hip.profile_read(reset=True)
+            return ms, n, kin
+        return 0.0, 0, {}
 
     vlb = []
     for it in range(args.warmup):
@@ -309,8 +312,9 @@ def main():
         vlb.append(v)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = prof(True)
-    kinfo = hip.profile_kernels() if hasattr(hip, "profile_kernels") else {}
+    kernel_ms, launches, kinfo = prof(True)
+    kinfo = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches_per_step": v["launches"] / max(args.steps, 1)}
+             for k, v in kinfo.items()}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
