@@ -299,9 +299,9 @@ static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, c
 // (+ their statistics) requested.
 static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
   static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE"); return !e || atoi(e) != 0; }();   // tuning knob
-  if (!on || wants_tables || ctx->structure != MIMO_STRUCT_FULL) return false;
+  if (!on || wants_tables || ctx->D > 16) return false;       // (16 rows x Dz <= 256 elements per wave step)
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
-  return rowwave_covers(K, ctx->F16, ZS) && label_stats_covers(K, ctx->D);
+  return rowwave_covers(K, ctx->F16, ZS) && label_stats_covers(K, ctx->D, ctx->structure);
 }
 
 // Theta image of the row-owner label kernel: [NS][KB][64]; component k sits in A-row (k / V) + 4 (k % 4) of row block
@@ -325,15 +325,25 @@ static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b,
     const double* bk = b + (size_t)k * D;
     const double* Wk = W + (size_t)k * D * D;
     if (c[k] != c[k] || c[k] > 1.7976931348623157e308) return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
-    put(k, feat_index(D, D, D), c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
+    put(k, fidx(ctx, D, D), c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
+    for (int a = 0; a < D; ++a) put(k, fidx(ctx, a, D), bk[a]);
+    if (ctx->structure == MIMO_STRUCT_LINEAR) {       // the shared quadratic term stays with the caller (mimo_set_structure)
+      if (k > 0 && memcmp(Wk, W, sizeof(double) * D * D) != 0)
+        return fail(ctx, MIMO_E_INVALID, "linear structure is set (mimo_set_structure) but W[%d] differs from W[0]", k);
+      continue;
+    }
     for (int a = 0; a < D; ++a) {
-      put(k, feat_index(D, a, D), bk[a]);
-      put(k, feat_index(D, a, a), -0.5 * Wk[a * D + a]);
-      for (int bb = a + 1; bb < D; ++bb) put(k, feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+      put(k, fidx(ctx, a, a), -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) {
+        if (ctx->structure == MIMO_STRUCT_FULL) put(k, feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+        else if (Wk[a * D + bb] != 0.0 || Wk[bb * D + a] != 0.0)
+          return fail(ctx, MIMO_E_INVALID, "diagonal structure is set (mimo_set_structure) but W[%d] has the "
+                      "off-diagonal entry (%d,%d)", k, a, bb);
+      }
     }
   }
   if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
-  for (int k = K; k < 16 * KB; ++k) put(k, feat_index(D, D, D), kPadLogDensity);
+  for (int k = K; k < 16 * KB; ++k) put(k, fidx(ctx, D, D), kPadLogDensity);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MIMO_OK;
 }
@@ -442,7 +452,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
-  const bool lstats = !small && ((src == kSrcLabels && ctx->structure == MIMO_STRUCT_FULL && label_stats_covers(K, D)) || rowwave);
+  const bool lstats = !small && ((src == kSrcLabels && D <= 16 && label_stats_covers(K, D, ctx->structure)) || rowwave);
   const int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
                    : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
@@ -470,7 +480,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
     }
     if (a.do_stats) {
       rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
-        HIP_TRY(ctx, launch_label_stats(a, grid, ctx->stream));
+        HIP_TRY(ctx, launch_label_stats(a, ctx->structure, grid, ctx->stream));
         return MIMO_OK;
       });
       if (rc) return rc;
@@ -813,8 +823,7 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
   const bool rv = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) &&
-                  ctx->n_bad == 0 && ctx->structure == MIMO_STRUCT_FULL && !use_small(ctx, K) &&
-                  vi_rowwave_covers(K, ctx->F16, a.ZS);
+                  ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
   if ((rc = rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
@@ -1269,7 +1278,7 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   if (use_small(ctx, K)) {
     out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
     out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
-  } else if (!gibbs && ctx->n_bad == 0 && ctx->structure == MIMO_STRUCT_FULL && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
+  } else if (!gibbs && ctx->n_bad == 0 && ctx->D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     out8[6] = rowwave_grid(a, ctx->num_cu);
   } else if (gibbs && use_rowwave(ctx, K, false)) {

@@ -98,9 +98,9 @@ int rowwave_kb(int K);
 bool rowwave_covers(int K, int F16, int ZS);
 int rowwave_grid(const KernelArgs& a, int num_cu);
 hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
-bool label_stats_covers(int K, int D);
+bool label_stats_covers(int K, int D, int structure);
 int label_stats_grid(const KernelArgs& a, int num_cu);
-hipError_t launch_label_stats(const KernelArgs& a, int grid, hipStream_t stream);
+hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipStream_t stream);
 
 hipError_t launch_table_entropy(const double* table, int64_t count, double* partials, int nblocks,
                                 double* out, hipStream_t stream);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   wg_sync();
 
   // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < ZI (16 D <= 144 up to Dz = 9, <= 256 up to 16)
-  constexpr int ZI = NS4 <= 4 ? 3 : 4;
+  constexpr int ZI = 4;     // (16 Dz <= 256: Dz <= 16 — full maps beyond Dz = 9 and the reduced maps of structured blocks)
   const int64_t nsteps = (N + 15) / 16;
   const int64_t nwaves = (int64_t)gridDim.x * (kRowWaveWG / 64), wv = (int64_t)blockIdx.x * (kRowWaveWG / 64) + wave;
   int zoff[ZI];
@@ -361,17 +361,18 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void vi_rowwave_kernel(const KernelA
 
   const int64_t nsteps = (N + 15) / 16;
   const int64_t nwaves = (int64_t)gridDim.x * (kRowWaveWG / 64), wv = (int64_t)blockIdx.x * (kRowWaveWG / 64) + wave;
-  int zoff[3];
+  constexpr int ZI = 4;      // 16 Dz <= 256 elements per step (Dz <= 16: the reduced feature maps of structured blocks)
+  int zoff[ZI];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < ZI; ++i) {
     const int e = lane + 64 * i, r = e / D;
     zoff[i] = e < 16 * D ? r * ZS + (e - r * D) : -1;
   }
-  double zr[3];
+  double zr[ZI];
   auto load_z = [&](int64_t t) {
     const int64_t base = t * 16 * D, total = N * D;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < ZI; ++i) {
       const int64_t gidx = base + lane + 64 * i;
       zr[i] = (zoff[i] >= 0 && gidx < total) ? a.Z[gidx] : 0.0;
     }
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void vi_rowwave_kernel(const KernelA
     const int64_t n = t * 16 + j;
     const bool valid = n < N;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < ZI; ++i)
       if (zoff[i] >= 0) Zw[zoff[i]] = zr[i];
     if (q == 0) {
       Zw[j * ZS + D] = valid ? 1.0 : 0.0;     // rows past N: every feature 0 — l = 0, and nothing reaches the statistics
@@ -594,12 +595,16 @@ hipError_t launch_vi_rowwave(const KernelArgs& a, int grid, hipStream_t stream) 
 // thread k adds its rows in ascending row order.  Partial block per workgroup in the tile kernels' layout.
 // ------------------------------------------------------------------------------------------
 constexpr int kLsTile = 512;
+constexpr int kLsWideTile = 256;     // tile of the Dz > 10 variants (their z tile is wider)
 
-template <int DZ>
+// FS: feature set — 0: full map (n, sum z, upper triangle of sum z z'), 1: diagonal structure (sum z_a^2, sum z_a, n in the
+// order of diag_feat_index), 2: linear structure (sum z_a, n): the reduced maps of mimo_set_structure, Dz <= 16.
+template <int DZ, int FS = 0>
 __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a) {
-  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
-  constexpr int ZS = DZ <= 2 ? 2 : DZ <= 6 ? 6 : 10;   // 16-byte aligned rows, odd stride in 16-byte units (random rows: no systematic bank conflicts)
-  constexpr int T = kLsTile, NW = T / 32;           // bitmap words per component
+  constexpr int F = FS == 0 ? (DZ + 1) * (DZ + 2) / 2 : FS == 1 ? 2 * DZ + 1 : DZ + 1;
+  constexpr int ZS = DZ <= 2 ? 2 : DZ <= 6 ? 6 : DZ <= 10 ? 10 : DZ <= 14 ? 14 : 18;   // 16-byte aligned rows, odd stride in 16-byte units (random rows: no systematic bank conflicts)
+  constexpr int T = DZ <= 10 ? kLsTile : kLsWideTile, NW = T / 32;           // rows per tile, bitmap words per component
+  constexpr int RPT = T / kWG;                       // rows per thread and tile
   constexpr int ZPT = (T * DZ + kWG - 1) / kWG;     // z elements per thread
   __shared__ __align__(16) double Zt[T * ZS];
   __shared__ __align__(16) uint32_t bitmap[kWG * NW];   // [k][word] — k-major so that thread k reads 16 consecutive words
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   for (int f = 0; f < F; ++f) acc[f] = 0.0;
 
   double zr[ZPT];
-  int lab[2];
+  int lab[2] = {-1, -1};
   auto load_tile = [&](int64_t t) {
     const int64_t base = t * T * DZ, total = N * DZ;
 #pragma unroll
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
       zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < RPT; ++h) {
       const int64_t n = t * T + tid + kWG * h;
       const int l = n < N ? a.labels[n] : -1;
       lab[h] = l < K ? l : -1;            // a label outside [0, K) (a caller's vector) is skipped, never an index
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
     wg_sync();
     if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
-    if (l1 >= 0) atomicOr(&bitmap[l1 * NW + ((tid + kWG) >> 5)], 1u << (tid & 31));
+    if (RPT > 1 && l1 >= 0) atomicOr(&bitmap[l1 * NW + ((tid + kWG) >> 5)], 1u << (tid & 31));
     wg_sync();
     // rows of component tid, and the exclusive prefix over the components (where its list starts)
     int cntk = 0;
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
       list[start[l] + rank] = (uint16_t)row;
     };
     place(l0, tid);
-    place(l1, tid + kWG);
+    if (RPT > 1) place(l1, tid + kWG);
     wg_sync();
     // thread (component myk, part mypart): every P-th row of the component's list, ascending
     const int st = start[myk], cmine = cnts[myk];
@@ -700,12 +705,20 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
       double z[DZ];
 #pragma unroll
       for (int d = 0; d < DZ; ++d) z[d] = zp[d];
-      int f = 0;
+      if constexpr (FS == 0) {
+        int f = 0;
 #pragma unroll
-      for (int i = 0; i < DZ; ++i) {
+        for (int i = 0; i < DZ; ++i) {
 #pragma unroll
-        for (int jx = i; jx < DZ; ++jx) { acc[f] = fma(z[i], z[jx], acc[f]); ++f; }
-        acc[f] += z[i]; ++f;
+          for (int jx = i; jx < DZ; ++jx) { acc[f] = fma(z[i], z[jx], acc[f]); ++f; }
+          acc[f] += z[i]; ++f;
+        }
+      } else if constexpr (FS == 1) {
+#pragma unroll
+        for (int i = 0; i < DZ; ++i) { acc[i] = fma(z[i], z[i], acc[i]); acc[DZ + i] += z[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < DZ; ++i) acc[i] += z[i];
       }
       acc[F - 1] += 1.0;
     }
@@ -717,8 +730,9 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   double* P_out = a.partials + (size_t)blockIdx.x * pstride;
   if (P > 1) {
     // add the parts of every component in part order, eight features at a time through LDS
-    double* red = reinterpret_cast<double*>(bitmap);   // [kWG][8]  (the bitmap is free now)
-    static_assert(sizeof(uint32_t) * kWG * NW >= sizeof(double) * kWG * 8, "reduction scratch fits the bitmap");
+    static_assert(sizeof(double) * T * ZS >= sizeof(double) * kWG * 8 || sizeof(uint32_t) * kWG * NW >= sizeof(double) * kWG * 8,
+                  "reduction scratch fits the bitmap or the z tile");
+    double* red = sizeof(uint32_t) * kWG * NW >= sizeof(double) * kWG * 8 ? reinterpret_cast<double*>(bitmap) : Zt;   // [kWG][8]
 #pragma unroll
     for (int f0 = 0; f0 < F; f0 += 8) {
       wg_sync();
@@ -758,7 +772,6 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
 // (sum z_i z_j for j >= i, and sum z_i; slice 0 also the count) — and, if threads are left (Kp < 256 / FP), the rows of
 // the component's list as in label_stats_kernel.  FP = 4 for K <= 64, 2 for K <= 128 (Dz <= 12).  Tiles of 256 rows.
 // ------------------------------------------------------------------------------------------
-constexpr int kLsWideTile = 256;
 constexpr int slice_count(int DZ, int FP, int S) {
   int n = S == 0 ? 1 : 0;
   for (int i = S; i < DZ; i += FP) n += DZ - i + 1;
@@ -941,35 +954,56 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
   }
 }
 
-bool label_stats_covers(int K, int D) {
+bool label_stats_covers(int K, int D, int structure) {
   if (K < rowwave_min_k() || K > 256 || D < 1 || D > 16) return false;
-  if (D <= 9) return true;
+  if (D <= 9 || structure != 0) return true;     // reduced maps (diagonal / linear): at most 2 Dz + 1 accumulators
   return K <= 64 || (K <= 128 && D <= 12);      // wide kernel: 4 feature slices up to K = 64, 2 up to K = 128 (Dz <= 12)
 }
 
 int label_stats_grid(const KernelArgs& a, int num_cu) {
-  const int tile = a.D <= 9 ? kLsTile : kLsWideTile;
+  const int tile = a.D <= (a.diag ? 10 : 9) ? kLsTile : kLsWideTile;
   const int64_t tiles = (a.N + tile - 1) / tile;
   int64_t g = (int64_t)num_cu * 2;
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
 }
 
-hipError_t launch_label_stats(const KernelArgs& a, int grid, hipStream_t stream) {
-  typedef void (*fn_t)(const KernelArgs);
-  static const fn_t table[9] = {label_stats_kernel<1>, label_stats_kernel<2>, label_stats_kernel<3>, label_stats_kernel<4>,
-                                label_stats_kernel<5>, label_stats_kernel<6>, label_stats_kernel<7>, label_stats_kernel<8>,
-                                label_stats_kernel<9>};
-  if (a.D < 1 || a.D > 16) return hipErrorInvalidValue;
-  if (a.D <= 9) {
-    hipLaunchKernelGGL(table[a.D - 1], dim3(grid), dim3(kWG), 0, stream, a);
-    return hipGetLastError();
+template <int FS>
+static void (*pick_label_stats_struct(int D))(const KernelArgs) {
+  switch (D) {
+    case 1: return label_stats_kernel<1, FS>;   case 2: return label_stats_kernel<2, FS>;
+    case 3: return label_stats_kernel<3, FS>;   case 4: return label_stats_kernel<4, FS>;
+    case 5: return label_stats_kernel<5, FS>;   case 6: return label_stats_kernel<6, FS>;
+    case 7: return label_stats_kernel<7, FS>;   case 8: return label_stats_kernel<8, FS>;
+    case 9: return label_stats_kernel<9, FS>;
+    default: break;
   }
-  static const fn_t wide4[7] = {label_stats_wide_kernel<10, 4>, label_stats_wide_kernel<11, 4>, label_stats_wide_kernel<12, 4>,
-                                label_stats_wide_kernel<13, 4>, label_stats_wide_kernel<14, 4>, label_stats_wide_kernel<15, 4>,
-                                label_stats_wide_kernel<16, 4>};
-  static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
-  fn_t fn = a.K <= 64 ? wide4[a.D - 10] : (a.K <= 128 && a.D <= 12) ? wide2[a.D - 10] : nullptr;
+  if constexpr (FS != 0) {          // the reduced maps reach Dz = 16 with one thread per component (the full map: wide kernel)
+    switch (D) {
+      case 10: return label_stats_kernel<10, FS>; case 11: return label_stats_kernel<11, FS>;
+      case 12: return label_stats_kernel<12, FS>; case 13: return label_stats_kernel<13, FS>;
+      case 14: return label_stats_kernel<14, FS>; case 15: return label_stats_kernel<15, FS>;
+      case 16: return label_stats_kernel<16, FS>;
+    }
+  }
+  return nullptr;
+}
+
+// structure: 0 full, 1 diagonal, 2 linear (MIMO_STRUCT_*)
+hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipStream_t stream) {
+  typedef void (*fn_t)(const KernelArgs);
+  if (a.D < 1 || a.D > 16) return hipErrorInvalidValue;
+  fn_t fn = nullptr;
+  if (structure == 1) fn = pick_label_stats_struct<1>(a.D);
+  else if (structure == 2) fn = pick_label_stats_struct<2>(a.D);
+  else if (a.D <= 9) fn = pick_label_stats_struct<0>(a.D);
+  else {
+    static const fn_t wide4[7] = {label_stats_wide_kernel<10, 4>, label_stats_wide_kernel<11, 4>, label_stats_wide_kernel<12, 4>,
+                                  label_stats_wide_kernel<13, 4>, label_stats_wide_kernel<14, 4>, label_stats_wide_kernel<15, 4>,
+                                  label_stats_wide_kernel<16, 4>};
+    static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
+    fn = a.K <= 64 ? wide4[a.D - 10] : (a.K <= 128 && a.D <= 12) ? wide2[a.D - 10] : nullptr;
+  }
   if (!fn) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);
   return hipGetLastError();
