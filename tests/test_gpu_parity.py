@@ -348,6 +348,7 @@ def test_sharded_device_route_over_one_rank_rccl(engine, native, monkeypatch):
     N, D, K = 50000, 16, 64
     Z, c, b, Wf = _random_problem(rng, N, D, K)
     Wt = np.ascontiguousarray(np.broadcast_to(Wf[:1], Wf.shape))
+    Z8, c8, b8, W8 = _random_problem(rng, 30011, 8, 32)           # a shape of the row-owner kernels (softmax and label pass)
     engine.upload(Z)
     created = not dist.is_initialized()
     if created:
@@ -381,6 +382,17 @@ def test_sharded_device_route_over_one_rank_rccl(engine, native, monkeypatch):
             finally:
                 engine.set_structure('full')
                 sh.set_structure('full')
+        engine.upload(Z8); sh.upload(Z8)
+        assert engine.plan(32)["kind"] == "rowwave-vi" and engine.plan(32, gibbs=True)["kind"] == "rowwave"
+        S0, sc0 = engine.estep(c8, b8, W8)
+        S1, sc1 = sh.estep(c8, b8, W8)
+        sh.estep_async(c8, b8, W8)
+        S2, sc2 = sh.estep_wait()
+        for S, sc in ((S1, sc1), (S2, sc2)):
+            assert np.array_equal(S.n, S0.n) and np.array_equal(S.sxx, S0.sxx) and sc[0] == sc0[0]
+        _, G0 = engine.gibbs_labels(c8, b8, W8, seed=5, sweep=2, return_labels=False)
+        _, G1 = sh.gibbs_labels(c8, b8, W8, seed=5, sweep=2, return_labels=False)
+        assert np.array_equal(G0.n, G1.n) and np.array_equal(G0.sxx, G1.sxx)
         sh.inner.close()
     finally:
         if created:
@@ -850,3 +862,16 @@ def test_row_owner_softmax_pass(engine, D, K, N):
             n2, _, sxx2 = O.packed_stats(Z, np.exp(L2 - lse2))
             So, sco = engine.estep(c2, b, W)
             assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * max(1., abs(lse2.sum()))
+
+
+def test_empty_data_on_the_row_owner_kernels(engine):
+    """N = 0 through the row-owner routes: zero statistics, no labels, no launch that reads a row."""
+    rng = np.random.default_rng(1)
+    for D, K in ((8, 32), (8, 200), (12, 40)):
+        Z, c, b, W = _random_problem(rng, 0, D, K)
+        engine.upload(Z)
+        S, sc = engine.estep(c, b, W)
+        assert not S.n.any() and not S.sxx.any() and sc[0] == 0.0
+        lab, G = engine.gibbs_labels(c, b, W, seed=1, sweep=1)
+        assert lab.shape == (0,) and not G.n.any() and not G.sxx.any()
+        assert not engine.label_stats(np.zeros(0, dtype=np.int32), K).n.any()
