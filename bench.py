@@ -189,22 +189,6 @@ def self_launch(args, argv):
     raise SystemExit(0)
 
 
-def shader_clock_mhz(device_index):
-    """Current shader clock from sysfs (the '*' line of pp_dpm_sclk), or None."""
-    try:
-        import glob
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if not cards:
-            return None
-        with open(cards[min(device_index, len(cards) - 1)]) as f:
-            for ln in f:
-                if "*" in ln:
-                    return float(ln.split(":")[1].strip().split("M")[0])
-    except Exception:
-        pass
-    return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,7 +309,6 @@ def main():
     if not args.no_sustained and not dry and dist is None:
         # the same step for >= 3 s after the timed steps: a 20-launch burst says nothing about sustained FP64 clocks
         ts, t_end, it = [], time.perf_counter() + 3.0, args.warmup + args.steps
-        clk0 = shader_clock_mhz(local_rank)
         while time.perf_counter() < t_end or len(ts) < 5:
             torch.cuda.synchronize()
             a = time.perf_counter()
@@ -335,7 +318,8 @@ def main():
             it += 1
         sustained = {"seconds": float(np.sum(ts)) / 1e3, "steps": len(ts), "ms_per_step_median": float(np.median(ts)),
                      "ms_per_step_min": float(np.min(ts)), "ms_per_step_last10_median": float(np.median(ts[-10:])),
-                     "shader_clock_mhz_before_after": [clk0, shader_clock_mhz(local_rank)]}
+                     # in-kernel counters (s_memtime / s_memrealtime) of a short float64 loop right after the leg
+                     "shader_clock_mhz_under_f64_load": hip.shader_clock_mhz() if hasattr(hip, "shader_clock_mhz") else None}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

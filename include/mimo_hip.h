@@ -328,6 +328,11 @@ double mimo_philox_uniform(uint64_t seed, uint64_t row, uint64_t sweep);
 int mimo_profile(mimo_ctx* ctx, int enable);
 int mimo_profile_read(mimo_ctx* ctx, double* kernel_ms, int64_t* launches, int reset);
 
+/* Median shader clock (MHz) of a short float64 VALU loop on every SIMD, from the in-kernel counters (s_memtime against the
+ * constant 100 MHz s_memrealtime): what the device runs at under this kind of load, right now.  bench.py reports it after
+ * its sustained leg. */
+int mimo_shader_clock_mhz(mimo_ctx* ctx, double* mhz);
+
 /* Per-kernel breakdown of the same measurement: one text line "name<TAB>total_ms<TAB>launches" per kernel of the
  * passes since the last reset (mimo_profile_read with reset = 1 clears it). */
 int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);

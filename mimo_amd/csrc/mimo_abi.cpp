@@ -6,6 +6,7 @@
 #include "mimo_kernels.h"
 #include "mimo_extra.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1173,6 +1174,27 @@ int mimo_nan_info(mimo_ctx* ctx, int64_t* n_bad, double* row_mask_out, int K, in
         for (int k = 0; k < K; ++k) label_counts[k] = (int64_t)h[k];
       }
     }
+    return MIMO_OK;
+  });
+}
+
+int mimo_shader_clock_mhz(mimo_ctx* ctx, double* mhz) {
+  return guarded(ctx, [&]() -> int {
+    int rc = bind(ctx); if (rc) return rc;
+    if (!mhz) return fail(ctx, MIMO_E_INVALID, "mimo_shader_clock_mhz: out is NULL");
+    const int grid = ctx->num_cu * 4;
+    if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, (size_t)grid * 2))) return rc;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(ctx->partials);
+    HIP_TRY(ctx, launch_clock_probe(d, grid, 20000, ctx->stream));      // ~0.3 ms of v_fma_f64 on every SIMD
+    std::vector<unsigned long long> h((size_t)grid * 2);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> v;
+    for (int g = 0; g < grid; ++g)
+      if (h[2 * g + 1] > 0) v.push_back((double)h[2 * g] / (double)h[2 * g + 1] * 100.0);
+    if (v.empty()) return fail(ctx, MIMO_E_HIP, "mimo_shader_clock_mhz: no samples");
+    std::sort(v.begin(), v.end());
+    *mhz = v[v.size() / 2];
     return MIMO_OK;
   });
 }

@@ -18,6 +18,9 @@ hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t
                               unsigned long long* bad_counts, hipStream_t stream);
 hipError_t launch_mask_table(const double* table, const double* mask, double* out, int K, int64_t N, hipStream_t stream);
 
+// shader clock under float64 load (mimo_small.hip): out[2 g] = shader-clock ticks, out[2 g + 1] = 100 MHz ticks of workgroup g
+hipError_t launch_clock_probe(unsigned long long* out, int grid, int iters, hipStream_t stream);
+
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;
 bool vi_rowwave_covers(int K, int F16, int ZS);

@@ -473,6 +473,31 @@ hipError_t launch_mask_table(const double* table, const double* mask, double* ou
 }
 
 // ------------------------------------------------------------------------------------------
+// Shader clock under float64 load: every workgroup runs a short v_fma_f64 loop bracketed by s_memtime (shader clock
+// counter) and s_memrealtime (constant 100 MHz); clock = d memtime / d memrealtime x 100 MHz (as tools/f64_rates.hip).
+// bench.py calls it right after its sustained leg, while the device is warm.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, double a, double b) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  double x0 = a + threadIdx.x * 1e-9, x1 = a * 2, x2 = a * 3, x3 = a * 4;
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b), "v"(a));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t1 - t0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (x0 + x1 + x2 + x3 == 12345.678) out[0] = 0;      // keeps the loop
+}
+
+hipError_t launch_clock_probe(unsigned long long* out, int grid, int iters, hipStream_t stream) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(kWG), 0, stream, out, iters, 0.999, 1e-3);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 // components per lane / lanes per row for (Dz, K): KL = 4 up to Dz = 3, 2 at Dz = 4 (Theta rows + accumulators of a

@@ -196,6 +196,12 @@ class HipEngine:
             out[name] = {"ms": float(ms), "launches": int(n)}
         return out
 
+    def shader_clock_mhz(self):
+        """Median shader clock under a short float64 load, from the in-kernel counters (mimo_shader_clock_mhz)."""
+        out = C.c_double()
+        self._check(self._lib.mimo_shader_clock_mhz(self._ctx, C.byref(out)))
+        return out.value
+
     def plan(self, K, gibbs=False):
         """How a pass with K components runs on the resident data (mimo_plan): kind, kernels, HBM passes."""
         o = (C.c_int64 * 8)()
