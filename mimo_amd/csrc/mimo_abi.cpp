@@ -116,9 +116,14 @@ static int ls_pad() {
 static unsigned long long* g_stamps = nullptr;
 static int g_stamps_grid = 0;
 extern "C" int mimo_debug_stamps_grid() { return g_stamps_grid; }
+extern "C" int mimo_debug_stamps_trace(unsigned long long* out128) {   // phase boundaries of workgroups 0 and grid / 2
+  return hipMemcpy(out128, g_stamps + (size_t)3 * 8192 * 32, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+static int g_stamps_sel = 0;                       // 1: the chunked E-step's block (second half of the buffer)
+extern "C" void mimo_debug_stamps_select(int sel) { g_stamps_sel = sel; }
 extern "C" int mimo_debug_stamps(double* out8) {   // mean cycles per wave of each phase, last launch
   std::vector<unsigned long long> h((size_t)g_stamps_grid * 32);
-  if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(h.data(), g_stamps + (g_stamps_sel ? (size_t)8192 * 32 : 0), h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   for (int i = 0; i < 8; ++i) out8[i] = 0;
   for (size_t w = 0; w < h.size() / 8; ++w) for (int i = 0; i < 8; ++i) out8[i] += (double)h[w * 8 + i];
   for (int i = 0; i < 8; ++i) out8[i] /= (double)(h.size() / 8);
@@ -465,7 +470,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
 #ifdef MIMO_STAMPS
   {
     static unsigned long long* stamps_d = nullptr;
-    if (!stamps_d) (void)hipMalloc(reinterpret_cast<void**>(&stamps_d), 8192 * 4 * 8 * sizeof(unsigned long long));
+    if (!stamps_d) (void)hipMalloc(reinterpret_cast<void**>(&stamps_d), 4 * 8192 * 4 * 8 * sizeof(unsigned long long));
     a.stamps = stamps_d;
     g_stamps = stamps_d; g_stamps_grid = grid;
   }

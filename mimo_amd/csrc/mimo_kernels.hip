@@ -77,6 +77,30 @@ __device__ __forceinline__ double philox_for_tile(PhiloxBatch& pb, const KernelA
   return uu;
 }
 
+// Wave priority of the matrix phases.  Two workgroups share a CU; at equal priority they fall into lock step (both in
+// their MFMA phase, then both in their latency-bound build phase with the pipe idle).  MIMO_ASYM_PRIO = 1 / 2 runs the
+// matrix phases of one of the two at priority 1 (1: upper half of the grid, 2: odd workgroups), so the other one's
+// MFMAs fill exactly the gaps.  Scheduling only: results do not depend on it.
+#ifndef MIMO_ASYM_PRIO
+#define MIMO_ASYM_PRIO 0
+#endif
+#define MFMA_PRIO()                                                                        \
+  do {                                                                                    \
+    if (MIMO_ASYM_PRIO && prio_hi) __builtin_amdgcn_s_setprio(1);                         \
+    else __builtin_amdgcn_s_setprio(0);                                                   \
+  } while (0)
+
+// Start-up stagger (experiment): the second workgroup of a CU starts MIMO_STAGGER x ~1024 cycles late, so that its matrix
+// phases fall into the other one's latency-bound phases.
+#ifndef MIMO_STAGGER
+#define MIMO_STAGGER 0
+#endif
+#define STAGGER_START()                                                                    \
+  do {                                                                                    \
+    if (MIMO_STAGGER > 0 && 2 * blockIdx.x >= gridDim.x)                                  \
+      for (int i_ = 0; i_ < MIMO_STAGGER; ++i_) __builtin_amdgcn_s_sleep(16);             \
+  } while (0)
+
 #ifdef MIMO_STAMPS
 // diagnostic build: per-wave cycle sums of the phases of the tile loop (never in the shipped library)
 #define STAMP(i)                                                                          \
@@ -488,6 +512,7 @@ void fused_kernel(const KernelArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches and SGPR bases
+  const bool prio_hi = MIMO_ASYM_PRIO == 2 ? (blockIdx.x & 1) != 0 : 2 * blockIdx.x >= gridDim.x;   // (scalar)
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
   const int ZS = a.ZS, RS = a.RS, LS = a.LS;
@@ -519,6 +544,9 @@ void fused_kernel(const KernelArgs a) {
     if (e >= NE) e = 0;   // padding element: any valid slice, never consumed
     const int h = e / (NS * RP), rem = e % (NS * RP);
     const int s = rem / RP, i = h * RP + rem % RP;
+#ifdef MIMO_WHATIF_THETA_L1       // what-if build (wrong results): every slice from the same two cache lines
+    return thw[(e & 1) * 64 + lane];
+#endif
     return thw[(4 * i * NSI + s) * 64 + lane];
   };
   const gptr_t thw0 = thw;
@@ -591,14 +619,26 @@ void fused_kernel(const KernelArgs a) {
     for (int jj = 0; jj < NCB; ++jj) w[jj] = reinterpret_cast<const uint32_t*>(fe)[fgrp * NCB + jj];
   }
 
+  STAGGER_START();
 #ifdef MIMO_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+#ifdef MIMO_STAMPS
+  int st_it = 0;
 #endif
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
     wg_sync();  // z~ tile of this step is in LDS; the previous tile's readers are done
     STAMP(0);
+#ifdef MIMO_STAMPS
+    // absolute phase boundaries of iterations 8..23 of the two workgroups of one CU (0 and gridDim.x / 2), wave 0
+    const bool st_trace = a.stamps && wave == 0 && lane == 0 && (blockIdx.x == 0 || 2 * blockIdx.x == gridDim.x) &&
+                          st_it >= 8 && st_it < 24;
+    unsigned long long* st_tr = a.stamps + (size_t)3 * 8192 * 32 + (blockIdx.x ? 64 : 0) + 4 * (st_it - 8);
+    if (st_trace) st_tr[0] = st_prev;
+    ++st_it;
+#endif
 
     // ---- 2. feature tile (+ externally supplied weights) --------------------------------
     // VALU phases run at raised priority: the f64 VALU shares its pipe with the co-resident
@@ -654,9 +694,12 @@ void fused_kernel(const KernelArgs a) {
       if (tid < T) labs[tid] = (n0 + tid) < N ? a.labels[n0 + tid] : -1;   // one-hot operand is built on the fly
     }
     STAMP(1);
-    __builtin_amdgcn_s_setprio(0);
+    MFMA_PRIO();
     wg_sync();
     STAMP(2);
+#ifdef MIMO_STAMPS
+    if (st_trace) st_tr[1] = st_prev;
+#endif
 
     if constexpr (SRC == kSrcEstep) {
       // ---- 3. L tile = Theta . Phi' ------------------------------------------------------
@@ -763,10 +806,13 @@ void fused_kernel(const KernelArgs a) {
         }
       }
       STAMP(5);
-      __builtin_amdgcn_s_setprio(0);
+      MFMA_PRIO();
       wg_sync();
       STAMP(6);
     }
+#ifdef MIMO_STAMPS
+    if (st_trace) st_tr[2] = st_prev;
+#endif
 
     // ---- 5. S += R . Phi ----------------------------------------------------------------
     // step s contracts the 4 rows {s, s+8, s+16, s+24}: A lane (i = j, kk = q) = R[8q+s][16rb+j],
@@ -905,6 +951,9 @@ void fused_kernel(const KernelArgs a) {
     store_z(t + gridDim.x);
     load_z(t + 2 * (int64_t)gridDim.x);
     STAMP(7);
+#ifdef MIMO_STAMPS
+    if (st_trace) st_tr[3] = st_prev;
+#endif
   }
 #ifdef MIMO_STAMPS
   if (a.stamps && lane == 0)
@@ -983,6 +1032,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool prio_hi = MIMO_ASYM_PRIO == 2 ? (blockIdx.x & 1) != 0 : 2 * blockIdx.x >= gridDim.x;   // (scalar)
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
   const int ZS = a.ZS, RS = a.RS, LS = a.LS;
@@ -1005,16 +1055,26 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
     const int ch = bl / NPASS, h = bl - ch * NPASS;
     return thw + ((size_t)(4 * h * RP) * NSP + (size_t)ch * NSc) * 64;
   };
+#ifdef MIMO_WHATIF_THETA_L1       // what-if build (wrong results): every slice from the same two cache lines
+  auto slice = [&](gptr_t base, int ee) { return thw[(ee & 1) * 64]; };
+#else
   auto slice = [&](gptr_t base, int ee) { return base[((size_t)(4 * (ee % RP)) * NSP + ee / RP) * 64]; };
+#endif
   double ring[PF];
   if (mfma_wave) {
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = slice(block_base(0), e);
   }
 
+  STAGGER_START();
+#ifdef MIMO_STAMPS
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
   for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int64_t n0 = t * T;
     wg_sync();
+    STAMP(0);
     {
       const int64_t base = n0 * D, total = N * D;
       for (int e = tid; e < T * D; e += kWG) {
@@ -1030,8 +1090,11 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 #pragma unroll
     for (int i = 0; i < RBW; ++i) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
 
+    STAMP(1);
     for (int ch = 0; ch < nchunk; ++ch) {
       wg_sync();   // z~ rows visible / previous chunk's MFMA reads of Ph are done
+      STAMP(2);
+      if (MIMO_ASYM_PRIO) __builtin_amdgcn_s_setprio(2);
       {
         const double* zrow = Zs + frow * ZS;
         double* prow = Ph + frow * RS + fgrp * (2 * NCBc);
@@ -1039,7 +1102,10 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
 #pragma unroll
         for (int jj = 0; jj < 2 * NCBc; ++jj) prow[jj] = zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]];
       }
+      STAMP(3);
+      if (MIMO_ASYM_PRIO) MFMA_PRIO();
       wg_sync();
+      STAMP(4);
       if constexpr (SPLIT != 0) {
         if (mfma_wave) {     // RBW = 1: one pass, LE = NSc slices per chunk, one column group
           const double* p = Ph + (16 * sidx + j) * RS + q;
@@ -1078,6 +1144,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
           }
         }
       }
+      STAMP(5);
     }
     if constexpr (SPLIT != 0) {
       if (mfma_wave) {
@@ -1098,6 +1165,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
       }
     }
     wg_sync();
+    STAMP(6);
     __builtin_amdgcn_s_setprio(2);
     if constexpr (RBW == 1)
       normalise_tile<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp, a.lse,
@@ -1105,8 +1173,13 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
     else
       normalise_tile_chunked<RBW, kGeneric>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, a.logp, a.resp,
                                             a.lse, sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
-    __builtin_amdgcn_s_setprio(0);
+    MFMA_PRIO();
+    STAMP(7);
   }
+#ifdef MIMO_STAMPS
+  if (a.stamps && lane == 0)
+    for (int i = 0; i < 8; ++i) a.stamps[(size_t)8192 * 32 + ((size_t)blockIdx.x * 4 + wave) * 8 + i] = st_sum[i];
+#endif
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
   wg_sync();
