@@ -545,19 +545,27 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       }
     }
     if (a.do_stats) {
-      const int gmax = stats_group_ncb(a.K16);
+      const bool wide = stats_src == kSrcWeights && wide_stats_covers(a.K16, D);     // 8-wave statistics kernel (mimo_wide.hip)
+      const int gmax = wide ? wide_stats_group_ncb(a.K16, ncb_total) : stats_group_ncb(a.K16);
       for (int cb0 = 0; cb0 < ncb_total; cb0 += gmax) {
         KernelArgs g = st;
         const int ncb = ncb_total - cb0 < gmax ? ncb_total - cb0 : gmax;
         g.cb0 = cb0; g.F16 = 16 * ncb; g.RS = g.F16 + 1; g.F16_total = a.F16;
         g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
         if (cb0 > 0) g.write_scalars = 0;
-        rc = timed_launch(ctx, src == kSrcEstep ? "fused_kernel(statistics of a column group)" : "fused_kernel", [&]() -> int {
-          bool unsupported = false;
-          HIP_TRY(ctx, launch_fused(g, stats_src, grid, ctx->stream, &unsupported));
-          if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no statistics kernel for K=%d, Dz=%d", K, D);
-          return MIMO_OK;
-        });
+        if (wide) {
+          rc = timed_launch(ctx, "wide_stats_kernel", [&]() -> int {
+            HIP_TRY(ctx, launch_wide_stats(g, grid, ctx->stream));
+            return MIMO_OK;
+          });
+        } else {
+          rc = timed_launch(ctx, src == kSrcEstep ? "fused_kernel(statistics of a column group)" : "fused_kernel", [&]() -> int {
+            bool unsupported = false;
+            HIP_TRY(ctx, launch_fused(g, stats_src, grid, ctx->stream, &unsupported));
+            if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "no statistics kernel for K=%d, Dz=%d", K, D);
+            return MIMO_OK;
+          });
+        }
         if (rc) return rc;
       }
     }

@@ -21,6 +21,11 @@ hipError_t launch_mask_table(const double* table, const double* mask, double* ou
 // shader clock under float64 load (mimo_small.hip): out[2 g] = shader-clock ticks, out[2 g + 1] = 100 MHz ticks of workgroup g
 hipError_t launch_clock_probe(unsigned long long* out, int grid, int iters, hipStream_t stream);
 
+// wide shapes (Dz > 16), statistics of a K-major weight table: one 8-wave workgroup per CU (mimo_wide.hip)
+bool wide_stats_covers(int K16, int D);
+int wide_stats_group_ncb(int K16, int ncb_total);     // feature column blocks per launch
+hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
+
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;
 bool vi_rowwave_covers(int K, int F16, int ZS);

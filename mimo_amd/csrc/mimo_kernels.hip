@@ -1067,6 +1067,35 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
   }
 
   STAGGER_START();
+  // Z tile staging as in fused_kernel: the NEXT tile's rows travel in registers while this one is processed
+  // (T*D <= 1024 elements for Dz <= 32: 4 per thread)
+  constexpr int ZPT = 4;
+  int zoff[ZPT];
+#pragma unroll
+  for (int i = 0; i < ZPT; ++i) {
+    const int e = tid + kWG * i;
+    const int pt = e / D;
+    zoff[i] = e < T * D ? pt * ZS + (e - pt * D) : -1;
+  }
+  double zr[ZPT];
+  auto load_z = [&](int64_t t) {
+    const int64_t base = t * T * D, total = N * D;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + kWG * i;
+      zr[i] = (zoff[i] >= 0 && g < total) ? a.Z[g] : 0.0;
+    }
+  };
+  auto store_z = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i)
+      if (zoff[i] >= 0) Zs[zoff[i]] = zr[i];
+    if (tid < T) {
+      Zs[tid * ZS + D] = (t * T + tid) < N ? 1.0 : 0.0;
+      Zs[tid * ZS + D + 1] = 0.0;
+    }
+  };
+  load_z(blockIdx.x);
 #ifdef MIMO_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -1075,17 +1104,8 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
     const int64_t n0 = t * T;
     wg_sync();
     STAMP(0);
-    {
-      const int64_t base = n0 * D, total = N * D;
-      for (int e = tid; e < T * D; e += kWG) {
-        const int pt = e / D, d = e - pt * D;
-        Zs[pt * ZS + d] = (base + e) < total ? a.Z[base + e] : 0.0;
-      }
-      if (tid < T) {
-        Zs[tid * ZS + D] = (n0 + tid) < N ? 1.0 : 0.0;
-        Zs[tid * ZS + D + 1] = 0.0;
-      }
-    }
+    store_z(t);                                   // fetched while the previous tile was processed
+    load_z(t + gridDim.x);
     d4 acc[RBW][2];
 #pragma unroll
     for (int i = 0; i < RBW; ++i) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
@@ -1096,11 +1116,30 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
       STAMP(2);
       if (MIMO_ASYM_PRIO) __builtin_amdgcn_s_setprio(2);
       {
+        // 2*NCBc features of one row per thread: the (a, b) byte pairs arrive as NCBc dwords, then all operands of a
+        // half are read before its products are stored (reads and writes alias for the compiler: interleaved, every
+        // feature would wait out its own three LDS round trips)
         const double* zrow = Zs + frow * ZS;
         double* prow = Ph + frow * RS + fgrp * (2 * NCBc);
-        const uint8_t* ft = fe + 2 * (ch * CF + fgrp * 2 * NCBc);
+        const uint32_t* ftw = reinterpret_cast<const uint32_t*>(fe + 2 * (ch * CF + fgrp * 2 * NCBc));
+        uint32_t wds[NCBc];
 #pragma unroll
-        for (int jj = 0; jj < 2 * NCBc; ++jj) prow[jj] = zrow[ft[2 * jj]] * zrow[ft[2 * jj + 1]];
+        for (int i = 0; i < NCBc; ++i) wds[i] = ftw[i];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double za[NCBc], zb[NCBc];
+#pragma unroll
+          for (int i = 0; i < NCBc; ++i) {
+            const int jj = h * NCBc + i;
+            const uint32_t w2 = wds[jj >> 1] >> (16 * (jj & 1));
+            za[i] = zrow[w2 & 255u];
+            zb[i] = zrow[(w2 >> 8) & 255u];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NCBc; ++i) prow[h * NCBc + i] = za[i] * zb[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       STAMP(3);
       if (MIMO_ASYM_PRIO) MFMA_PRIO();

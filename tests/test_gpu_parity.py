@@ -127,7 +127,9 @@ def _random_problem(rng, N, D, K):
 @pytest.mark.parametrize("N,D,K", [(0, 3, 2), (1, 1, 1), (31, 16, 16), (32, 2, 4), (33, 5, 70), (4099, 8, 256),
                                     (4099, 12, 64), (20011, 16, 64), (1000, 9, 200), (777, 13, 17),
                                     # two-stage path (chunked E-step + column-group statistics)
-                                    (2051, 32, 128), (515, 32, 16), (700, 12, 200), (333, 20, 256), (100, 17, 3)])
+                                    (2051, 32, 128), (515, 32, 16), (700, 12, 200), (333, 20, 256), (100, 17, 3),
+                                    # 8-wave statistics kernel of the two-stage path (3 <= K16 <= 8): every blocks-per-wave instantiation
+                                    (3000, 24, 64), (1500, 17, 40), (999, 28, 100), (640, 20, 72), (4097, 32, 90)])
 def test_engine_vs_oracle_seeded(engine, N, D, K):
     """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
     from oracle import mimo_oracle as O
