@@ -26,6 +26,10 @@ bool wide_stats_covers(int K16, int D);
 int wide_stats_group_ncb(int K16, int ncb_total);     // feature column blocks per launch
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
 
+// ... and their E-step (softmax pass of the VI modes; the label draw stays with estep_chunked_kernel)
+bool wide_estep_covers(int K16, int D);
+hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
+
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;
 bool vi_rowwave_covers(int K, int F16, int ZS);

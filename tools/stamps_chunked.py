@@ -14,7 +14,9 @@ for it in range(2): eng.estep(c, b, W)
 lib = L.load(); lib.mimo_debug_stamps.argtypes = [C.POINTER(C.c_double)]
 grid = lib.mimo_debug_stamps_grid()
 ntile = (N + 31) // 32 / grid
-for sel, names in ((1, ["wait top barrier", "z staging (synchronous loads)", "chunks: wait barrier", "chunks: feature build",
+for sel, names in ((2, ["chunk: MFMA steps + build hooks", "chunk: barrier wait", "softmax: local max (+ logp)", "barrier wait",
+                        "softmax: exp + partial sums", "barrier wait", "softmax: totals, table write", "-"]),
+                   (1, ["wait top barrier", "z staging (synchronous loads)", "chunks: wait barrier", "chunks: feature build",
                         "chunks: wait barrier 2", "chunks: MFMA", "Lt write + barrier", "normalise + table write"]),
                    (0, ["wait B0 (top barrier)", "feature build + weight tile load", "wait B2", "-", "-", "-", "-",
                         "stats MFMA + z staging"])):
@@ -22,7 +24,8 @@ for sel, names in ((1, ["wait top barrier", "z staging (synchronous loads)", "ch
     out = (C.c_double * 8)()
     assert lib.mimo_debug_stamps(out) == 0
     tot = sum(out)
-    print(("chunked E-step" if sel else "last statistics launch") + f": cycles per wave per tile: total {tot/ntile:.0f} (grid {grid})")
+    if tot == 0: continue
+    print(("wide E-step" if sel == 2 else "chunked E-step" if sel else "last statistics launch") + f": cycles per wave per tile: total {tot/ntile:.0f} (grid {grid})")
     for n, v in zip(names, out):
         if n != "-": print(f"  {n:34s} {v/ntile:8.0f}  {100*v/tot:5.1f}%")
 tr = (C.c_ulonglong * 128)()
