@@ -119,10 +119,10 @@ extern "C" int mimo_debug_stamps_grid() { return g_stamps_grid; }
 extern "C" int mimo_debug_stamps_trace(unsigned long long* out128) {   // phase boundaries of workgroups 0 and grid / 2
   return hipMemcpy(out128, g_stamps + (size_t)3 * 8192 * 32, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
-static int g_stamps_sel = 0;                       // region: 0 fused / statistics, 1 chunked E-step, 2 wide E-step (8 waves)
+static int g_stamps_sel = 0;                       // region: 0 fused / statistics, 1 chunked E-step, 2 wide E-step
 extern "C" void mimo_debug_stamps_select(int sel) { g_stamps_sel = sel; }
 extern "C" int mimo_debug_stamps(double* out8) {   // mean cycles per wave of each phase, last launch
-  std::vector<unsigned long long> h((size_t)g_stamps_grid * (g_stamps_sel == 2 ? 64 : 32));
+  std::vector<unsigned long long> h((size_t)g_stamps_grid * 32);
   if (hipMemcpy(h.data(), g_stamps + (size_t)g_stamps_sel * 8192 * 32, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   for (int i = 0; i < 8; ++i) out8[i] = 0;
   for (size_t w = 0; w < h.size() / 8; ++w) for (int i = 0; i < 8; ++i) out8[i] += (double)h[w * 8 + i];
@@ -523,6 +523,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
     if (src == kSrcEstep) {
       KernelArgs e = a;
       e.RS = 16 * kChunkNCB + 1;
+      e.split = (a.split || a.resp || a.logp || a.lse) ? 1 : 0;   // include/mimo_hip.h: scalars[1..2] come with the split or any kept table
       if (!e.gibbs && e.do_stats && !e.resp) {       // statistics need the table: keep it internally
         const size_t kn = (size_t)K * (size_t)(ctx->N > 0 ? ctx->N : 1);
         if ((rc = ensure_dev(ctx, &ctx->resp, &ctx->resp_cap, kn))) return rc;
@@ -530,7 +531,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       }
       if (chunked_lds_bytes(e) > 160 * 1024)
         return fail(ctx, MIMO_E_UNSUPPORTED, "K=%d, Dz=%d needs more LDS than one CU has", K, D);
-      if (!e.gibbs && wide_estep_covers(a.K16, D)) {          // 8-wave softmax pass (mimo_wide.hip)
+      if (!e.gibbs && wide_estep_covers(a.K16, D, a.F16)) {          // 8-wave softmax pass (mimo_wide.hip)
         rc = timed_launch(ctx, "wide_estep_kernel", [&]() -> int {
           HIP_TRY(ctx, launch_wide_estep(e, grid, ctx->stream));
           return MIMO_OK;

@@ -27,7 +27,7 @@ int wide_stats_group_ncb(int K16, int ncb_total);     // feature column blocks p
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
 
 // ... and their E-step (softmax pass of the VI modes; the label draw stays with estep_chunked_kernel)
-bool wide_estep_covers(int K16, int D);
+bool wide_estep_covers(int K16, int D, int F16);
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image

@@ -70,7 +70,9 @@ int fused_grid(const KernelArgs& a, int num_cu, int src);
 hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);
 // chunked E-step for shapes outside the fused kernels (Dz > 16, or K > 64 with Dz > 9): no statistics
 size_t chunked_lds_bytes(const KernelArgs& a);
-int chunked_ns_pad(int F16);      // contraction steps of the Theta image padded to whole chunks
+// contraction steps per row block of the Theta image of the two-stage path: padded to whole chunks of BOTH E-step kernels
+// (estep_chunked_kernel: 36 steps per chunk; wide_estep_kernel: 24)
+__host__ __device__ inline int chunked_ns_pad(int F16) { return (F16 + 287) / 288 * 72; }
 hipError_t launch_estep_chunked(const KernelArgs& a, int grid, hipStream_t stream);
 bool fused_covers(int K16, int ncb, int src);
 int stats_group_ncb(int K16);   // feature column blocks one statistics launch can accumulate for this K

@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(kWG, (RBW <= 2 ? 2 : 1)) void estep_chunked_kernel(
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16, F16 = a.F16;
   const int ZS = a.ZS, RS = a.RS, LS = a.LS;
-  const int nchunk = (F16 + CF - 1) / CF, NSP = nchunk * NSc;   // Theta image is zero-padded to NSP steps
+  const int nchunk = (F16 + CF - 1) / CF, NSP = chunked_ns_pad(F16);   // Theta image is zero-padded to NSP steps per row block
   const int NB = nchunk * NPASS;                                 // (chunk, pass) blocks per tile
   const int64_t N = a.N;
   const bool gibbs = a.gibbs != 0;
@@ -1658,11 +1658,6 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, a);
   return hipGetLastError();
-}
-
-int chunked_ns_pad(int F16) {
-  const int CF = 16 * kChunkNCB;
-  return (F16 + CF - 1) / CF * (CF / 4);
 }
 
 size_t chunked_lds_bytes(const KernelArgs& a) {

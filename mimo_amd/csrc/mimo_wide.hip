@@ -262,77 +262,81 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// E-step of the wide shapes (softmax pass, no statistics): the 8-wave counterpart of estep_chunked_kernel.
-//   * wave w owns row blocks w, w + 8 (RBW of them) and both 16-row column groups of a 32-row tile; the Theta slices
-//     stream from the L2-resident image through a 6-deep register ring (what-if build: serving every slice from one
-//     cache line changes nothing, so L2 is not the bound);
-//   * the feature tile is built chunk by chunk (144 features, the chunking of the Theta image) into a double buffer,
-//     the reads of chunk c + 1 after matrix step 12, its products and stores after step 24 of chunk c: one barrier
-//     per chunk, no LDS round trip in front of an MFMA;
+// E-step of the wide shapes (softmax pass, no statistics): estep_chunked_kernel's blocking — two 4-wave workgroups
+// per CU, wave w owns row blocks w, w + 4, ... (RBW of them) and both 16-row column groups of a 32-row tile — without
+// its latency-bound phases:
+//   * the Theta slices stream from the L2-resident image through a 6-deep register ring (what-if build: serving every
+//     slice from one cache line changes nothing, so L2 is not the bound);
+//   * the feature tile is built chunk by chunk (96 features = 24 contraction steps) into a double buffer: table
+//     offsets after matrix step 2, operand reads after step 8, products and stores after step 16 of the PREVIOUS
+//     chunk — one barrier per chunk, no LDS round trip in front of an MFMA, z rows two tiles ahead in registers;
+//     what is left of a chunk barrier's bubble is filled by the other workgroup of the CU (an 8-wave variant of
+//     this kernel, one workgroup per CU, stalled all eight waves there: 16 % of the tile time in barrier waits);
 //   * the softmax runs on the accumulators (C layout: lane (q, j), register r = component q + 4r of the wave's row
 //     block, datum j of the column group): per-datum max / sum / sum e l of the wave's 16 RBW components by two
-//     cross-row exchanges, the eight waves' partials through 3 x 8 x 32 doubles of LDS in a fixed order, the table
+//     cross-row exchanges, the four waves' partials through 3 x 4 x 32 doubles of LDS in a fixed order, the table
 //     written from the registers (16 consecutive rows = one 128-byte line per component and column group).
 // VI mode only (no label draw); scalars and tables as estep_chunked_kernel's.
 // ------------------------------------------------------------------------------------------
+constexpr int kWideEstepCF = 96;       // features per chunk
 template <int RBW>
-__global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a) {
-  constexpr int T = kTile, CF = 16 * kChunkNCB, NSc = CF / 4, RSc = CF + 2, PF = 6, NBF = CF * T / kWideWG;
-  static_assert(NBF * kWideWG == CF * T && (NSc * RBW) % PF == 0, "chunk geometry");
+__global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) {
+  constexpr int T = kTile, CF = kWideEstepCF, NSc = CF / 4, RSc = CF + 2, PF = 6, NBF = CF * T / kWG, NW = kWG / 64, ZPT = 4;
+  static_assert(NBF * kWG == CF * T && (NSc * RBW) % PF == 0, "chunk geometry");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16;
   const int ZS = (D + 2) | 1;
-  const int nchunk = (a.F16 + CF - 1) / CF, NSP = nchunk * NSc;
+  const int nchunk = (a.F16 + CF - 1) / CF, NSP = chunked_ns_pad(a.F16);     // row-block stride of the Theta image
   const int64_t N = a.N, total = N * D, G = gridDim.x;
 
   extern __shared__ __align__(16) unsigned char smem[];
   double* Zs = reinterpret_cast<double*>(smem);               // [2][T][ZS]
   double* Ph = Zs + 2 * T * ZS;                                // [2][T][RSc]  feature chunks
-  double* red = Ph + 2 * T * RSc;                              // [3][8][T]   per-wave partial max / sum / sum e l
-  double* etab = red + 3 * 8 * T;                              // [64]
+  double* red = Ph + 2 * T * RSc;                              // [3][NW][T]  per-wave partial max / sum / sum e l
+  double* etab = red + 3 * NW * T;                              // [64]
   uint32_t* fo = reinterpret_cast<uint32_t*>(etab + 64);       // [nchunk CF]  byte offsets (a | b << 16) into a z~ row
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
-  for (int e = tid; e < nchunk * CF; e += kWideWG) {
+  for (int e = tid; e < nchunk * CF; e += kWG) {
     const uint32_t fa = e < a.F16 ? a.feat[2 * e] : (uint32_t)(D + 1), fb = e < a.F16 ? a.feat[2 * e + 1] : (uint32_t)(D + 1);
     fo[e] = 8u * fa | (8u * fb) << 16;
   }
 
   // z staging (as wide_stats_kernel): registers hold the tile after next; rows past N are zero with a zero "1" slot
-  int zoff[2];
+  int zoff[ZPT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int e = tid + kWideWG * i, pt = e / D;
+  for (int i = 0; i < ZPT; ++i) {
+    const int e = tid + kWG * i, pt = e / D;
     zoff[i] = e < T * D ? pt * ZS + (e - pt * D) : -1;
   }
-  double zr[2];
+  double zr[ZPT];
   auto load_z = [&](int64_t t) {
     const int64_t base = t * T * D;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t g = base + tid + kWideWG * i;
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + kWG * i;
       zr[i] = a.Z[g < total ? g : total - 1];
     }
   };
   auto store_z = [&](int64_t t, double* Zb) {
     const int64_t base = t * T * D;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (zoff[i] >= 0) Zb[zoff[i]] = base + tid + kWideWG * i < total ? zr[i] : 0.0;
+    for (int i = 0; i < ZPT; ++i)
+      if (zoff[i] >= 0) Zb[zoff[i]] = base + tid + kWG * i < total ? zr[i] : 0.0;
     if (tid < T) {
       Zb[tid * ZS + D] = t * T + tid < N ? 1.0 : 0.0;
       Zb[tid * ZS + D + 1] = 0.0;
     }
   };
 
-  // feature build of one chunk: thread (row, fgrp) makes column fgrp of each of the 9 column blocks
+  // feature build of one chunk: thread (row, fgrp) makes columns fgrp and fgrp + 8 of each of the 6 column blocks
   const int frow = tid & (T - 1), fgrp = tid >> 5;
   uint32_t w2[NBF];
   double za[NBF], zb[NBF];
   auto build_offsets = [&](int ch) {
 #pragma unroll
-    for (int i = 0; i < NBF; ++i) w2[i] = fo[ch * CF + 16 * i + fgrp];
+    for (int i = 0; i < NBF; ++i) w2[i] = fo[ch * CF + 8 * i + fgrp];
   };
   auto build_loads = [&](const double* zb_) {
     const unsigned char* zrow = reinterpret_cast<const unsigned char*>(zb_ + frow * ZS);
@@ -345,15 +349,15 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
   auto build_stores = [&](double* pb_) {
     double* prow = pb_ + frow * RSc + fgrp;
 #pragma unroll
-    for (int i = 0; i < NBF; ++i) prow[16 * i] = za[i] * zb[i];
+    for (int i = 0; i < NBF; ++i) prow[8 * i] = za[i] * zb[i];
   };
 
-  // Theta stream of this wave: element e = s * RBW + i of a tile is slice s of row block wave + 8 i (a row block past
+  // Theta stream of this wave: element e = s * RBW + i of a tile is slice s of row block wave + 4 i (a row block past
   // K16 streams the last one's slices: its accumulators are overwritten with the padding value before the softmax)
   gptr_t thb[RBW];
 #pragma unroll
   for (int i = 0; i < RBW; ++i) {
-    const int rbi = wave + 8 * i < K16 ? wave + 8 * i : K16 - 1;
+    const int rbi = wave + NW * i < K16 ? wave + NW * i : K16 - 1;
     thb[i] = (gptr_t)(a.theta + (size_t)rbi * NSP * 64 + lane);
   }
   auto slice = [&](int ch, int ee) {          // element ee (0 .. NSc RBW - 1) of chunk ch
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
   };
   double ring[PF];
   double sc_lse = 0.0, sc_rl = 0.0;
+  const bool want_sel = a.split != 0;        // sum_k r l only feeds the entropy split of the ELBO scalars
 
   if ((int64_t)blockIdx.x < a.ntiles) {
     load_z(blockIdx.x);
@@ -413,8 +418,8 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 2) { build_offsets(nch); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 12) { build_loads(Zn); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 24) { build_stores(Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 8) { build_loads(Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 16) { build_stores(Pn); __builtin_amdgcn_sched_barrier(0); }
       }
       if (ch == 0) {                          // z~ of the next tile: read from the last chunk on
         store_z(t + G, Zs + (cur ^ 1) * T * ZS);
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
     __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int i = 0; i < RBW; ++i)
-      if (wave + 8 * i >= K16) {               // (scalar) no such row block: 16 padding components
+      if (wave + NW * i >= K16) {               // (scalar) no such row block: 16 padding components
         acc[i][0] = d4{kPadLogDensity, kPadLogDensity, kPadLogDensity, kPadLogDensity};
         acc[i][1] = acc[i][0];
       }
@@ -439,7 +444,8 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       double v = fmax(fmax(acc[0][c][0], acc[0][c][1]), fmax(acc[0][c][2], acc[0][c][3]));
-      if (RBW == 2) v = fmax(v, fmax(fmax(acc[RBW - 1][c][0], acc[RBW - 1][c][1]), fmax(acc[RBW - 1][c][2], acc[RBW - 1][c][3])));
+#pragma unroll
+      for (int i = 1; i < RBW; ++i) v = fmax(v, fmax(fmax(acc[i][c][0], acc[i][c][1]), fmax(acc[i][c][2], acc[i][c][3])));
       v = fmax(v, __shfl_xor(v, 16));
       v = fmax(v, __shfl_xor(v, 32));
       m[c] = v;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = 16 * (wave + 8 * i) + q + 4 * r;
+            const int k = 16 * (wave + NW * i) + q + 4 * r;
             const int64_t n = n0 + 16 * c + j;
             if (k < K && n < N) a.logp[(int64_t)k * N + n] = acc[i][c][r];
           }
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
     for (int c = 0; c < 2; ++c) {
       double v = red[16 * c + j];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) v = fmax(v, red[w * T + 16 * c + j]);
+      for (int w = 1; w < NW; ++w) v = fmax(v, red[w * T + 16 * c + j]);
       m[c] = v;
     }
 #pragma unroll
@@ -476,9 +482,9 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double l = acc[i][c][r];
-          const int k = 16 * (wave + 8 * i) + q + 4 * r;
+          const int k = 16 * (wave + NW * i) + q + 4 * r;
           e4[r] = exp_nonpos(l - m[c], etab);
-          t4[r] = e4[r] * ((k < K && l > kOffLogDensity) ? l : 0.0);     // switched-off / padding components: 0 * l := 0
+          t4[r] = want_sel ? e4[r] * ((k < K && l > kOffLogDensity) ? l : 0.0) : 0.0;   // switched-off / padding components: 0 * l := 0
           acc[i][c][r] = e4[r];
         }
         se += (e4[0] + e4[1]) + (e4[2] + e4[3]);
@@ -489,17 +495,17 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
       ssum[c] = se; ssel[c] = sl;
     }
     if (q == 0) {
-      red[(8 + wave) * T + j] = ssum[0]; red[(8 + wave) * T + 16 + j] = ssum[1];
-      red[(16 + wave) * T + j] = ssel[0]; red[(16 + wave) * T + 16 + j] = ssel[1];
+      red[(NW + wave) * T + j] = ssum[0]; red[(NW + wave) * T + 16 + j] = ssum[1];
+      red[(2 * NW + wave) * T + j] = ssel[0]; red[(2 * NW + wave) * T + 16 + j] = ssel[1];
     }
     WSTAMP(4);
     wg_sync();
     WSTAMP(5);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      double v = red[8 * T + 16 * c + j], u = red[16 * T + 16 * c + j];
+      double v = red[NW * T + 16 * c + j], u = red[2 * NW * T + 16 * c + j];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) { v += red[(8 + w) * T + 16 * c + j]; u += red[(16 + w) * T + 16 * c + j]; }
+      for (int w = 1; w < NW; ++w) { v += red[(NW + w) * T + 16 * c + j]; u += red[(2 * NW + w) * T + 16 * c + j]; }
       ssum[c] = v; ssel[c] = u;
     }
 #pragma unroll
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
         for (int i = 0; i < RBW; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = 16 * (wave + 8 * i) + q + 4 * r;
+            const int k = 16 * (wave + NW * i) + q + 4 * r;
             if (k < K) a.resp[(int64_t)k * N + n] = acc[i][c][r] * inv;
           }
       }
@@ -531,14 +537,14 @@ __global__ __launch_bounds__(kWideWG) void wide_estep_kernel(const KernelArgs a)
   }
 #ifdef MIMO_STAMPS
   if (a.stamps && lane == 0)
-    for (int i = 0; i < 8; ++i) a.stamps[(size_t)2 * 8192 * 32 + ((size_t)blockIdx.x * 8 + wave) * 8 + i] = st_sum[i];
+    for (int i = 0; i < 8; ++i) a.stamps[(size_t)2 * 8192 * 32 + ((size_t)blockIdx.x * 4 + wave) * 8 + i] = st_sum[i];
 #endif
   sc_lse = wave_sum(sc_lse);
   sc_rl = wave_sum(sc_rl);
   if (tid == 0) {
     const size_t pstride = (size_t)K16 * 16 * a.F16_total + 4;
     double* Ps = a.partials + (size_t)blockIdx.x * pstride + (size_t)K16 * 16 * a.F16_total;
-    Ps[0] = sc_lse; Ps[1] = sc_rl; Ps[2] = 1.0; Ps[3] = 0.0;
+    Ps[0] = sc_lse; Ps[1] = sc_rl; Ps[2] = want_sel ? 1.0 : 0.0; Ps[3] = 0.0;     // [2] > 0 after the reduction: the split is valid
   }
 }
 
@@ -584,23 +590,26 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) 
 }
 
 
-bool wide_estep_covers(int K16, int D) {
+bool wide_estep_covers(int K16, int D, int F16) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_ESTEP"); return !e || atoi(e) != 0; }();   // tuning knob
-  return on && D > kMaxFusedD && D <= kMaxD && K16 >= 5 && K16 <= 16;
+  // (K16 <= 4: one row block per wave, half of the waves idle below K16 = 3 — measured 3 % slower than the chunked kernel)
+  // F16 > one chunk: the z rows of the next tile are staged during the first chunk and read from the last one on
+  // (reduced feature maps — diagonal, linear — of a wide Dz stay with the chunked kernel)
+  return on && D > kMaxFusedD && D <= kMaxD && K16 >= 5 && K16 <= 16 && F16 > kWideEstepCF;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
-  const int ZS = (D + 2) | 1, CF = 16 * kChunkNCB, nchunk = (F16 + CF - 1) / CF;
-  return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * (CF + 2) + 3 * 8 * kTile + 64) + sizeof(uint32_t) * (size_t)nchunk * CF;
+  const int ZS = (D + 2) | 1, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
+  return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * (CF + 2) + 3 * 4 * kTile + 64) + sizeof(uint32_t) * (size_t)nchunk * CF;
 }
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  if (a.gibbs || a.K16 < 1 || a.K16 > 16 || a.D * kTile > 2 * kWideWG || a.F16 <= 16 * kChunkNCB) return hipErrorInvalidValue;
-  fn_t fn = a.K16 > 8 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
+  if (a.gibbs || a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 <= kWideEstepCF) return hipErrorInvalidValue;
+  fn_t fn = a.K16 > 8 ? wide_estep_kernel<4> : a.K16 > 4 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
   const size_t lds = wide_estep_lds_bytes(a.D, a.F16);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 80 * 1024) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kWideWG), lds, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, a);
   return hipGetLastError();
 }
 

@@ -16,7 +16,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("source,at_least", [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30)])
+@pytest.mark.parametrize("source,at_least", [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30),
+                                             ("mimo_wide.hip", 10)])
 def test_every_barrier_is_reached_with_lds_drained(tmp_path, source, at_least):
     asm = str(tmp_path / (source + ".s"))
     cmd = [HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-fno-honor-nans",
