@@ -49,7 +49,7 @@ CONFIGS = {
            10_000_000, 8, 256, "gibbs"),
     "c4": ("C4: mixture of linear-Gaussian experts, N=5e6 per GPU, x in R^8 -> y in R^4, K=64, mean-field VB",
            5_000_000, 12, 64, "ilr"),
-    "c5": ("C5: mean-field VB GMM, N=1e7 per GPU, D=32, K=128 (two-stage path: chunked E-step + column-group statistics)",
+    "c5": ("C5: mean-field VB GMM, N=1e7 per GPU, D=32, K=128 (two-stage path: E-step writing the responsibility table + statistics per column group)",
            10_000_000, 32, 128, "vi"),
 }
 

@@ -1333,7 +1333,8 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
     out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;
     out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
   } else {
-    const int gmax = stats_group_ncb(a.K16), groups = (ncb + gmax - 1) / gmax;
+    const bool wide = !gibbs && wide_stats_covers(a.K16, ctx->D);       // as run_pass
+    const int gmax = wide ? wide_stats_group_ncb(a.K16, ncb) : stats_group_ncb(a.K16), groups = (ncb + gmax - 1) / gmax;
     out8[0] = MIMO_PLAN_TWO_STAGE; out8[1] = 1 + groups;
     out8[2] = gibbs ? 0 : 1;             // the (K, N) responsibility table goes through HBM
     out8[3] = gibbs ? 0 : groups;        // and is read once per statistics launch
