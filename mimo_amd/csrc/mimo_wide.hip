@@ -551,9 +551,15 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
+static int wide_min_d() {
+  // measured at N=2e6 against the round-1 pair (which these shapes ran on): Dz=16, K=128 4.64 -> 3.48 ms per VI pass,
+  // Dz=16, K=200 12.5 -> 8.7, Dz=14, K=100 3.41 -> 3.01, Dz=12, K=128 2.89 -> 2.74, Dz=13, K=256 8.35 -> 8.47
+  static const int v = [] { const char* e = getenv("MIMO_WIDE_MIN_D"); return e ? atoi(e) : 10; }();   // tuning knob
+  return v;
+}
 bool wide_stats_covers(int K16, int D) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_STATS"); return !e || atoi(e) != 0; }();   // tuning knob
-  return on && D > kMaxFusedD && D <= kMaxD && K16 >= 3 && K16 <= 8;
+  return on && D >= wide_min_d() && D <= kMaxD && K16 >= 3 && K16 <= 8;
 }
 // column blocks per launch: as few launches as 12 blocks per wave allow, of equal size
 int wide_stats_group_ncb(int K16, int ncb_total) {
@@ -595,7 +601,7 @@ bool wide_estep_covers(int K16, int D, int F16) {
   // (K16 <= 4: one row block per wave, half of the waves idle below K16 = 3 — measured 3 % slower than the chunked kernel)
   // F16 > one chunk: the z rows of the next tile are staged during the first chunk and read from the last one on
   // (reduced feature maps — diagonal, linear — of a wide Dz stay with the chunked kernel)
-  return on && D > kMaxFusedD && D <= kMaxD && K16 >= 5 && K16 <= 16 && F16 > kWideEstepCF;
+  return on && D >= wide_min_d() && D <= kMaxD && K16 >= 5 && K16 <= 16 && F16 > kWideEstepCF;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
   const int ZS = (D + 2) | 1, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
