@@ -26,7 +26,7 @@ bool wide_stats_covers(int K16, int D);
 int wide_stats_group_ncb(int K16, int ncb_total);     // feature column blocks per launch
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
 
-// ... and their E-step (softmax pass of the VI modes; the label draw stays with estep_chunked_kernel)
+// ... and their E-step (softmax table or label draw)
 bool wide_estep_covers(int K16, int D, int F16);
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 

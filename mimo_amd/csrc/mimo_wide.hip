@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 //     block, datum j of the column group): per-datum max / sum / sum e l of the wave's 16 RBW components by two
 //     cross-row exchanges, the four waves' partials through 3 x 4 x 32 doubles of LDS in a fixed order, the table
 //     written from the registers (16 consecutive rows = one 128-byte line per component and column group).
-// VI mode only (no label draw); scalars and tables as estep_chunked_kernel's.
+// Softmax table or label draw; scalars and tables as estep_chunked_kernel's.
 // ------------------------------------------------------------------------------------------
 constexpr int kWideEstepCF = 96;       // features per chunk
 template <int RBW>
@@ -295,7 +295,10 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
   double* Zs = reinterpret_cast<double*>(smem);               // [2][T][ZS]
   double* Ph = Zs + 2 * T * ZS;                                // [2][T][RSc]  feature chunks
   double* red = Ph + 2 * T * RSc;                              // [3][NW][T]  per-wave partial max / sum / sum e l
-  double* etab = red + 3 * NW * T;                              // [64]
+  double* rbs = red + 3 * NW * T;                              // [16][T]     label draw: sum of e per row block
+  double* ured = rbs + 16 * T;                                 // [T]         ... uniforms of the tile's rows
+  int* cred = reinterpret_cast<int*>(ured + T);                // [NW][T]     ... per-wave counts
+  double* etab = reinterpret_cast<double*>(cred + NW * T);                              // [64]
   uint32_t* fo = reinterpret_cast<uint32_t*>(etab + 64);       // [nchunk CF]  byte offsets (a | b << 16) into a z~ row
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
   for (int e = tid; e < nchunk * CF; e += kWG) {
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
   double ring[PF];
   double sc_lse = 0.0, sc_rl = 0.0;
   const bool want_sel = a.split != 0;        // sum_k r l only feeds the entropy split of the ELBO scalars
+  const bool gibbs = a.gibbs != 0;
 
   if ((int64_t)blockIdx.x < a.ntiles) {
     load_z(blockIdx.x);
@@ -499,6 +503,25 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
       red[(2 * NW + wave) * T + j] = ssel[0]; red[(2 * NW + wave) * T + 16 + j] = ssel[1];
     }
     WSTAMP(4);
+    if (gibbs) {
+      // label draw (mimo/utils/stats.py:10-17), scale-invariant form of normalise_tile: label = #{k : u E_K > E_k} on the
+      // UNNORMALISED cumulative sums E_k.  Component order = row block, then q + 4 r inside it: the row-block sums go
+      // through LDS, inside a block the four q lanes scan each r and carry the rows before it.
+      double bsum[RBW][2];
+#pragma unroll
+      for (int i = 0; i < RBW; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          double v = (acc[i][c][0] + acc[i][c][1]) + (acc[i][c][2] + acc[i][c][3]);
+          v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+          bsum[i][c] = v;
+          if (q == 0 && wave + NW * i < 16) rbs[(wave + NW * i) * T + 16 * c + j] = v;
+        }
+      if (wave == 0 && lane < T) {
+        const int64_t n = n0 + lane;
+        ured[lane] = a.u ? (n < N ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+      }
+    }
     wg_sync();
     WSTAMP(5);
 #pragma unroll
@@ -508,6 +531,58 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
       for (int w = 1; w < NW; ++w) { v += red[(NW + w) * T + 16 * c + j]; u += red[(2 * NW + w) * T + 16 * c + j]; }
       ssum[c] = v; ssel[c] = u;
     }
+    if (gibbs) {
+      int cnt[2] = {0, 0};
+      double ctot[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // totals in row-block order (this is E_K); prefix of the blocks in front of each of this wave's blocks
+        double run = 0.0, base[RBW];
+        for (int rb = 0; rb < K16; ++rb) {
+#pragma unroll
+          for (int i = 0; i < RBW; ++i) base[i] = rb == wave + NW * i ? run : base[i];
+          run += rbs[rb * T + 16 * c + j];
+        }
+        ctot[c] = run;
+        const double tl = ured[16 * c + j] * run;
+#pragma unroll
+        for (int i = 0; i < RBW; ++i) {
+          if (wave + NW * i < K16) {
+            double carry = base[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double e = acc[i][c][r];
+              double p = e;                        // inclusive scan over the four q lanes
+              double t = __shfl_up(p, 16); if (q >= 1) p += t;
+              t = __shfl_up(p, 32);        if (q >= 2) p += t;
+              cnt[c] += tl > carry + p ? 1 : 0;
+              double rs = e; rs += __shfl_xor(rs, 16); rs += __shfl_xor(rs, 32);
+              carry += rs;
+            }
+          }
+        }
+        cnt[c] += __shfl_xor(cnt[c], 16);
+        cnt[c] += __shfl_xor(cnt[c], 32);
+      }
+      if (q == 0) { cred[wave * T + j] = cnt[0]; cred[wave * T + 16 + j] = cnt[1]; }
+      wg_sync();
+      if (wave == 0 && q == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int64_t n = n0 + 16 * c + j;
+          if (n < N) {
+            int tot = cred[16 * c + j];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) tot += cred[w * T + 16 * c + j];
+            if (a.labels) a.labels[n] = tot < K ? tot : K - 1;
+            const double lse = m[c] + log(ctot[c]);
+            sc_lse += lse;
+            sc_rl += ssel[c] / ctot[c];
+            if (a.lse) a.lse[n] = lse;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int64_t n = n0 + 16 * c + j;
@@ -530,6 +605,7 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
             if (k < K) a.resp[(int64_t)k * N + n] = acc[i][c][r] * inv;
           }
       }
+    }
     }
     __builtin_amdgcn_s_setprio(0);
     WSTAMP(6);
@@ -605,11 +681,12 @@ bool wide_estep_covers(int K16, int D, int F16) {
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
   const int ZS = (D + 2) | 1, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
-  return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * (CF + 2) + 3 * 4 * kTile + 64) + sizeof(uint32_t) * (size_t)nchunk * CF;
+  return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * (CF + 2) + 3 * 4 * kTile + 16 * kTile + kTile + 64) +
+         sizeof(int) * 4 * kTile + sizeof(uint32_t) * (size_t)nchunk * CF;
 }
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  if (a.gibbs || a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 <= kWideEstepCF) return hipErrorInvalidValue;
+  if (a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 <= kWideEstepCF) return hipErrorInvalidValue;
   fn_t fn = a.K16 > 8 ? wide_estep_kernel<4> : a.K16 > 4 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
   const size_t lds = wide_estep_lds_bytes(a.D, a.F16);
   if (lds > 80 * 1024) return hipErrorInvalidValue;
