@@ -1,4 +1,4 @@
-"""Stress: the round-2 kernels (small-shape kernel, row-owner label kernel, label statistics) launched many times on
+"""Stress: the round-2 kernels (small-shape kernel, row-owner label kernel, label statistics, wide E-step / statistics) launched many times on
 several shapes — every launch must return the bits of the first one and agree with the oracle (labels exact).
     python tools/stress_round2.py [launches]"""
 import os, sys
@@ -11,7 +11,9 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 eng = HipEngine(0)
 bad = 0
 for (N, D, K) in ((3 * 1024 * 256 + 5, 2, 4), (400003, 2, 25), (300007, 4, 16), (3 * 8 * 256 * 16 + 9, 8, 256), (500009, 8, 64),
-                  (400001, 5, 16), (350003, 9, 130), (200003, 1, 32), (300011, 16, 64), (250007, 12, 128), (200009, 13, 20)):
+                  (400001, 5, 16), (350003, 9, 130), (200003, 1, 32), (300011, 16, 64), (250007, 12, 128), (200009, 13, 20),
+                  # two-stage shapes on the wide kernels (mimo_wide.hip)
+                  (150011, 32, 128), (120007, 16, 200), (130003, 24, 100), (100003, 20, 72)):
     rng = np.random.default_rng(N % 1000 + D + K)
     Z = rng.standard_normal((N, D)) * 1.5; A = rng.standard_normal((K, D, D))
     W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D); mu = rng.standard_normal((K, D)) * 2
