@@ -458,7 +458,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
-  const bool lstats = !small && ((src == kSrcLabels && D <= 16 && label_stats_covers(K, D, ctx->structure)) || rowwave);
+  const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave);
   const int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
                    : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
@@ -552,7 +552,16 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
         st.resp = ctx->table_tmp;
       }
     }
-    if (a.do_stats) {
+    if (a.do_stats && stats_src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) {
+      // label-indexed statistics of the labels just drawn: the HBM-bound pass instead of one-hot products per column group
+      KernelArgs g = st;
+      g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
+      rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
+        HIP_TRY(ctx, launch_label_stats(g, ctx->structure, grid, ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
+    } else if (a.do_stats) {
       const bool wide = stats_src == kSrcWeights && wide_stats_covers(a.K16, D);     // 8-wave statistics kernel (mimo_wide.hip)
       const int gmax = wide ? wide_stats_group_ncb(a.K16, ncb_total) : stats_group_ncb(a.K16);
       for (int cb0 = 0; cb0 < ncb_total; cb0 += gmax) {
@@ -1338,8 +1347,12 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
     out8[0] = MIMO_PLAN_TWO_STAGE; out8[1] = 1 + groups;
     out8[2] = gibbs ? 0 : 1;             // the (K, N) responsibility table goes through HBM
     out8[3] = gibbs ? 0 : groups;        // and is read once per statistics launch
-    out8[4] = 1 + groups;                // Z: the chunked E-step + every statistics launch
+    out8[4] = 1 + groups;                // Z: the E-step + every statistics launch
     out8[5] = gibbs ? 1 + groups : 0;
+    if (gibbs && label_stats_covers(K, ctx->D, ctx->structure)) {      // label-indexed statistics (as run_pass)
+      const int ll = label_stats_launches(K, ctx->D, ctx->structure);
+      out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
+    }
     out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
   }
   out8[7] = ctx->num_cu;

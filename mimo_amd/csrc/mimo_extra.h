@@ -30,6 +30,9 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
 bool wide_estep_covers(int K16, int D, int F16);
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 
+// label statistics (mimo_rowwave.hip): launches of one pass — 1, or the slice groups of the Dz > 16 / large-K kernel
+int label_stats_launches(int K, int D, int structure);
+
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;
 bool vi_rowwave_covers(int K, int F16, int ZS);

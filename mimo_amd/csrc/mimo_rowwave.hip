@@ -954,10 +954,211 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same pass where label_stats_wide_kernel's accumulators no longer fit: Dz = 17 .. 32 (F up to 561), and K > 64
+// (K > 128 at Dz <= 12) at Dz = 10 .. 16.  The upper triangle is cut into FPT interleaved slices (FPT = 4 up to Dz = 16,
+// 16 above: at most 51 accumulators per thread next to the 32 registers that carry the next tile), a launch takes the min(FPT, 256 / Kp) slices [s0, s0 + FPL) that its
+// 256 / Kp threads per component can hold, and the host launches FPT / FPL times into the same partial block (each launch
+// reads Z once: 8 N Dz bytes — Dz = 32, K = 128: 8 launches, 4 GB per 2e6 rows, against 6 one-hot MFMA launches of the tile
+// kernel before).  The row of a member is read from the LDS tile per product instead of being copied to registers first
+// (z_i once per triangle row, z_j per product: 8 F / FPT bytes of LDS reads per thread and member).
+// ------------------------------------------------------------------------------------------
+template <int DZ, int FPT, int S, int MAXA>
+__device__ __forceinline__ void slice_accumulate_lds(double (&acc)[MAXA], const double* __restrict__ zp) {
+  int a = 0;
+#pragma unroll
+  for (int i = S; i < DZ; i += FPT) {
+    const double zi = zp[i];
+#pragma unroll
+    for (int j = i; j < DZ; ++j) { acc[a] = fma(zi, zp[j], acc[a]); ++a; }
+    acc[a] += zi; ++a;
+  }
+  if constexpr (S == 0) acc[a] += 1.0;
+}
+template <int DZ>
+__global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelArgs a) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
+  constexpr int FPT = DZ <= 16 ? 4 : 16;
+  constexpr int ZS = DZ | 1;                                  // odd: members' rows are arbitrary, a column is conflict-free
+  constexpr int T = kLsWideTile, NW = T / 32;
+  constexpr int ZPT = (T * DZ + kWG - 1) / kWG;
+  constexpr int MAXA = slice_count(DZ, FPT, 0);               // slice 0 is the largest
+  extern __shared__ __align__(16) unsigned char smem_ls[];
+  double* Zt = reinterpret_cast<double*>(smem_ls);                                   // [T][ZS]; the epilogue's red[kWG * 8] aliases it
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(Zt + (T * ZS > kWG * 8 ? T * ZS : kWG * 8));   // [kWG][NW]
+  int* start = reinterpret_cast<int*>(bitmap + kWG * NW);                            // [kWG + 1]
+  int* cnts = start + kWG + 1;                                                       // [kWG]
+  int* wsum = cnts + kWG;                                                            // [4]
+  uint16_t* list = reinterpret_cast<uint16_t*>(wsum + 4);                            // [T]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T;
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;                                    // K <= 256 = kWG
+  const int P = kWG / Kp;                                     // threads per component
+  const int FPL = P < FPT ? P : FPT, RP = P / FPL;            // slices of this launch, row parts per (component, slice)
+  const int myk = tid & (Kp - 1), part = tid / Kp, fslice = part % FPL, rpart = part / FPL;
+  const int myslice = a.cb0 + fslice;                         // (uniform per wave when Kp >= 64)
+
+  double acc[MAXA];
+#pragma unroll
+  for (int i = 0; i < MAXA; ++i) acc[i] = 0.0;
+
+  double zr[ZPT];
+  int lab;
+  auto load_tile = [&](int64_t t) {
+    const int64_t base = t * T * DZ, total = N * DZ;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + (int64_t)kWG * i;
+      zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+    }
+    const int64_t n = t * T + tid;
+    const int l = n < N ? a.labels[n] : -1;
+    lab = l < K ? l : -1;
+  };
+  if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    wg_sync();
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int e = tid + kWG * i;
+      if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
+    }
+    {
+      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
+    }
+    const int l0 = lab;
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+    wg_sync();
+    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+    wg_sync();
+    int cntk = 0;
+    {
+      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) {
+        const uint4 v = bm[w];
+        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    start[tid] = off + incl - cntk;
+    cnts[tid] = cntk;
+    wg_sync();
+    if (l0 >= 0) {
+      const uint32_t* bm = bitmap + l0 * NW;
+      const int wq = tid >> 5;
+      int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
+      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+      list[start[l0] + rank] = (uint16_t)tid;
+    }
+    wg_sync();
+    const int st = start[myk], cmine = cnts[myk];
+    if (myslice < FPT)
+      for (int p = rpart; p < cmine; p += RP)
+      {
+        const double* zp = Zt + (int)list[st + p] * ZS;
+        switch (myslice) {      // (explicit cases: a recursive template dispatch left acc[] in scratch)
+#define MIMO_SL(S) case S: if constexpr (S < FPT) slice_accumulate_lds<DZ, FPT, S, MAXA>(acc, zp); break;
+          MIMO_SL(0) MIMO_SL(1) MIMO_SL(2) MIMO_SL(3) MIMO_SL(4) MIMO_SL(5) MIMO_SL(6) MIMO_SL(7)
+          MIMO_SL(8) MIMO_SL(9) MIMO_SL(10) MIMO_SL(11) MIMO_SL(12) MIMO_SL(13) MIMO_SL(14) MIMO_SL(15)
+#undef MIMO_SL
+          default: break;
+        }
+      }
+  }
+
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P_out = a.partials + (size_t)blockIdx.x * pstride;
+  if (RP > 1) {          // add the row parts of every (component, slice) in part order, eight accumulators at a time
+    double* red = Zt;
+#pragma unroll
+    for (int f0 = 0; f0 < MAXA; f0 += 8) {
+      wg_sync();
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (f0 + i < MAXA) red[tid * 8 + i] = acc[f0 + i];
+      wg_sync();
+      if (rpart == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (f0 + i < MAXA) {
+            double s = acc[f0 + i];
+            for (int qq = 1; qq < RP; ++qq) s += red[((qq * FPL + fslice) * Kp + myk) * 8 + i];
+            acc[f0 + i] = s;
+          }
+        }
+      }
+    }
+  }
+  // rows of the partial block without a component (first launch)
+  if (a.cb0 == 0)
+    for (int k = K + tid; k < a.K16 * 16; k += kWG)
+      for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
+  if (rpart == 0 && myk < K && myslice < FPT) {
+    double* Pk = P_out + (size_t)myk * FT;
+    // accumulator a of slice s -> feature index (the order of slice_accumulate_lds: rows i = s, s + FPT, ... of the
+    // triangle, each with its DZ - i products and the linear term; slice 0 ends with the count).  Computed at run time:
+    // a switch over the slices around unrolled stores kept every accumulator live in all 16 cases (3 KB of scratch).
+    auto dest = [&](int aidx) -> int {
+      int base = 0;
+      for (int i = myslice; i < DZ; i += FPT) {
+        const int len = DZ - i + 1;
+        if (aidx < base + len) return i * (DZ + 1) - i * (i - 1) / 2 + (aidx - base);
+        base += len;
+      }
+      return (myslice == 0 && aidx == base) ? F - 1 : -1;
+    };
+#pragma unroll
+    for (int ai = 0; ai < MAXA; ++ai) {
+      const int d = dest(ai);
+      if (d >= 0) Pk[d] = acc[ai];
+    }
+  }
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = P_out + (size_t)a.K16 * 16 * FT;
+    Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
+  }
+}
+
+static bool xwide_on() {
+  static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_XWIDE"); return !e || atoi(e) != 0; }();   // tuning knob
+  return on;
+}
+// wide kernel: 4 feature slices up to K = 64, 2 up to K = 128 (Dz <= 12); everything else of the full map: sliced launches
+static bool label_stats_wide_covers(int K, int D) { return D >= 10 && D <= 16 && (K <= 64 || (K <= 128 && D <= 12)); }
 bool label_stats_covers(int K, int D, int structure) {
-  if (K < rowwave_min_k() || K > 256 || D < 1 || D > 16) return false;
-  if (D <= 9 || structure != 0) return true;     // reduced maps (diagonal / linear): at most 2 Dz + 1 accumulators
-  return K <= 64 || (K <= 128 && D <= 12);      // wide kernel: 4 feature slices up to K = 64, 2 up to K = 128 (Dz <= 12)
+  if (K < rowwave_min_k() || K > 256 || D < 1) return false;
+  if (structure != 0) return D <= 16;            // reduced maps (diagonal / linear): at most 2 Dz + 1 accumulators
+  if (D <= 9 || label_stats_wide_covers(K, D)) return true;
+  return xwide_on() && D <= kMaxD;
+}
+
+// launches of one statistics pass (each reads Z once): 1, or the slice groups of label_stats_xwide_kernel
+int label_stats_launches(int K, int D, int structure) {
+  if (structure != 0 || D <= 9 || label_stats_wide_covers(K, D)) return 1;
+  const int fpt = D <= 16 ? 4 : 16;
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;
+  const int P = kWG / Kp, fpl = P < fpt ? P : fpt;
+  return fpt / fpl;
 }
 
 int label_stats_grid(const KernelArgs& a, int num_cu) {
@@ -990,19 +1191,51 @@ static void (*pick_label_stats_struct(int D))(const KernelArgs) {
 }
 
 // structure: 0 full, 1 diagonal, 2 linear (MIMO_STRUCT_*)
+template <int DZ>
+static hipError_t launch_xwide(const KernelArgs& a, int grid, hipStream_t stream) {
+  constexpr int FPT = DZ <= 16 ? 4 : 16, ZS = DZ | 1, T = kLsWideTile;
+  const size_t zt = (size_t)(T * ZS > kWG * 8 ? T * ZS : kWG * 8);
+  const size_t lds = sizeof(double) * zt + sizeof(uint32_t) * kWG * (T / 32) + sizeof(int) * (2 * kWG + 1 + 4) + sizeof(uint16_t) * T;
+  auto fn = label_stats_xwide_kernel<DZ>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int Kp = 1;
+  while (Kp < a.K) Kp <<= 1;
+  const int P = kWG / Kp, FPL = P < FPT ? P : FPT;
+  for (int s0 = 0; s0 < FPT; s0 += FPL) {          // FPT / FPL launches into the same partial block
+    KernelArgs g = a;
+    g.cb0 = s0;
+    if (s0 > 0) g.write_scalars = 0;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, g);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// structure: 0 full, 1 diagonal, 2 linear (MIMO_STRUCT_*)
 hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  if (a.D < 1 || a.D > 16) return hipErrorInvalidValue;
+  if (a.D < 1 || a.D > kMaxD || a.K < 1 || a.K > 256) return hipErrorInvalidValue;
   fn_t fn = nullptr;
   if (structure == 1) fn = pick_label_stats_struct<1>(a.D);
   else if (structure == 2) fn = pick_label_stats_struct<2>(a.D);
   else if (a.D <= 9) fn = pick_label_stats_struct<0>(a.D);
-  else {
+  else if (label_stats_wide_covers(a.K, a.D)) {
     static const fn_t wide4[7] = {label_stats_wide_kernel<10, 4>, label_stats_wide_kernel<11, 4>, label_stats_wide_kernel<12, 4>,
                                   label_stats_wide_kernel<13, 4>, label_stats_wide_kernel<14, 4>, label_stats_wide_kernel<15, 4>,
                                   label_stats_wide_kernel<16, 4>};
     static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
-    fn = a.K <= 64 ? wide4[a.D - 10] : (a.K <= 128 && a.D <= 12) ? wide2[a.D - 10] : nullptr;
+    fn = a.K <= 64 ? wide4[a.D - 10] : wide2[a.D - 10];
+  } else {
+    switch (a.D) {
+#define MIMO_XW(d) case d: return launch_xwide<d>(a, grid, stream);
+      MIMO_XW(10) MIMO_XW(11) MIMO_XW(12) MIMO_XW(13) MIMO_XW(14) MIMO_XW(15) MIMO_XW(16) MIMO_XW(17) MIMO_XW(18) MIMO_XW(19)
+      MIMO_XW(20) MIMO_XW(21) MIMO_XW(22) MIMO_XW(23) MIMO_XW(24) MIMO_XW(25) MIMO_XW(26) MIMO_XW(27) MIMO_XW(28) MIMO_XW(29)
+      MIMO_XW(30) MIMO_XW(31) MIMO_XW(32)
+#undef MIMO_XW
+      default: return hipErrorInvalidValue;
+    }
   }
   if (!fn) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);

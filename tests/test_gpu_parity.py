@@ -683,6 +683,33 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
         assert not np.any(lab_o == K // 3) and So.n[K // 3] == 0 and So.n.sum() == N
 
 
+@pytest.mark.parametrize("D,K", [(32, 128), (20, 72), (24, 40), (17, 3), (32, 256), (28, 16), (16, 128), (13, 100), (10, 200),
+                                 (16, 256), (12, 129), (31, 64), (23, 33)])
+@pytest.mark.parametrize("N", [1, 300, 4099, 70001])
+def test_sliced_label_statistics(engine, D, K, N):
+    """Label-indexed statistics where one launch cannot hold a component's accumulators (Dz = 17 .. 32, and K > 64 at
+    Dz = 10 .. 16: label_stats_xwide_kernel, feature slices over several launches): after the label draw of the sweep
+    and for caller-supplied labels, against the oracle — labels and counts exact, statistics to 1e-11, identical bits on
+    a second launch, every row on one component / on three components."""
+    from oracle import mimo_oracle as O
+    rng = np.random.default_rng(1300 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K, gibbs=True)["kind"] in ("two-stage", "fused")
+    L = O.canonical_eval(Z, c, b, W)
+    lab_p, Sp = engine.gibbs_labels(c, b, W, seed=9, sweep=2)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(9, np.arange(N), 2))
+    assert np.array_equal(lab_p, ref_p)
+    n, sx, sxx = O.packed_stats(Z, O.one_hot(ref_p, K))
+    assert np.array_equal(Sp.n, n) and rel_err(Sp.sx, sx) < 1e-11 and rel_err(Sp.sxx, sxx) < 1e-11
+    lab_q, Sq = engine.gibbs_labels(c, b, W, seed=9, sweep=2)
+    assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx) and np.array_equal(Sq.sx, Sp.sx)
+    for lab_c in (np.full(N, K - 1), rng.choice([0, K // 2, K - 1], size=N), rng.integers(K, size=N)):
+        Sc = engine.label_stats(lab_c, K)
+        nc, sxc, sxxc = O.packed_stats(Z, O.one_hot(lab_c, K))
+        assert np.array_equal(Sc.n, nc) and rel_err(Sc.sx, sxc) < 1e-11 and rel_err(Sc.sxx, sxxc) < 1e-11
+
+
 def test_sample_discrete_from_log_function(engine):
     """mimo_amd.utils.stats.sample_discrete_from_log (mimo/utils/stats.py:8-21 of the reference) on a caller-supplied
     table: same draw as the reference's formula for the same numpy.random state, any axis, any leading shape, with and
