@@ -683,7 +683,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
         assert not np.any(lab_o == K // 3) and So.n[K // 3] == 0 and So.n.sum() == N
 
 
-@pytest.mark.parametrize("D,K", [(32, 128), (20, 72), (24, 40), (17, 3), (32, 256), (28, 16), (16, 128), (13, 100), (10, 200),
+@pytest.mark.parametrize("D,K", [(32, 128), (20, 72), (24, 40), (17, 17), (32, 256), (28, 24), (16, 128), (13, 100), (10, 200),
                                  (16, 256), (12, 129), (31, 64), (23, 33)])
 @pytest.mark.parametrize("N", [1, 300, 4099, 70001])
 def test_sliced_label_statistics(engine, D, K, N):
