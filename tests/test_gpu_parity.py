@@ -685,7 +685,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
 
 @pytest.mark.parametrize("D,K", [(32, 128), (20, 72), (24, 40), (17, 17), (32, 256), (28, 24), (16, 128), (13, 100), (10, 200),
                                  (16, 256), (12, 129), (31, 64), (23, 33)])
-@pytest.mark.parametrize("N", [1, 300, 4099, 70001])
+@pytest.mark.parametrize("N", [1, 4099, 20011])
 def test_sliced_label_statistics(engine, D, K, N):
     """Label-indexed statistics where one launch cannot hold a component's accumulators (Dz = 17 .. 32, and K > 64 at
     Dz = 10 .. 16: label_stats_xwide_kernel, feature slices over several launches): after the label draw of the sweep

@@ -25,3 +25,12 @@ grid = lib.mimo_debug_stamps_grid()
 tot = sum(out); ntile = (N + 31) // 32 / grid
 print(f"cycles per wave per tile: total {tot/ntile:.0f}")
 for n, v in zip(names, out): print(f"  {n:28s} {v/ntile:8.0f}  {100*v/tot:5.1f}%")
+tr = (C.c_ulonglong * 128)()
+if hasattr(lib, "mimo_debug_stamps_trace"):
+    lib.mimo_debug_stamps_trace.argtypes = [C.POINTER(C.c_ulonglong)]
+    if lib.mimo_debug_stamps_trace(tr) == 0 and any(tr):
+        t0 = min(v for v in tr if v)
+        print("wave 0 of workgroups 0 and grid/2: iteration: [tile start, build done + barrier, normalise done + barrier, tile end] cycles")
+        for it in range(16):
+            a = [tr[4 * it + i] - t0 for i in range(4)]; b = [tr[64 + 4 * it + i] - t0 for i in range(4)]
+            print(f"  it {it + 8:2d}  A {a[0]:7d} {a[1]:7d} {a[2]:7d} {a[3]:7d}   B {b[0]:7d} {b[1]:7d} {b[2]:7d} {b[3]:7d}")
