@@ -173,7 +173,11 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 #pragma unroll
       for (int i = 0; i < NCBL; ++i) {
         acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s], bv[i], acc[i], 0, 0, 0);
+#ifdef MIMO_WHATIF_HALF_B       // what-if build (wrong results): every second B operand is a copy of its neighbour -> half the LDS reads
+        if (s + 1 < 8) { if (i % 2 == 0) bv[i] = phq[(s + 1) * RS + 16 * CP * i]; else bv[i] = bv[i - 1]; }
+#else
         if (s + 1 < 8) bv[i] = phq[(s + 1) * RS + 16 * CP * i];   // operand of the next step: NCBL MFMAs ahead of its use
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);      // no hoisting of later steps' reads: 8 x NCBL operands do not fit
       if (s / 2 < NBATCH) {
@@ -674,10 +678,12 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) 
 
 bool wide_estep_covers(int K16, int D, int F16) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_ESTEP"); return !e || atoi(e) != 0; }();   // tuning knob
-  // (K16 <= 4: one row block per wave, half of the waves idle below K16 = 3 — measured 3 % slower than the chunked kernel)
   // F16 > one chunk: the z rows of the next tile are staged during the first chunk and read from the last one on
   // (reduced feature maps — diagonal, linear — of a wide Dz stay with the chunked kernel)
-  return on && D >= wide_min_d() && D <= kMaxD && K16 >= 5 && K16 <= 16 && F16 > kWideEstepCF;
+  // K16 = 4 (one row block per wave, all four busy): equal to the chunked kernel within +-5 % (Dz=32, K=64 2.89 / 2.89 ms,
+  // Dz=20, K=60 1.62 / 1.66; label draw 2.99 / 2.82, 1.78 / 1.54) — stays there; K16 = 3: Dz=28, K=40 2.33 against 2.72 ms
+  static const int min_k16 = [] { const char* e = getenv("MIMO_WIDE_ESTEP_MIN_K16"); return e ? atoi(e) : 5; }();   // tuning knob
+  return on && D >= wide_min_d() && D <= kMaxD && (K16 >= min_k16 || K16 == 3) && K16 <= 16 && F16 > kWideEstepCF;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
   const int ZS = (D + 2) | 1, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
