@@ -132,7 +132,9 @@ def _random_problem(rng, N, D, K):
                                     (3000, 24, 64), (1500, 17, 40), (999, 28, 100), (640, 20, 72), (4097, 32, 90),
                                     # ... and the same kernels at 10 <= Dz <= 16 with K > 64
                                     (3000, 16, 128), (2500, 14, 100), (1200, 16, 200), (900, 13, 256), (1000, 12, 128), (801, 10, 90),
-                                    (2222, 28, 40), (1111, 15, 35)])
+                                    (2222, 28, 40), (1111, 15, 35),
+                                    # ... ragged and tiny row counts through the same kernels
+                                    (1, 32, 128), (31, 20, 72), (33, 24, 100), (65, 16, 200), (0, 32, 128)])
 def test_engine_vs_oracle_seeded(engine, N, D, K):
     """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
     from oracle import mimo_oracle as O
