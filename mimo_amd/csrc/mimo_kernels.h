@@ -41,7 +41,7 @@ struct KernelArgs {
   int do_stats;
   int split;              // also accumulate sum_k r l (entropy split of the ELBO scalars)
   int64_t ntiles;
-  int cb0;                // statistics modes: first 16-wide feature column block of this launch
+  int cb0;                // statistics modes: first 16-wide feature column block of this launch (label_stats_xwide_kernel: first feature slice)
   int F16_total;          // padded feature count of the whole problem (partials row stride)
   int write_scalars;      // write the 4 scalar slots of the partial block (0: another launch owns them)
   int diag;               // feature table is a reduced one (diagonal: 2 Dz + 1, linear: Dz + 1 features): table-driven E-step kernels

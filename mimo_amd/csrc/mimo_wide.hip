@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 #pragma unroll
       for (int i = 0; i < NCBL; ++i) {
         acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s], bv[i], acc[i], 0, 0, 0);
-#ifdef MIMO_WHATIF_HALF_B       // what-if build (wrong results): every second B operand is a copy of its neighbour -> half the LDS reads
+#ifdef MIMO_WHATIF_HALF_B       // what-if build (wrong results): every second B operand is a copy of its neighbour -> half the LDS
+                                // reads: 1.522 -> 1.495 ms per launch at C5's shape, i.e. LDS operand traffic is not what bounds this kernel
         if (s + 1 < 8) { if (i % 2 == 0) bv[i] = phq[(s + 1) * RS + 16 * CP * i]; else bv[i] = bv[i - 1]; }
 #else
         if (s + 1 < 8) bv[i] = phq[(s + 1) * RS + 16 * CP * i];   // operand of the next step: NCBL MFMAs ahead of its use
