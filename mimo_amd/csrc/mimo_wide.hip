@@ -556,13 +556,15 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
             double carry = base[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+              // inclusive scan over the four q lanes and their total from ONE butterfly: s01 = the pair sum (e0 + e1 or
+              // e2 + e3), t2 = the other pair's; prefix = (q odd ? s01 : e) + (q >= 2 ? t2 : 0) — for q = 2 that is
+              // (e0 + e1) + e2, the order of the reference's cumulative sum
               const double e = acc[i][c][r];
-              double p = e;                        // inclusive scan over the four q lanes
-              double t = __shfl_up(p, 16); if (q >= 1) p += t;
-              t = __shfl_up(p, 32);        if (q >= 2) p += t;
+              const double s01 = e + __shfl_xor(e, 16);
+              const double t2 = __shfl_xor(s01, 32);
+              const double p = ((q & 1) ? s01 : e) + ((q & 2) ? t2 : 0.0);
               cnt[c] += tl > carry + p ? 1 : 0;
-              double rs = e; rs += __shfl_xor(rs, 16); rs += __shfl_xor(rs, 32);
-              carry += rs;
+              carry += s01 + t2;
             }
           }
         }
