@@ -957,10 +957,9 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
 // ------------------------------------------------------------------------------------------
 // The same pass where label_stats_wide_kernel's accumulators no longer fit: Dz = 17 .. 32 (F up to 561), and K > 64
 // (K > 128 at Dz <= 12) at Dz = 10 .. 16.  The upper triangle is cut into FPT interleaved slices (FPT = 4 up to Dz = 16,
-// 16 above: at most 51 accumulators per thread next to the 32 registers that carry the next tile), a launch takes the min(FPT, 256 / Kp) slices [s0, s0 + FPL) that its
+// 8 up to Dz = 29, 16 above: at most 76 accumulators per thread next to the 16 registers that carry the next 128-row tile), a launch takes the min(FPT, 256 / Kp) slices [s0, s0 + FPL) that its
 // 256 / Kp threads per component can hold, and the host launches FPT / FPL times into the same partial block (each launch
-// reads Z once: 8 N Dz bytes — Dz = 32, K = 128: 8 launches, 4 GB per 2e6 rows, against 6 one-hot MFMA launches of the tile
-// kernel before).  The row of a member is read from the LDS tile per product instead of being copied to registers first
+// reads Z once: 8 N Dz bytes — Dz = 32, K = 128: 8 launches, Dz = 28: 4 — against 6 one-hot MFMA launches of the tile kernel before).  The row of a member is read from the LDS tile per product instead of being copied to registers first
 // (z_i once per triangle row, z_j per product: 8 F / FPT bytes of LDS reads per thread and member).
 // ------------------------------------------------------------------------------------------
 template <int DZ, int FPT, int S, int MAXA>
@@ -975,12 +974,19 @@ __device__ __forceinline__ void slice_accumulate_lds(double (&acc)[MAXA], const 
   }
   if constexpr (S == 0) acc[a] += 1.0;
 }
-template <int DZ>
+// Feature slices FPT and rows per tile of the sliced label statistics.  4 slices x 256 rows up to Dz = 16.  Above: 8 slices
+// need the registers of half a prefetched tile, i.e. 128-row tiles (Dz = 24, K = 100: 1.25 -> 0.75 ms against 16 x 256) — but
+// half the rows per tile also halve the members per component, and a wave runs as long as its busiest lane: at Dz = 30 .. 32
+// (85 accumulators: a small spill on top) that costs more than it gives from K = 65 on (Dz = 32, K = 128: 1.87 against 1.51 ms;
+// K = 32: 0.70 against 0.84), so those shapes keep 16 x 256.
+constexpr int xwide_tile(int FPT) { return FPT == 8 ? kLsWideTile / 2 : kLsWideTile; }
+static int xwide_fpt(int D, int K) { return D <= 16 ? 4 : (D <= 29 || K <= 64) ? 8 : 16; }
+
+template <int DZ, int FPT>
 __global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelArgs a) {
   constexpr int F = (DZ + 1) * (DZ + 2) / 2;
-  constexpr int FPT = DZ <= 16 ? 4 : 16;
   constexpr int ZS = DZ | 1;                                  // odd: members' rows are arbitrary, a column is conflict-free
-  constexpr int T = kLsWideTile, NW = T / 32;
+  constexpr int T = xwide_tile(FPT), NW = T / 32;
   constexpr int ZPT = (T * DZ + kWG - 1) / kWG;
   constexpr int MAXA = slice_count(DZ, FPT, 0);               // slice 0 is the largest
   extern __shared__ __align__(16) unsigned char smem_ls[];
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelA
       zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
     }
     const int64_t n = t * T + tid;
-    const int l = n < N ? a.labels[n] : -1;
+    const int l = (tid < T && n < N) ? a.labels[n] : -1;
     lab = l < K ? l : -1;
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -1156,7 +1162,7 @@ bool label_stats_covers(int K, int D, int structure) {
 // launches of one statistics pass (each reads Z once): 1, or the slice groups of label_stats_xwide_kernel
 int label_stats_launches(int K, int D, int structure) {
   if (structure != 0 || D <= 9 || label_stats_wide_covers(K, D)) return 1;
-  const int fpt = D <= 16 ? 4 : 16;
+  const int fpt = xwide_fpt(D, K);
   int Kp = 1;
   while (Kp < K) Kp <<= 1;
   const int P = kWG / Kp, fpl = P < fpt ? P : fpt;
@@ -1193,12 +1199,12 @@ static void (*pick_label_stats_struct(int D))(const KernelArgs) {
 }
 
 // structure: 0 full, 1 diagonal, 2 linear (MIMO_STRUCT_*)
-template <int DZ>
+template <int DZ, int FPT>
 static hipError_t launch_xwide(const KernelArgs& a, int grid, hipStream_t stream) {
-  constexpr int FPT = DZ <= 16 ? 4 : 16, ZS = DZ | 1, T = kLsWideTile;
+  constexpr int ZS = DZ | 1, T = xwide_tile(FPT);
   const size_t zt = (size_t)(T * ZS > kWG * 8 ? T * ZS : kWG * 8);
   const size_t lds = sizeof(double) * zt + sizeof(uint32_t) * kWG * (T / 32) + sizeof(int) * (2 * kWG + 1 + 4) + sizeof(uint16_t) * T;
-  auto fn = label_stats_xwide_kernel<DZ>;
+  auto fn = label_stats_xwide_kernel<DZ, FPT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int Kp = 1;
@@ -1230,12 +1236,18 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
     static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
     fn = a.K <= 64 ? wide4[a.D - 10] : wide2[a.D - 10];
   } else {
+    const bool s8 = xwide_fpt(a.D, a.K) == 8;
     switch (a.D) {
-#define MIMO_XW(d) case d: return launch_xwide<d>(a, grid, stream);
-      MIMO_XW(10) MIMO_XW(11) MIMO_XW(12) MIMO_XW(13) MIMO_XW(14) MIMO_XW(15) MIMO_XW(16) MIMO_XW(17) MIMO_XW(18) MIMO_XW(19)
-      MIMO_XW(20) MIMO_XW(21) MIMO_XW(22) MIMO_XW(23) MIMO_XW(24) MIMO_XW(25) MIMO_XW(26) MIMO_XW(27) MIMO_XW(28) MIMO_XW(29)
-      MIMO_XW(30) MIMO_XW(31) MIMO_XW(32)
-#undef MIMO_XW
+#define MIMO_XW4(d) case d: return launch_xwide<d, 4>(a, grid, stream);
+#define MIMO_XW8(d) case d: return launch_xwide<d, 8>(a, grid, stream);
+#define MIMO_XWB(d) case d: return s8 ? launch_xwide<d, 8>(a, grid, stream) : launch_xwide<d, 16>(a, grid, stream);
+      MIMO_XW4(10) MIMO_XW4(11) MIMO_XW4(12) MIMO_XW4(13) MIMO_XW4(14) MIMO_XW4(15) MIMO_XW4(16)
+      MIMO_XW8(17) MIMO_XW8(18) MIMO_XW8(19) MIMO_XW8(20) MIMO_XW8(21) MIMO_XW8(22) MIMO_XW8(23) MIMO_XW8(24) MIMO_XW8(25)
+      MIMO_XW8(26) MIMO_XW8(27) MIMO_XW8(28) MIMO_XW8(29)
+      MIMO_XWB(30) MIMO_XWB(31) MIMO_XWB(32)
+#undef MIMO_XW4
+#undef MIMO_XW8
+#undef MIMO_XWB
       default: return hipErrorInvalidValue;
     }
   }
