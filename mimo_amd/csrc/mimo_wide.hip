@@ -43,8 +43,10 @@ constexpr int kWideNCBL = 12;      // accumulator column blocks per wave, at mos
 
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte load of an 8-byte aligned address
 
-template <int RBN, int NCBL>
+template <int RBN, int NCBL, int RBW = 1>
 __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a) {
+  // RBW row blocks per wave (rb, rb + RBN, ...): K <= 128 runs RBW = 1; K <= 256 RBW = 2 with RBN = 8 — every B operand
+  // then feeds two MFMAs, at twice the weight registers
   constexpr int T = kTile, CP = 8 / RBN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,21 +102,29 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 
   // matrix role of this wave
   const int rb = wave % RBN, cpart = wave / RBN;
-  const int kcomp = 16 * rb + j;
-  const double* wrow = a.resp + (int64_t)(kcomp < K ? kcomp : K - 1) * N;
-  // A operands of one tile: rows 8q .. 8q+7 of this lane's component, 64 contiguous bytes
-  auto load_w = [&](int64_t t, double (&w)[8]) {
-    const double* p = wrow + (t < last_tile ? t : last_tile) * T + 8 * q;
+  const double* wrow[RBW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const d2u v = *reinterpret_cast<const d2u*>(p + 2 * i);
-      w[2 * i] = v[0]; w[2 * i + 1] = v[1];
-    }
+  for (int r = 0; r < RBW; ++r) {
+    const int kcomp = 16 * (rb + RBN * r) + j;
+    wrow[r] = a.resp + (int64_t)(kcomp < K ? kcomp : K - 1) * N;
+  }
+  // A operands of one tile: rows 8q .. 8q+7 of this lane's component(s), 64 contiguous bytes each
+  auto load_w = [&](int64_t t, double (&w)[RBW][8]) {
+    const int64_t off = (t < last_tile ? t : last_tile) * T + 8 * q;
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const d2u v = *reinterpret_cast<const d2u*>(wrow[r] + off + 2 * i);
+        w[r][2 * i] = v[0]; w[r][2 * i + 1] = v[1];
+      }
   };
 
-  d4 acc[NCBL];
+  d4 acc[RBW][NCBL];
 #pragma unroll
-  for (int i = 0; i < NCBL; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < RBW; ++r)
+#pragma unroll
+    for (int i = 0; i < NCBL; ++i) acc[r][i] = d4{0.0, 0.0, 0.0, 0.0};
 
   // feature build: thread (row, fgrp) makes feature column fgrp of every column block, in batches of <= 6 features
   // whose operand reads (after matrix step 2b) and product stores (after step 2b + 1) sit BETWEEN the matrix steps of
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
   static_assert(NBATCH <= 4, "two matrix steps per batch");
   double* Ph1 = Ph + T * RS;                         // second feature tile
 
-  double wa[8], wb[8];
+  double wa[RBW][8], wb[RBW][8];
   // this thread's (a, b) byte offsets stay in registers: a table read inside the matrix phase would put an LDS round
   // trip (s_waitcnt in the in-order instruction stream) in front of the following MFMAs
   uint32_t w2[NBF];
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
   int cur = 0;
   // iteration i (tile t): matrix steps on Phi(t) in Ph[cur]; Phi(t + G) built from Zs[cur ^ 1] into Ph[cur ^ 1];
   // z~(t + 2G) staged into Zs[cur]; z(t + 3G) fetched
-  auto tile = [&](int64_t t, double (&wc)[8], double (&wn)[8]) {
+  auto tile = [&](int64_t t, double (&wc)[RBW][8], double (&wn)[RBW][8]) {
     const double* Pc = cur ? Ph1 : Ph;
     double* Pn = cur ? Ph : Ph1;
     const double* Zn = Zs + (cur ^ 1) * T * ZS;
@@ -172,13 +182,12 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
       // B lane (kk = q, col j) = Phi[8q + s][16 cb + j]
 #pragma unroll
       for (int i = 0; i < NCBL; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s], bv[i], acc[i], 0, 0, 0);
-#ifdef MIMO_WHATIF_HALF_B       // what-if build (wrong results): every second B operand is a copy of its neighbour -> half the LDS
-                                // reads: 1.522 -> 1.495 ms per launch at C5's shape, i.e. LDS operand traffic is not what bounds this kernel
-        if (s + 1 < 8) { if (i % 2 == 0) bv[i] = phq[(s + 1) * RS + 16 * CP * i]; else bv[i] = bv[i - 1]; }
-#else
-        if (s + 1 < 8) bv[i] = phq[(s + 1) * RS + 16 * CP * i];   // operand of the next step: NCBL MFMAs ahead of its use
-#endif
+#pragma unroll
+        for (int r = 0; r < RBW; ++r) acc[r][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[r][s], bv[i], acc[r][i], 0, 0, 0);
+        // operand of the next step: NCBL MFMAs ahead of its use.  (What-if: with every second operand a copy of its
+        // neighbour — half the LDS reads, wrong results — a launch at C5's shape took 1.495 instead of 1.522 ms: LDS
+        // operand traffic is not what bounds this kernel.)
+        if (s + 1 < 8) bv[i] = phq[(s + 1) * RS + 16 * CP * i];
       }
       __builtin_amdgcn_sched_barrier(0);      // no hoisting of later steps' reads: 8 x NCBL operands do not fit
       if (s / 2 < NBATCH) {
@@ -236,10 +245,13 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int64_t n = n0 + 8 * q + s;
-      const double w = n < N ? wrow[n] : 0.0;
 #pragma unroll
-      for (int i = 0; i < NCBL; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, phq[s * RS + 16 * CP * i], acc[i], 0, 0, 0);
+      for (int r = 0; r < RBW; ++r) {
+        const double w = n < N ? wrow[r][n] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NCBL; ++i)
+          acc[r][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, phq[s * RS + 16 * CP * i], acc[r][i], 0, 0, 0);
+      }
     }
   }
 
@@ -247,15 +259,19 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
   const int FT = a.F16_total, Kpad = 16 * K16;
   const size_t pstride = (size_t)Kpad * FT + 4;
   double* P = a.partials + (size_t)blockIdx.x * pstride + 16 * a.cb0;
-  if (rb < K16) {
 #pragma unroll
-    for (int i = 0; i < NCBL; ++i) {
-      const int cb = cpart + CP * i;
-      if (cb < ncb) {
+  for (int rr = 0; rr < RBW; ++rr) {
+    const int rbi = rb + RBN * rr;
+    if (rbi < K16) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * rb + q + 4 * r;
-          P[(size_t)k * FT + 16 * cb + j] = k < K ? acc[i][r] : 0.0;
+      for (int i = 0; i < NCBL; ++i) {
+        const int cb = cpart + CP * i;
+        if (cb < ncb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rbi + q + 4 * r;
+            P[(size_t)k * FT + 16 * cb + j] = k < K ? acc[rr][i][r] : 0.0;
+          }
         }
       }
     }
@@ -642,11 +658,13 @@ static int wide_min_d() {
 }
 bool wide_stats_covers(int K16, int D) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_STATS"); return !e || atoi(e) != 0; }();   // tuning knob
-  return on && D >= wide_min_d() && D <= kMaxD && K16 >= 3 && K16 <= 8;
+  return on && D >= wide_min_d() && D <= kMaxD && K16 >= 3 && K16 <= 16;
 }
 // column blocks per launch: as few launches as 12 blocks per wave allow, of equal size
 int wide_stats_group_ncb(int K16, int ncb_total) {
-  const int cp = K16 > 4 ? 1 : 2, cap = (K16 > 4 ? kWideNCBL : 8) * cp;    // two feature tiles of 32 x (16 cap + 2) doubles in LDS
+  // accumulator blocks per wave: 12 (K <= 128), 8 (K <= 64: two feature tiles of 32 x (16 * 16 + 2) doubles in LDS), 6 x 2 row
+  // blocks (K <= 256)
+  const int cp = K16 > 4 ? 1 : 2, cap = (K16 > 8 ? 6 : K16 > 4 ? kWideNCBL : 8) * cp;
   const int launches = (ncb_total + cap - 1) / cap;
   return (ncb_total + launches - 1) / launches;
 }
@@ -663,7 +681,10 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) 
   const int ncb = a.F16 / 16, cp = a.K16 > 4 ? 1 : 2;
   if (ncb < 1 || ncb > (cp == 1 ? kWideNCBL : 16) || a.D * kTile > 2 * kWideWG) return hipErrorInvalidValue;
   fn_t fn = nullptr;
-  switch (wide_ncbl(a.K16, ncb)) {
+  if (a.K16 > 8) {
+    if (ncb > 6) return hipErrorInvalidValue;
+    fn = wide_ncbl(a.K16, ncb) == 4 ? wide_stats_kernel<8, 4, 2> : wide_stats_kernel<8, 6, 2>;
+  } else switch (wide_ncbl(a.K16, ncb)) {
     case 4: fn = cp == 1 ? wide_stats_kernel<8, 4> : wide_stats_kernel<4, 4>; break;
     case 6: fn = cp == 1 ? wide_stats_kernel<8, 6> : wide_stats_kernel<4, 6>; break;
     case 8: fn = cp == 1 ? wide_stats_kernel<8, 8> : wide_stats_kernel<4, 8>; break;
