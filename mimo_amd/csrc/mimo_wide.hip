@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 //   * the Theta slices stream from the L2-resident image through a 6-deep register ring (what-if build: serving every
 //     slice from one cache line changes nothing, so L2 is not the bound);
 //   * the feature tile is built chunk by chunk (96 features = 24 contraction steps) into a double buffer: table
-//     offsets after matrix step 2, operand reads after step 8, products and stores after step 16 of the PREVIOUS
+//     offsets after matrix step 2, operand reads after steps 6 / 14, products and stores after steps 10 / 18 of the PREVIOUS
 //     chunk — one barrier per chunk, no LDS round trip in front of an MFMA, z rows two tiles ahead in registers;
 //     what is left of a chunk barrier's bubble is filled by the other workgroup of the CU (an 8-wave variant of
 //     this kernel, one workgroup per CU, stalled all eight waves there: 16 % of the tile time in barrier waits);
@@ -356,24 +356,26 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
 
   // feature build of one chunk: thread (row, fgrp) makes columns fgrp and fgrp + 8 of each of the 6 column blocks
   const int frow = tid & (T - 1), fgrp = tid >> 5;
+  // (in two halves of NBF / 2: the operands of a half live in registers for four matrix steps)
+  constexpr int NBH = NBF / 2;
   uint32_t w2[NBF];
-  double za[NBF], zb[NBF];
+  double za[NBH], zb[NBH];
   auto build_offsets = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < NBF; ++i) w2[i] = fo[ch * CF + 8 * i + fgrp];
   };
-  auto build_loads = [&](const double* zb_) {
+  auto build_loads = [&](int h, const double* zb_) {
     const unsigned char* zrow = reinterpret_cast<const unsigned char*>(zb_ + frow * ZS);
 #pragma unroll
-    for (int i = 0; i < NBF; ++i) {
-      za[i] = *reinterpret_cast<const double*>(zrow + (w2[i] & 0xFFFFu));
-      zb[i] = *reinterpret_cast<const double*>(zrow + (w2[i] >> 16));
+    for (int i = 0; i < NBH; ++i) {
+      za[i] = *reinterpret_cast<const double*>(zrow + (w2[h * NBH + i] & 0xFFFFu));
+      zb[i] = *reinterpret_cast<const double*>(zrow + (w2[h * NBH + i] >> 16));
     }
   };
-  auto build_stores = [&](double* pb_) {
+  auto build_stores = [&](int h, double* pb_) {
     double* prow = pb_ + frow * RSc + fgrp;
 #pragma unroll
-    for (int i = 0; i < NBF; ++i) prow[8 * i] = za[i] * zb[i];
+    for (int i = 0; i < NBH; ++i) prow[8 * (h * NBH + i)] = za[i] * zb[i];
   };
 
   // Theta stream of this wave: element e = s * RBW + i of a tile is slice s of row block wave + 4 i (a row block past
@@ -400,8 +402,10 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
     for (int e = 0; e < PF; ++e) ring[e] = slice(0, e);
     wg_sync();
     build_offsets(0);
-    build_loads(Zs);
-    build_stores(Ph);
+    build_loads(0, Zs);
+    build_stores(0, Ph);
+    build_loads(1, Zs);
+    build_stores(1, Ph);
     wg_sync();
   }
   int cur = 0, pbuf = 0;
@@ -443,8 +447,10 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 2) { build_offsets(nch); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 8) { build_loads(Zn); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 16) { build_stores(Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 6) { build_loads(0, Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 10) { build_stores(0, Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 14) { build_loads(1, Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 18) { build_stores(1, Pn); __builtin_amdgcn_sched_barrier(0); }
       }
       if (ch == 0) {                          // z~ of the next tile: read from the last chunk on
         store_z(t + G, Zs + (cur ^ 1) * T * ZS);
