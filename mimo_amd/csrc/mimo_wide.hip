@@ -1,6 +1,7 @@
-// Wide shapes (Dz > 16: the two-stage path): statistics S = R . Phi of a K-major weight table.
+// The two-stage shapes (Dz > 16, or K > 64 at Dz >= 10): E-step and statistics kernels without latency-bound phases.
 //
-// Why a second kernel next to fused_kernel<.., kModeWeights>: at Dz = 32, K = 128 that one runs as two 4-wave
+// wide_stats_kernel: statistics S = R . Phi of a K-major weight table.  Why a second kernel next to
+// fused_kernel<.., kModeWeights>: at Dz = 32, K = 128 that one runs as two 4-wave
 // workgroups per CU, each staging a 32 x 128 weight tile through LDS and building 6 column blocks of features per
 // tile, 6 launches per sweep.  The per-phase trace (tools/stamps_chunked.py) shows the two workgroups of a CU in lock
 // step: both wait out the weight tile's HBM round trip and the feature build's LDS chains together (5.1k cycles,
@@ -8,13 +9,15 @@
 // start-up stagger do not separate them (a build that overlaps the neighbour's matrix phase gets one VALU issue slot
 // per 64-cycle MFMA and falls back into step), so the idle phase itself has to go:
 //   * ONE 8-wave workgroup per CU; wave w owns row block w % RBN and every CP-th column block (CP = 8 / RBN) of the
-//     launch: 12 accumulator blocks per wave, 12 (RBN = 8) or 24 (RBN = 4) column blocks per launch — the table is
-//     read 3 x (K = 128, Dz = 32) instead of 6 x, Z four times instead of seven;
+//     launch: up to 12 accumulator blocks per wave, 12 (RBN = 8) or 16 (RBN = 4) column blocks per launch — the table is
+//     read 3 x (K = 128, Dz = 32) instead of 6 x, Z four times instead of seven; 128 < K <= 256: two row blocks per wave;
 //   * the weights never touch LDS: lane (j, q) of the wave that owns row block rb loads the 8 consecutive rows
 //     8q .. 8q+7 of component 16 rb + j — 64 contiguous bytes — and register s IS the MFMA A operand of contraction
 //     step s (rows s, s+8, s+16, s+24); the next tile's 8 registers are in flight during this tile's matrix phase;
-//   * z rows travel two tiles ahead in registers (double-buffered z tile), so the build phase is LDS-only: 2 barriers
-//     per tile, no global latency on the critical path.
+//   * z rows travel ahead in registers (double-buffered z tile) and the NEXT tile's features are built between this
+//     tile's matrix steps into a second feature tile: one barrier per tile, no global or LDS round trip in front of an
+//     MFMA; the tile loop is branch-free (clamped addresses instead of bounds tests).
+// wide_estep_kernel (below): the softmax / label-draw pass that writes the table or the labels.
 // Partial blocks, feature table and reduction are those of the tile kernels (mimo_kernels.hip).
 #include "mimo_device.h"
 #include "mimo_extra.h"
