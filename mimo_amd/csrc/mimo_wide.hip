@@ -387,10 +387,10 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
 #pragma unroll
   for (int i = 0; i < RBW; ++i) {
     const int rbi = wave + NW * i < K16 ? wave + NW * i : K16 - 1;
-    thb[i] = (gptr_t)(a.theta + (size_t)rbi * NSP * 64 + lane);
+    thb[i] = (gptr_t)(a.theta + (size_t)rbi * NSP * 64);       // scalar base: the loads use base + lane offset + immediate
   }
   auto slice = [&](int ch, int ee) {          // element ee (0 .. NSc RBW - 1) of chunk ch
-    return thb[ee % RBW][((size_t)ch * NSc + ee / RBW) * 64];
+    return thb[ee % RBW][((size_t)ch * NSc + ee / RBW) * 64 + lane];
   };
   double ring[PF];
   double sc_lse = 0.0, sc_rl = 0.0;
@@ -427,6 +427,20 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
       const double* Zn = Zs + (last ? cur ^ 1 : cur) * T * ZS;             // ... from this tile's rows or the next tile's
       const double* Pc = Ph + pbuf * T * RSc;
       double* Pn = Ph + (pbuf ^ 1) * T * RSc;
+      // scalar bases of this chunk's Theta slices and of the first of the next chunk's, one per window of 8 slices
+      // (forced into SGPRs: a load is then base + lane offset + an immediate below 4 KB, not a 64-bit VALU address)
+      constexpr int NWIN = (NSc + 7) / 8;
+      gptr_t cbase[RBW][NWIN], nbase[RBW];
+#pragma unroll
+      for (int i = 0; i < RBW; ++i) {
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+          cbase[i][w] = thb[i] + ((size_t)ch * NSc + 8 * w) * 64;
+          asm volatile("" : "+s"(cbase[i][w]));
+        }
+        nbase[i] = thb[i] + (size_t)nch * NSc * 64;
+        asm volatile("" : "+s"(nbase[i]));
+      }
       int p_off = j * RSc + q;
       asm volatile("" : "+v"(p_off));
       const double* p0 = Pc + p_off;
@@ -444,7 +458,11 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
         for (int i = 0; i < RBW; ++i) {
           const int ee = s * RBW + i;
           const double av = ring[ee % PF];
-          ring[ee % PF] = ee + PF < NSc * RBW ? slice(ch, ee + PF) : slice(nch, ee + PF - NSc * RBW);
+          {
+            const int en = ee + PF, sn = en / RBW;            // (compile-time after unrolling)
+            ring[ee % PF] = en < NSc * RBW ? cbase[en % RBW][sn / 8][(sn % 8) * 64 + lane]
+                                           : nbase[en % RBW][(sn - NSc) * 64 + lane];
+          }
           acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0[s & 3], acc[i][0], 0, 0, 0);
           acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1[s & 3], acc[i][1], 0, 0, 0);
         }
