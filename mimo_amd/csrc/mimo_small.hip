@@ -64,7 +64,14 @@ void small_kernel(const KernelArgs a) {
   constexpr bool kEstep = MODE <= kGeneric;
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "G divides 16");
 
+#ifndef MIMO_SMALL_EXP2048
+#define MIMO_SMALL_EXP2048 1      // 2048-entry exp table (13 instead of 15 instructions per exponential, 16 KB of LDS)
+#endif
+#if MIMO_SMALL_EXP2048
+  __shared__ double etab[kExpTab];
+#else
   __shared__ double etab[64];
+#endif
   __shared__ double red[VB][kWG + 1];
   __shared__ double part[VB][16];
   __shared__ double sred[8];
@@ -78,7 +85,11 @@ void small_kernel(const KernelArgs a) {
   double* const out_logp = MODE == kGeneric ? a.logp : nullptr;
   double* const out_resp = MODE == kGeneric ? a.resp : nullptr;
   double* const out_lse = MODE == kGeneric ? a.lse : nullptr;
+#if MIMO_SMALL_EXP2048
+  for (int e = tid; e < kExpTab; e += kWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+#else
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+#endif
 
   // Theta rows of this lane's components ([G KL][F] row-major, padding components carry c = -1e300): G = 1 makes
   // the addresses wave-uniform and the rows live in SGPRs
@@ -171,7 +182,11 @@ void small_kernel(const KernelArgs a) {
       for (int s = 1; s < G; s <<= 1) m = fmax(m, __shfl_xor(m, s));
       double e[KL];
 #pragma unroll
+#if MIMO_SMALL_EXP2048
+      for (int c = 0; c < KL; ++c) e[c] = exp_nonpos_t2048(l[c] - m, etab);
+#else
       for (int c = 0; c < KL; ++c) e[c] = exp_nonpos(l[c] - m, etab);
+#endif
       double sel = 0.0;
       if constexpr (MODE == kGeneric) {     // sum_k e l feeds the entropy split of the ELBO scalars (switched-off / padding: 0)
 #pragma unroll
