@@ -303,6 +303,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 // Softmax table or label draw; scalars and tables as estep_chunked_kernel's.
 // ------------------------------------------------------------------------------------------
 constexpr int kWideEstepCF = 96;       // features per chunk
+constexpr int kWideEstepZS = 35;       // z~ row stride (doubles): odd, >= kMaxD + 2
 template <int RBW>
 __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) {
   constexpr int T = kTile, CF = kWideEstepCF, NSc = CF / 4, RSc = CF + 2, PF = 6, NBF = CF * T / kWG, NW = kWG / 64, ZPT = 4;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int D = a.D, K = a.K, K16 = a.K16;
-  const int ZS = (D + 2) | 1;
+  constexpr int ZS = kWideEstepZS;                             // fixed (odd, >= Dz + 2): row offsets of the feature build are immediates
   const int nchunk = (a.F16 + CF - 1) / CF, NSP = chunked_ns_pad(a.F16);     // row-block stride of the Theta image
   const int64_t N = a.N, total = N * D, G = gridDim.x;
 
@@ -357,28 +358,32 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
     }
   };
 
-  // feature build of one chunk: thread (row, fgrp) makes columns fgrp and fgrp + 8 of each of the 6 column blocks
-  const int frow = tid & (T - 1), fgrp = tid >> 5;
-  // (in two halves of NBF / 2: the operands of a half live in registers for four matrix steps)
-  constexpr int NBH = NBF / 2;
-  uint32_t w2[NBF];
-  double za[NBH], zb[NBH];
+  // feature build of one chunk: thread (fcol = tid & 31, rq = tid >> 5) makes the features fcol, fcol + 32, fcol + 64 of the
+  // chunk for the four rows 4 rq .. 4 rq + 3: one (a, b) offset pair per feature — two address adds — and the rows at
+  // immediate offsets (ZS and RSc are compile-time), 1.5 VALU instructions per product instead of 3 with a thread per row
+  const int fcol = tid & 31, rq = tid >> 5;
+  constexpr int NFG = CF / 32;                                 // feature groups of 32 columns per chunk
+  static_assert(NFG == 3 && T == 32 && kWG == 256, "build mapping");
+  uint32_t w2[NFG];
+  double za[4], zb[4];
   auto build_offsets = [&](int ch) {
 #pragma unroll
-    for (int i = 0; i < NBF; ++i) w2[i] = fo[ch * CF + 8 * i + fgrp];
+    for (int m = 0; m < NFG; ++m) w2[m] = fo[ch * CF + 32 * m + fcol];
   };
-  auto build_loads = [&](int h, const double* zb_) {
-    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(zb_ + frow * ZS);
+  auto build_loads = [&](int m, const double* zb_) {
+    const unsigned char* zq = reinterpret_cast<const unsigned char*>(zb_ + 4 * rq * ZS);
+    const unsigned char* pa = zq + (w2[m] & 0xFFFFu);
+    const unsigned char* pb = zq + (w2[m] >> 16);
 #pragma unroll
-    for (int i = 0; i < NBH; ++i) {
-      za[i] = *reinterpret_cast<const double*>(zrow + (w2[h * NBH + i] & 0xFFFFu));
-      zb[i] = *reinterpret_cast<const double*>(zrow + (w2[h * NBH + i] >> 16));
+    for (int r = 0; r < 4; ++r) {
+      za[r] = *reinterpret_cast<const double*>(pa + r * ZS * 8);
+      zb[r] = *reinterpret_cast<const double*>(pb + r * ZS * 8);
     }
   };
-  auto build_stores = [&](int h, double* pb_) {
-    double* prow = pb_ + frow * RSc + fgrp;
+  auto build_stores = [&](int m, double* pb_) {
+    double* prow = pb_ + 4 * rq * RSc + 32 * m + fcol;
 #pragma unroll
-    for (int i = 0; i < NBH; ++i) prow[8 * (h * NBH + i)] = za[i] * zb[i];
+    for (int r = 0; r < 4; ++r) prow[r * RSc] = za[r] * zb[r];
   };
 
   // Theta stream of this wave: element e = s * RBW + i of a tile is slice s of row block wave + 4 i (a row block past
@@ -405,10 +410,11 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
     for (int e = 0; e < PF; ++e) ring[e] = slice(0, e);
     wg_sync();
     build_offsets(0);
-    build_loads(0, Zs);
-    build_stores(0, Ph);
-    build_loads(1, Zs);
-    build_stores(1, Ph);
+#pragma unroll
+    for (int m = 0; m < NFG; ++m) {
+      build_loads(m, Zs);
+      build_stores(m, Ph);
+    }
     wg_sync();
   }
   int cur = 0, pbuf = 0;
@@ -468,10 +474,12 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 2) { build_offsets(nch); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 6) { build_loads(0, Zn); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 10) { build_stores(0, Pn); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 14) { build_loads(1, Zn); __builtin_amdgcn_sched_barrier(0); }
-        if (s == 18) { build_stores(1, Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 5) { build_loads(0, Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 8) { build_stores(0, Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 11) { build_loads(1, Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 14) { build_stores(1, Pn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 17) { build_loads(2, Zn); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 20) { build_stores(2, Pn); __builtin_amdgcn_sched_barrier(0); }
       }
       if (ch == 0) {                          // z~ of the next tile: read from the last chunk on
         store_z(t + G, Zs + (cur ^ 1) * T * ZS);
@@ -737,7 +745,8 @@ bool wide_estep_covers(int K16, int D, int F16) {
   return on && D >= wide_min_d() && D <= kMaxD && (K16 >= min_k16 || K16 == 3) && K16 <= 16 && F16 > kWideEstepCF;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
-  const int ZS = (D + 2) | 1, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
+  const int ZS = kWideEstepZS, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
+  (void)D;
   return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * (CF + 2) + 3 * 4 * kTile + 16 * kTile + kTile + 64) +
          sizeof(int) * 4 * kTile + sizeof(uint32_t) * (size_t)nchunk * CF;
 }
