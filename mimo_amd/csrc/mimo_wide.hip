@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
   const int D = a.D, K = a.K, K16 = a.K16;
   const int ncb = a.F16 / 16;                       // column blocks of this launch: NCBL * CP, or a few less (the
                                                     // surplus blocks are built from offset 0 and never stored)
-  const int ZS = (D + 2) | 1;                       // odd: the 32 rows of a column are conflict-free
+  constexpr int ZS = 35;                            // fixed (odd, >= kMaxD + 2): row offsets of the feature build are immediates
   constexpr int RS = 16 * NCBL * CP + 2;            // fixed (every operand offset is an immediate); = 2 mod 4: the four row groups of a B-operand read fall into disjoint banks
   const int64_t N = a.N;
 
@@ -129,39 +129,39 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
 #pragma unroll
     for (int i = 0; i < NCBL; ++i) acc[r][i] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // feature build: thread (row, fgrp) makes feature column fgrp of every column block, in batches of <= 6 features
-  // whose operand reads (after matrix step 2b) and product stores (after step 2b + 1) sit BETWEEN the matrix steps of
-  // the previous tile: the build's LDS round trips pass under 12 MFMAs each instead of holding all eight waves at a
-  // barrier, and one barrier per tile is left.
-  const int frow = tid & (T - 1), fgrp = tid >> 5;
-  constexpr int NBF = NCBL * CP;                     // features per thread
-  constexpr int NBATCH = (NBF + 5) / 6, BF = (NBF + NBATCH - 1) / NBATCH;
-  static_assert(NBATCH <= 4, "two matrix steps per batch");
+  // feature build: thread (fcol, rq) makes the feature columns fcol, fcol + NCOLS, ... for the NR rows NR rq .. of the tile
+  // (NR = 4 with 64-column groups where the column count allows, else 2 with 32-column groups): one (a, b) offset pair
+  // per NR products, the rows at immediate offsets.  Group g is read after matrix step g and multiplied / stored after
+  // step g + 1 of the PREVIOUS tile: the build's LDS round trips pass under NCBL MFMAs each instead of holding all
+  // eight waves at a barrier, and one barrier per tile is left.
+  constexpr int NBF = NCBL * CP;                     // products per thread
+  constexpr int NR = NBF % 4 == 0 ? 4 : 2, NCOLS = kWideWG * NR / T, NG = 16 * NBF / NCOLS;
+  static_assert(NG >= 1 && NG <= 7 && NG * NCOLS == 16 * NBF, "group g: read after step g, stored after step g + 1");
+  const int fcol = tid % NCOLS, rq = tid / NCOLS;
   double* Ph1 = Ph + T * RS;                         // second feature tile
 
   double wa[RBW][8], wb[RBW][8];
   // this thread's (a, b) byte offsets stay in registers: a table read inside the matrix phase would put an LDS round
   // trip (s_waitcnt in the in-order instruction stream) in front of the following MFMAs
-  uint32_t w2[NBF];
+  uint32_t w2[NG];
   wg_sync();
 #pragma unroll
-  for (int i = 0; i < NBF; ++i) w2[i] = i < ncb ? fo[16 * i + fgrp] : 0u;   // columns past ncb: offsets 0, a finite product nobody stores
-  double za[BF], zb[BF];
-  // batch bt of the feature tile built from the z~ rows at zb_ into the feature tile pb_
-  auto build_loads = [&](int bt, const double* zb_) {
-    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(zb_ + frow * ZS);
+  for (int g = 0; g < NG; ++g) w2[g] = NCOLS * g + fcol < 16 * ncb ? fo[NCOLS * g + fcol] : 0u;   // columns past ncb: offsets 0, a finite product nobody stores
+  double za[2][NR], zb[2][NR];
+  auto build_loads = [&](int g, const double* zb_) {
+    const unsigned char* zq = reinterpret_cast<const unsigned char*>(zb_ + NR * rq * ZS);
+    const unsigned char* pa = zq + (w2[g] & 0xFFFFu);
+    const unsigned char* pb = zq + (w2[g] >> 16);
 #pragma unroll
-    for (int i = 0; i < BF; ++i)
-      if (bt * BF + i < NBF) {
-        za[i] = *reinterpret_cast<const double*>(zrow + (w2[bt * BF + i] & 0xFFFFu));
-        zb[i] = *reinterpret_cast<const double*>(zrow + (w2[bt * BF + i] >> 16));
-      }
+    for (int r = 0; r < NR; ++r) {
+      za[g & 1][r] = *reinterpret_cast<const double*>(pa + r * ZS * 8);
+      zb[g & 1][r] = *reinterpret_cast<const double*>(pb + r * ZS * 8);
+    }
   };
-  auto build_stores = [&](int bt, double* pb_) {
-    double* prow = pb_ + frow * RS + fgrp;
+  auto build_stores = [&](int g, double* pb_) {
+    double* prow = pb_ + NR * rq * RS + NCOLS * g + fcol;
 #pragma unroll
-    for (int i = 0; i < BF; ++i)
-      if (bt * BF + i < NBF) prow[16 * (bt * BF + i)] = za[i] * zb[i];
+    for (int r = 0; r < NR; ++r) prow[r * RS] = za[g & 1][r] * zb[g & 1][r];
   };
 
   const int64_t G = gridDim.x;
@@ -193,11 +193,9 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
         if (s + 1 < 8) bv[i] = phq[(s + 1) * RS + 16 * CP * i];
       }
       __builtin_amdgcn_sched_barrier(0);      // no hoisting of later steps' reads: 8 x NCBL operands do not fit
-      if (s / 2 < NBATCH) {
-        if ((s & 1) == 0) build_loads(s / 2, Zn);
-        else build_stores(s / 2, Pn);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (s >= 1 && s - 1 < NG) build_stores(s - 1, Pn);
+      if (s < NG) build_loads(s, Zn);
+      __builtin_amdgcn_sched_barrier(0);
     }
     store_z(Zs + cur * T * ZS);               // z~(t + 2G), fetched one iteration ago
     load_z(t + 3 * G);
@@ -214,9 +212,9 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
     load_w(blockIdx.x, wa);
     wg_sync();
 #pragma unroll
-    for (int bt = 0; bt < NBATCH; ++bt) {
-      build_loads(bt, Zs);
-      build_stores(bt, Ph);
+    for (int g = 0; g < NG; ++g) {
+      build_loads(g, Zs);
+      build_stores(g, Ph);
     }
     wg_sync();
     int64_t t = blockIdx.x;
@@ -239,9 +237,9 @@ __global__ __launch_bounds__(kWideWG) void wide_stats_kernel(const KernelArgs a)
     }
     wg_sync();
 #pragma unroll
-    for (int bt = 0; bt < NBATCH; ++bt) {
-      build_loads(bt, Zs);
-      build_stores(bt, Ph);
+    for (int g = 0; g < NG; ++g) {
+      build_loads(g, Zs);
+      build_stores(g, Ph);
     }
     wg_sync();
     const double* phq = Ph + 8 * q * RS + 16 * cpart + j;
@@ -708,7 +706,8 @@ static int wide_ncbl(int K16, int ncb) {          // accumulator blocks per wave
   return need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 10 ? 10 : 12;
 }
 size_t wide_stats_lds_bytes(int D, int K16, int ncb) {
-  const int ZS = (D + 2) | 1, cp = K16 > 4 ? 1 : 2, RS = 16 * wide_ncbl(K16, ncb) * cp + 2;
+  (void)D;
+  const int ZS = 35, cp = K16 > 4 ? 1 : 2, RS = 16 * wide_ncbl(K16, ncb) * cp + 2;
   return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * RS) + sizeof(uint32_t) * 16 * (size_t)ncb;
 }
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) {
