@@ -531,7 +531,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       }
       if (chunked_lds_bytes(e) > 160 * 1024)
         return fail(ctx, MIMO_E_UNSUPPORTED, "K=%d, Dz=%d needs more LDS than one CU has", K, D);
-      if (wide_estep_covers(a.K16, D, a.F16)) {          // 8-wave softmax pass (mimo_wide.hip)
+      if (wide_estep_covers(a.K16, D, a.F16, e.gibbs)) {          // pipelined softmax / label pass (mimo_wide.hip)
         rc = timed_launch(ctx, "wide_estep_kernel", [&]() -> int {
           HIP_TRY(ctx, launch_wide_estep(e, grid, ctx->stream));
           return MIMO_OK;

@@ -27,7 +27,7 @@ int wide_stats_group_ncb(int K16, int ncb_total);     // feature column blocks p
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream);
 
 // ... and their E-step (softmax table or label draw)
-bool wide_estep_covers(int K16, int D, int F16);
+bool wide_estep_covers(int K16, int D, int F16, int gibbs);
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 
 // label statistics (mimo_rowwave.hip): launches of one pass — 1, or the slice groups of the Dz > 16 / large-K kernel

@@ -734,14 +734,16 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) 
 }
 
 
-bool wide_estep_covers(int K16, int D, int F16) {
+bool wide_estep_covers(int K16, int D, int F16, int gibbs) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_ESTEP"); return !e || atoi(e) != 0; }();   // tuning knob
   // F16 > one chunk: the z rows of the next tile are staged during the first chunk and read from the last one on
   // (reduced feature maps — diagonal, linear — of a wide Dz stay with the chunked kernel)
-  // K16 = 4 (one row block per wave, all four busy): equal to the chunked kernel within +-5 % (Dz=32, K=64 2.89 / 2.89 ms,
-  // Dz=20, K=60 1.62 / 1.66; label draw 2.99 / 2.82, 1.78 / 1.54) — stays there; K16 = 3: Dz=28, K=40 2.33 against 2.72 ms
+  // K16 = 4 (one row block per wave, all four busy), N = 2e6, against the chunked kernel: softmax pass Dz=32, K=64 2.77 / 2.86 ms,
+  // Dz=24, K=56 1.92 / 2.22, Dz=20, K=60 1.57 / 1.63 — here; label draw 2.82 / 2.77, 2.03 / 2.15, 1.64 / 1.53 — stays there.
+  // K16 = 3: Dz=28, K=40 2.33 against 2.72 ms.
   static const int min_k16 = [] { const char* e = getenv("MIMO_WIDE_ESTEP_MIN_K16"); return e ? atoi(e) : 5; }();   // tuning knob
-  return on && D >= wide_min_d() && D <= kMaxD && (K16 >= min_k16 || K16 == 3) && K16 <= 16 && F16 > kWideEstepCF;
+  const bool k_ok = K16 >= min_k16 || K16 == 3 || (K16 == 4 && !gibbs);
+  return on && D >= wide_min_d() && D <= kMaxD && k_ok && K16 <= 16 && F16 > kWideEstepCF;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
   const int ZS = kWideEstepZS, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
