@@ -691,28 +691,32 @@ static int wide_min_d() {
 }
 bool wide_stats_covers(int K16, int D) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_STATS"); return !e || atoi(e) != 0; }();   // tuning knob
+  // (K <= 32 — two row blocks, four column parts of four blocks — was tried: Dz=32, K=32 2.0 against 1.94 ms of the split tile
+  //  kernels, Dz=24, K=24 1.33 / 1.20, Dz=20, K=30 0.71 / 0.92: no clear gain, not instantiated)
   return on && D >= wide_min_d() && D <= kMaxD && K16 >= 3 && K16 <= 16;
 }
+// column parts of the eight waves: 8 / (waves that share the row blocks)
+static int wide_cp(int K16) { return K16 > 4 ? 1 : 2; }
 // column blocks per launch: as few launches as 12 blocks per wave allow, of equal size
 int wide_stats_group_ncb(int K16, int ncb_total) {
   // accumulator blocks per wave: 12 (K <= 128), 8 (K <= 64: two feature tiles of 32 x (16 * 16 + 2) doubles in LDS), 6 x 2 row
   // blocks (K <= 256)
-  const int cp = K16 > 4 ? 1 : 2, cap = (K16 > 8 ? 6 : K16 > 4 ? kWideNCBL : 8) * cp;
+  const int cp = wide_cp(K16), cap = (K16 > 8 ? 6 : K16 > 4 ? kWideNCBL : 8) * cp;
   const int launches = (ncb_total + cap - 1) / cap;
   return (ncb_total + launches - 1) / launches;
 }
 static int wide_ncbl(int K16, int ncb) {          // accumulator blocks per wave of the instantiation for this launch
-  const int cp = K16 > 4 ? 1 : 2, need = (ncb + cp - 1) / cp;
+  const int cp = wide_cp(K16), need = (ncb + cp - 1) / cp;
   return need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 10 ? 10 : 12;
 }
 size_t wide_stats_lds_bytes(int D, int K16, int ncb) {
   (void)D;
-  const int ZS = 35, cp = K16 > 4 ? 1 : 2, RS = 16 * wide_ncbl(K16, ncb) * cp + 2;
+  const int ZS = 35, cp = wide_cp(K16), RS = 16 * wide_ncbl(K16, ncb) * cp + 2;
   return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * RS) + sizeof(uint32_t) * 16 * (size_t)ncb;
 }
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  const int ncb = a.F16 / 16, cp = a.K16 > 4 ? 1 : 2;
+  const int ncb = a.F16 / 16, cp = wide_cp(a.K16);
   if (ncb < 1 || ncb > (cp == 1 ? kWideNCBL : 16) || a.D * kTile > 2 * kWideWG) return hipErrorInvalidValue;
   fn_t fn = nullptr;
   if (a.K16 > 8) {

@@ -134,7 +134,8 @@ def _random_problem(rng, N, D, K):
                                     (3000, 16, 128), (2500, 14, 100), (1200, 16, 200), (900, 13, 256), (1000, 12, 128), (801, 10, 90),
                                     (2222, 28, 40), (1111, 15, 35),
                                     # ... ragged and tiny row counts through the same kernels
-                                    (1, 32, 128), (31, 20, 72), (33, 24, 100), (65, 16, 200), (0, 32, 128)])
+                                    (1, 32, 128), (31, 20, 72), (33, 24, 100), (65, 16, 200), (0, 32, 128),
+                                    (700, 32, 32), (650, 20, 24), (900, 17, 30)])
 def test_engine_vs_oracle_seeded(engine, N, D, K):
     """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
     from oracle import mimo_oracle as O
