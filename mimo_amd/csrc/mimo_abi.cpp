@@ -459,8 +459,15 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
   const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave);
-  const int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
-                   : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
+  int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
+             : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
+  // two-stage pass on the pipelined E-step (mimo_wide.hip): that kernel is built for two workgroups per CU whatever K is
+  // (fused_grid's fallback assumes one for K > 128); the statistics launches of the pass share the grid (partial blocks)
+  if (!small && !lstats && !rowvi && src == kSrcEstep && !fused_covers(a.K16, a.F16 / 16, src) &&
+      wide_estep_covers(a.K16, D, a.F16, a.gibbs)) {
+    const int64_t g2 = 2 * (int64_t)ctx->num_cu;
+    grid = (int)(g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1));
+  }
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
@@ -1354,6 +1361,10 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
       out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
     }
     out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
+    if (wide_estep_covers(a.K16, ctx->D, a.F16, gibbs)) {                // as run_pass: two workgroups per CU
+      const int64_t g2 = 2 * (int64_t)ctx->num_cu;
+      out8[6] = g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1);
+    }
   }
   out8[7] = ctx->num_cu;
   return MIMO_OK;
