@@ -398,12 +398,17 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
   double ring[PF];
   double sc_lse = 0.0, sc_rl = 0.0;
   const bool want_sel = a.split != 0;        // sum_k r l only feeds the entropy split of the ELBO scalars
+  const bool single = nchunk == 1;          // F16 <= 96 (Dz = 10 .. 12)
   const bool gibbs = a.gibbs != 0;
 
   if ((int64_t)blockIdx.x < a.ntiles) {
     load_z(blockIdx.x);
     store_z(blockIdx.x, Zs);
     load_z(blockIdx.x + G);
+    if (single) {                             // one chunk per tile: the rows are staged two tiles ahead (see the tile loop)
+      store_z(blockIdx.x + G, Zs + T * ZS);
+      load_z(blockIdx.x + 2 * G);
+    }
 #pragma unroll
     for (int e = 0; e < PF; ++e) ring[e] = slice(0, e);
     wg_sync();
@@ -479,9 +484,14 @@ __global__ __launch_bounds__(kWG, 2) void wide_estep_kernel(const KernelArgs a) 
         if (s == 17) { build_loads(2, Zn); __builtin_amdgcn_sched_barrier(0); }
         if (s == 20) { build_stores(2, Pn); __builtin_amdgcn_sched_barrier(0); }
       }
-      if (ch == 0) {                          // z~ of the next tile: read from the last chunk on
-        store_z(t + G, Zs + (cur ^ 1) * T * ZS);
-        load_z(t + 2 * G);
+      if (ch == 0) {
+        if (single) {                         // this chunk's hooks read z~(t + G) from Zs[cur ^ 1]; Zs[cur] (this tile's rows,
+          store_z(t + 2 * G, Zs + cur * T * ZS);   // last read during the previous tile) takes the tile after next
+          load_z(t + 3 * G);
+        } else {                              // z~ of the next tile: read from the last chunk on
+          store_z(t + G, Zs + (cur ^ 1) * T * ZS);
+          load_z(t + 2 * G);
+        }
       }
       pbuf ^= 1;
       WSTAMP(0);
@@ -740,14 +750,13 @@ hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) 
 
 bool wide_estep_covers(int K16, int D, int F16, int gibbs) {
   static const bool on = [] { const char* e = getenv("MIMO_WIDE_ESTEP"); return !e || atoi(e) != 0; }();   // tuning knob
-  // F16 > one chunk: the z rows of the next tile are staged during the first chunk and read from the last one on
-  // (reduced feature maps — diagonal, linear — of a wide Dz stay with the chunked kernel)
+  // (reduced feature maps — diagonal, linear — stay with the chunked kernel: F16 >= 80 is the full map from Dz = 10 on)
   // K16 = 4 (one row block per wave, all four busy), N = 2e6, against the chunked kernel: softmax pass Dz=32, K=64 2.77 / 2.86 ms,
   // Dz=24, K=56 1.92 / 2.22, Dz=20, K=60 1.57 / 1.63 — here; label draw 2.82 / 2.77, 2.03 / 2.15, 1.64 / 1.53 — stays there.
   // K16 = 3: Dz=28, K=40 2.33 against 2.72 ms.
   static const int min_k16 = [] { const char* e = getenv("MIMO_WIDE_ESTEP_MIN_K16"); return e ? atoi(e) : 5; }();   // tuning knob
   const bool k_ok = K16 >= min_k16 || K16 == 3 || (K16 == 4 && !gibbs);
-  return on && D >= wide_min_d() && D <= kMaxD && k_ok && K16 <= 16 && F16 > kWideEstepCF;
+  return on && D >= wide_min_d() && D <= kMaxD && k_ok && K16 <= 16 && F16 >= 80;
 }
 size_t wide_estep_lds_bytes(int D, int F16) {
   const int ZS = kWideEstepZS, CF = kWideEstepCF, nchunk = (F16 + CF - 1) / CF;
@@ -757,7 +766,7 @@ size_t wide_estep_lds_bytes(int D, int F16) {
 }
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  if (a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 <= kWideEstepCF) return hipErrorInvalidValue;
+  if (a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 < 16) return hipErrorInvalidValue;
   fn_t fn = a.K16 > 8 ? wide_estep_kernel<4> : a.K16 > 4 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
   const size_t lds = wide_estep_lds_bytes(a.D, a.F16);
   if (lds > 80 * 1024) return hipErrorInvalidValue;
