@@ -84,7 +84,7 @@ double philox_uniform_host(uint64_t seed, uint64_t row, uint64_t sweep) {
 #define MIMO_RBW4_ESTEP_WGS 2   // workgroups per CU the RBW = 4 E-step kernels with NCB <= 3 are compiled for
 #endif
 template <int NCB, int RBW, int MODE, int DS = 0, int SPLIT = 0>
-__global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : (MODE <= kGeneric && NCB <= 3) ? MIMO_RBW4_ESTEP_WGS
+__global__ __launch_bounds__(kWG, (RBW == 1 ? 2 : (MODE <= kGeneric && RBW == 2) ? 2 : (MODE <= kGeneric && NCB <= 3) ? MIMO_RBW4_ESTEP_WGS
                                    : (MODE > kGeneric && RBW * NCB <= 12) ? 2 : 1))
 void fused_kernel(const KernelArgs a) {
   constexpr int SRC = MODE == kModeWeights ? kSrcWeights : MODE == kModeLabels ? kSrcLabels : kSrcEstep;
@@ -1197,11 +1197,16 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
     if (on) return a.K16 == 1 ? pick_estep_table_split<1>(ncb, mode) : pick_estep_table_split<2>(ncb, mode);
   }
   if (src == kSrcEstep && a.diag)
-    return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : pick_estep_table<4>(ncb, mode);
+    return rbw_for(a.K16) == 1 ? pick_estep_table<1>(ncb, mode) : (a.K16 <= 8 ? pick_estep_table<2>(ncb, mode) : pick_estep_table<4>(ncb, mode));
   if (src == kSrcEstep && a.K16 <= 2) {
     if (fused_fn f = a.K16 == 1 ? pick_estep_split<1>(a.D, mode) : pick_estep_split<2>(a.D, mode)) return f;
   }
-  if (src == kSrcEstep) return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
+  if (src == kSrcEstep) {
+    // 64 < K <= 128 (Dz <= 9): two row blocks per wave instead of four (half of which would multiply padding)
+    static const bool rbw2 = [] { const char* e = getenv("MIMO_ESTEP_RBW2"); return !e || atoi(e) != 0; }();   // tuning knob
+    if (rbw2 && a.K16 > 4 && a.K16 <= 8) if (fused_fn f = pick_estep<2>(a.D, mode)) return f;
+    return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
+  }
   if (a.K16 <= 2 && ncb >= 3) {   // K <= 32: split distribution of the statistics column blocks (see fused_kernel, SPLIT)
     static const bool on = [] { const char* e = getenv("MIMO_SPLIT_STATS"); return !e || atoi(e) != 0; }();   // tuning knob
     if (on) return a.K16 == 1 ? pick_stats<1, 1>(ncb, mode) : pick_stats<1, 2>(ncb, mode);
