@@ -706,40 +706,48 @@ bool wide_stats_covers(int K16, int D) {
   return on && D >= wide_min_d() && D <= kMaxD && K16 >= 3 && K16 <= 16;
 }
 // column parts of the eight waves: 8 / (waves that share the row blocks)
-static int wide_cp(int K16) { return K16 > 4 ? 1 : 2; }
+// 128 < K <= 192: four waves x three row blocks x two column parts of four blocks (8 column blocks per launch, no padding
+// row blocks) where that saves a launch over eight waves x two row blocks x six blocks (Dz=32: 5 launches of 1.73 ms against
+// 6 of 1.65 ms; Dz=16, 10 column blocks: 2 launches either way, and the second form has no spill: 1.58 against 1.77 ms)
+static bool wide_three(int K16, int ncb_total) { return K16 > 8 && K16 <= 12 && (ncb_total + 7) / 8 < (ncb_total + 5) / 6; }
+// column parts: K16 <= 4: four waves x one row block; 5 .. 8: eight waves; 9 .. 16: eight waves x two row blocks, or the above
+static int wide_cp(int K16, int ncb_total) { return wide_three(K16, ncb_total) ? 2 : K16 > 4 ? 1 : 2; }
 // column blocks per launch: as few launches as 12 blocks per wave allow, of equal size
 int wide_stats_group_ncb(int K16, int ncb_total) {
   // accumulator blocks per wave: 12 (K <= 128), 8 (K <= 64: two feature tiles of 32 x (16 * 16 + 2) doubles in LDS), 6 x 2 row
   // blocks (K <= 256)
-  const int cp = wide_cp(K16), cap = (K16 > 8 ? 6 : K16 > 4 ? kWideNCBL : 8) * cp;
+  const int cp = wide_cp(K16, ncb_total), cap = (wide_three(K16, ncb_total) ? 4 : K16 > 8 ? 6 : K16 > 4 ? kWideNCBL : 8) * cp;
   const int launches = (ncb_total + cap - 1) / cap;
   return (ncb_total + launches - 1) / launches;
 }
-static int wide_ncbl(int K16, int ncb) {          // accumulator blocks per wave of the instantiation for this launch
-  const int cp = wide_cp(K16), need = (ncb + cp - 1) / cp;
+static int wide_ncbl(int K16, int ncb, int ncb_total) {          // accumulator blocks per wave of the instantiation for this launch
+  const int cp = wide_cp(K16, ncb_total), need = (ncb + cp - 1) / cp;
   return need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 10 ? 10 : 12;
 }
-size_t wide_stats_lds_bytes(int D, int K16, int ncb) {
+size_t wide_stats_lds_bytes(int D, int K16, int ncb, int ncb_total) {
   (void)D;
-  const int ZS = 35, cp = wide_cp(K16), RS = 16 * wide_ncbl(K16, ncb) * cp + 2;
+  const int ZS = 35, cp = wide_cp(K16, ncb_total), RS = 16 * wide_ncbl(K16, ncb, ncb_total) * cp + 2;
   return sizeof(double) * ((size_t)2 * kTile * ZS + (size_t)2 * kTile * RS) + sizeof(uint32_t) * 16 * (size_t)ncb;
 }
 hipError_t launch_wide_stats(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
-  const int ncb = a.F16 / 16, cp = wide_cp(a.K16);
+  const int ncb = a.F16 / 16, nt = a.F16_total / 16, cp = wide_cp(a.K16, nt);
   if (ncb < 1 || ncb > (cp == 1 ? kWideNCBL : 16) || a.D * kTile > 2 * kWideWG) return hipErrorInvalidValue;
   fn_t fn = nullptr;
-  if (a.K16 > 8) {
+  if (wide_three(a.K16, nt)) {
+    if (ncb > 8) return hipErrorInvalidValue;
+    fn = wide_stats_kernel<4, 4, 3>;
+  } else if (a.K16 > 8) {
     if (ncb > 6) return hipErrorInvalidValue;
-    fn = wide_ncbl(a.K16, ncb) == 4 ? wide_stats_kernel<8, 4, 2> : wide_stats_kernel<8, 6, 2>;
-  } else switch (wide_ncbl(a.K16, ncb)) {
+    fn = wide_ncbl(a.K16, ncb, nt) == 4 ? wide_stats_kernel<8, 4, 2> : wide_stats_kernel<8, 6, 2>;
+  } else switch (wide_ncbl(a.K16, ncb, nt)) {
     case 4: fn = cp == 1 ? wide_stats_kernel<8, 4> : wide_stats_kernel<4, 4>; break;
     case 6: fn = cp == 1 ? wide_stats_kernel<8, 6> : wide_stats_kernel<4, 6>; break;
     case 8: fn = cp == 1 ? wide_stats_kernel<8, 8> : wide_stats_kernel<4, 8>; break;
     case 10: fn = cp == 1 ? wide_stats_kernel<8, 10> : nullptr; break;
     default: fn = cp == 1 ? wide_stats_kernel<8, 12> : nullptr; break;
   }
-  const size_t lds = wide_stats_lds_bytes(a.D, a.K16, ncb);
+  const size_t lds = wide_stats_lds_bytes(a.D, a.K16, ncb, nt);
   if (!fn || lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -767,7 +775,7 @@ size_t wide_estep_lds_bytes(int D, int F16) {
 hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
   if (a.K16 < 1 || a.K16 > 16 || a.D * kTile > 4 * kWG || a.F16 < 16) return hipErrorInvalidValue;
-  fn_t fn = a.K16 > 8 ? wide_estep_kernel<4> : a.K16 > 4 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
+  fn_t fn = a.K16 > 12 ? wide_estep_kernel<4> : a.K16 > 8 ? wide_estep_kernel<3> : a.K16 > 4 ? wide_estep_kernel<2> : wide_estep_kernel<1>;
   const size_t lds = wide_estep_lds_bytes(a.D, a.F16);
   if (lds > 80 * 1024) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
