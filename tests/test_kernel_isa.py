@@ -15,15 +15,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+SOURCES = [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30), ("mimo_wide.hip", 10)]
+
+
+@pytest.fixture(scope="module")
+def assemblies(tmp_path_factory):
+    """hipcc -S of every kernel file, all started together (the tile kernels alone take minutes): {source: (Popen, asm path)}."""
+    out = tmp_path_factory.mktemp("isa")
+    procs = {}
+    for source, _ in SOURCES:
+        asm = str(out / (source + ".s"))
+        cmd = [HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-fno-honor-nans",
+               "-Wno-unused-function", "-S", "-o", asm, os.path.join(ROOT, "mimo_amd", "csrc", source)]
+        procs[source] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), asm)
+    yield procs
+    for p, _ in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("source,at_least", [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30),
-                                             ("mimo_wide.hip", 10)])
-def test_every_barrier_is_reached_with_lds_drained(tmp_path, source, at_least):
-    asm = str(tmp_path / (source + ".s"))
-    cmd = [HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-fno-honor-nans",
-           "-Wno-unused-function", "-S", "-o", asm, os.path.join(ROOT, "mimo_amd", "csrc", source)]
-    build = subprocess.run(cmd, capture_output=True, text=True)
-    assert build.returncode == 0, build.stderr[-2000:]
+@pytest.mark.parametrize("source,at_least", SOURCES)
+def test_every_barrier_is_reached_with_lds_drained(assemblies, source, at_least):
+    proc, asm = assemblies[source]
+    _, err = proc.communicate()
+    assert proc.returncode == 0, err[-2000:]
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_barrier_waits as cbw
     kernels = cbw.kernels_of(asm)
