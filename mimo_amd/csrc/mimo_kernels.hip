@@ -137,7 +137,7 @@ void fused_kernel(const KernelArgs a) {
   // scalar base of this wave's first row block + per-lane element; slice offsets are immediates
   gptr_t thw = (gptr_t)(a.theta + (size_t)wave * NSI * 64);
   // element order of the stream: pass h (RP row blocks at a time), contraction step s, row block i2 of the pass
-  constexpr int RP = RBW >= 2 ? 2 : 1;
+  constexpr int RP = RBW == 3 ? 3 : RBW >= 2 ? 2 : 1;      // (three row blocks: one pass of three)
   auto theta_slice = [&](int e) -> double {
     if (e >= NE) e = 0;   // padding element: any valid slice, never consumed
     const int h = e / (NS * RP), rem = e % (NS * RP);
@@ -495,6 +495,10 @@ void fused_kernel(const KernelArgs a) {
           stats_body(std::integral_constant<int, 1>{}, lab_c);
         } else if constexpr (RBW == 2) {
           if (nact >= 2) stats_body(std::integral_constant<int, 2>{}, lab_c);
+          else stats_body(std::integral_constant<int, 1>{}, lab_c);
+        } else if constexpr (RBW == 3) {
+          if (nact >= 3) stats_body(std::integral_constant<int, 3>{}, lab_c);
+          else if (nact == 2) stats_body(std::integral_constant<int, 2>{}, lab_c);
           else stats_body(std::integral_constant<int, 1>{}, lab_c);
         } else {
           if (nact >= 4) stats_body(std::integral_constant<int, 4>{}, lab_c);
@@ -1205,6 +1209,7 @@ static fused_fn resolve_fused(const KernelArgs& a, int src) {
     // 64 < K <= 128 (Dz <= 9): two row blocks per wave instead of four (half of which would multiply padding)
     static const bool rbw2 = [] { const char* e = getenv("MIMO_ESTEP_RBW2"); return !e || atoi(e) != 0; }();   // tuning knob
     if (rbw2 && a.K16 > 4 && a.K16 <= 8) if (fused_fn f = pick_estep<2>(a.D, mode)) return f;
+    if (rbw2 && a.K16 > 8 && a.K16 <= 12) if (fused_fn f = pick_estep<3>(a.D, mode)) return f;     // 128 < K <= 192: three
     return rbw_for(a.K16) == 1 ? pick_estep<1>(a.D, mode) : pick_estep<4>(a.D, mode);
   }
   if (a.K16 <= 2 && ncb >= 3) {   // K <= 32: split distribution of the statistics column blocks (see fused_kernel, SPLIT)

@@ -139,7 +139,8 @@ def _random_problem(rng, N, D, K):
                                     # one feature chunk per tile (Dz = 10 .. 12, K > 64) in the pipelined E-step
                                     (3001, 12, 200), (2000, 10, 256), (1500, 11, 100), (33, 12, 129),
                                     # 128 < K <= 192: three row blocks per wave (E-step; statistics where that saves a launch)
-                                    (1300, 32, 192), (1100, 24, 144), (900, 16, 180), (700, 8, 100)])
+                                    (1300, 32, 192), (1100, 24, 144), (900, 16, 180), (700, 8, 100),
+                                    (4000, 8, 192), (2500, 5, 150), (3100, 9, 129), (33, 7, 177)])
 def test_engine_vs_oracle_seeded(engine, N, D, K):
     """Every entry point against the oracle's direct evaluation, ragged / empty / maximal shapes."""
     from oracle import mimo_oracle as O
