@@ -192,8 +192,8 @@ def self_launch(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

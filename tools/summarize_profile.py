@@ -19,7 +19,7 @@ def short(name):
 
 p = find("trace", "kernel_stats.csv")
 if p:
-    print("== rocprofv3 --kernel-trace --stats (bench.py, default --steps 10 --warmup 2, sustained leg included) ==")
+    print("== rocprofv3 --kernel-trace --stats (bench.py, default --steps 20 --warmup 5, sustained leg included) ==")
     for row in csv.DictReader(open(p)):
         print(f"{short(row['Name']):70s} calls {row['Calls']:>6s} total_ns {row['TotalDurationNs']:>14s} "
               f"avg_ns {float(row['AverageNs']):14.1f} pct {row['Percentage']}")
