@@ -248,7 +248,7 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
  * (lingauss.py:150-151) and evaluates the others on nan_to_num'ed values — that corner is not reproduced. */
 int mimo_nan_info(mimo_ctx* ctx, int64_t* n_bad, double* row_mask_out, int K, int64_t* label_counts);
 
-/* ---- sharding over the GPUs of a node/* ---- sharding over the GPUs of a node (one process per GPU) ----------------------------------
+/* ---- sharding over the GPUs of a node (one process per GPU) ----------------------------------
  * The path shards over rows: every per-datum quantity is local, the only exchange per pass is the sum of the packed
  * statistic block [K (1 + Dz + Dz^2)] + 3 scalars over the ranks (0.14 MB at K = 64, Dz = 16).
  * With a communicator attached, every entry point that returns statistics / scalars (mimo_estep, mimo_estep_weighted,
@@ -266,7 +266,7 @@ int mimo_comm_unique_id(char* id128);
 int mimo_comm_init(mimo_ctx* ctx, const char* id128, int rank, int world);
 int mimo_comm_destroy(mimo_ctx* ctx);
 
-/* ---- copy-outs of device-resident tables/* ---- copy-outs of device-resident tables ----------------------------------------------- */
+/* ---- copy-outs of device-resident tables ----------------------------------------------- */
 int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
 int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);
 int mimo_get_lse(mimo_ctx* ctx, double* lse_host /* N */);
@@ -348,6 +348,7 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_SMALL      3   /* small-shape VALU kernel (Dz <= 4, K <= 32): bound by HBM                        */
 #define MIMO_PLAN_ROWWAVE    4   /* label pass: row-owner label kernel + label-indexed statistics kernel            */
 #define MIMO_PLAN_ROWWAVE_VI 5   /* softmax pass at K <= 64, Dz <= 9: row-owner kernel for both matrix products     */
+#define MIMO_PLAN_NARROW     6   /* Dz <= 4 with 32 < K <= 128: 4x4x4 matrix-instruction kernels (+ label statistics) */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
 
 /* Test hook for the no-exception contract: throws, INSIDE the guarded boundary, kind 1: std::bad_alloc,

@@ -82,6 +82,7 @@ struct mimo_ctx {
   int comm_world = 1;
   bool rowwave_vi_call = false; // set by mimo_estep for the call in progress: row-owner softmax + statistics kernel
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
+  int narrow_call = 0;          // set for the call in progress: Theta is in the narrow image (1: softmax + statistics pass, 2: label pass)
 
   // pending asynchronous call (MIMO_F_ASYNC)
   bool pending_async = false;
@@ -354,6 +355,58 @@ static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b,
   return MIMO_OK;
 }
 
+// Passes of the narrow shapes (mimo_narrow.hip: F <= 16 features, 32 < K <= 128 on the 4x4x4 matrix instruction): plain
+// requests only — nothing but statistics + scalars (softmax pass) or labels + their statistics (label pass).
+static bool use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain) {
+  if (!plain || use_small(ctx, K)) return false;
+  const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
+  if (!narrow_covers(K, ctx->F, ctx->D, ZS, gibbs ? 1 : 0)) return false;
+  return gibbs ? label_stats_covers(K, ctx->D, ctx->structure) : ctx->n_bad == 0;
+}
+
+// Theta image of the narrow kernels: [NSF][V][16]; slice s V + c, entry 4 kk + j = Theta[component j V + c][feature 4 s + kk]
+// (an output lane holds a contiguous quarter of the components: narrow_kernel)
+static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  const int D = ctx->D, NSF = narrow_nsf(ctx->F), V = narrow_v(K);
+  const size_t count = (size_t)NSF * V * 16;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  double* img = ctx->theta_h;
+  memset(img, 0, count * sizeof(double));
+  bool finite = true;
+  auto put = [&](int k, int f, double v) {
+    finite = finite && std::fabs(v) <= 1.7976931348623157e308;
+    img[((size_t)(f / 4) * V + k % V) * 16 + 4 * (f % 4) + k / V] = v;
+  };
+  for (int k = 0; k < K; ++k) {
+    const double* bk = b + (size_t)k * D;
+    const double* Wk = W + (size_t)k * D * D;
+    if (c[k] != c[k] || c[k] > 1.7976931348623157e308) return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
+    put(k, fidx(ctx, D, D), c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
+    for (int a = 0; a < D; ++a) put(k, fidx(ctx, a, D), bk[a]);
+    if (ctx->structure == MIMO_STRUCT_LINEAR) {       // the shared quadratic term stays with the caller (mimo_set_structure)
+      if (k > 0 && memcmp(Wk, W, sizeof(double) * D * D) != 0)
+        return fail(ctx, MIMO_E_INVALID, "linear structure is set (mimo_set_structure) but W[%d] differs from W[0]", k);
+      continue;
+    }
+    for (int a = 0; a < D; ++a) {
+      put(k, fidx(ctx, a, a), -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) {
+        if (ctx->structure == MIMO_STRUCT_FULL) put(k, feat_index(D, a, bb), -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+        else if (Wk[a * D + bb] != 0.0 || Wk[bb * D + a] != 0.0)
+          return fail(ctx, MIMO_E_INVALID, "diagonal structure is set (mimo_set_structure) but W[%d] has the "
+                      "off-diagonal entry (%d,%d)", k, a, bb);
+      }
+    }
+  }
+  if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
+  for (int k = K; k < 4 * V; ++k) put(k, fidx(ctx, D, D), kPadLogDensity);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MIMO_OK;
+}
+
 static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
   if (use_small(ctx, K)) return upload_theta_small(ctx, c, b, W, K);
   const int D = ctx->D, F16 = ctx->F16;
@@ -458,12 +511,15 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
-  const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave);
+  const bool narrow_vi = src == kSrcEstep && ctx->narrow_call == 1;                 // narrow softmax + statistics pass
+  const bool narrow_g = src == kSrcEstep && ctx->narrow_call == 2;                  // narrow label pass + label statistics
+  const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave || narrow_g);
   int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
-             : rowvi ? rowwave_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
+             : rowvi ? rowwave_grid(a, ctx->num_cu) : narrow_vi ? narrow_grid(a, ctx->num_cu, ctx->F, 0)
+             : fused_grid(a, ctx->num_cu, src);
   // two-stage pass on the pipelined E-step (mimo_wide.hip): that kernel is built for two workgroups per CU whatever K is
   // (fused_grid's fallback assumes one for K > 128); the statistics launches of the pass share the grid (partial blocks)
-  if (!small && !lstats && !rowvi && src == kSrcEstep && !fused_covers(a.K16, a.F16 / 16, src) &&
+  if (!small && !lstats && !rowvi && !narrow_vi && src == kSrcEstep && !fused_covers(a.K16, a.F16 / 16, src) &&
       wide_estep_covers(a.K16, D, a.F16, a.gibbs)) {
     const int64_t g2 = 2 * (int64_t)ctx->num_cu;
     grid = (int)(g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1));
@@ -490,6 +546,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
         return MIMO_OK;
       });
       if (rc) return rc;
+    } else if (narrow_g) {
+      rc = timed_launch(ctx, "narrow_kernel", [&]() -> int {
+        HIP_TRY(ctx, launch_narrow(a, ctx->F, 1, narrow_grid(a, ctx->num_cu, ctx->F, 1), ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
     }
     if (a.do_stats) {
       rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
@@ -501,6 +563,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   } else if (rowvi) {
     rc = timed_launch(ctx, "vi_rowwave_kernel", [&]() -> int {
       HIP_TRY(ctx, launch_vi_rowwave(a, grid, ctx->stream));
+      return MIMO_OK;
+    });
+    if (rc) return rc;
+  } else if (narrow_vi) {
+    rc = timed_launch(ctx, "narrow_kernel", [&]() -> int {
+      HIP_TRY(ctx, launch_narrow(a, ctx->F, 0, grid, ctx->stream));
       return MIMO_OK;
     });
     if (rc) return rc;
@@ -664,6 +732,7 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
       a.do_stats = 0;
       if ((rc = run_pass(ctx, a, kSrcEstep, flags & ~(MIMO_F_DEVICE_OUT), nullptr, nullptr))) return rc;
       ctx->rowwave_call = false;
+      ctx->narrow_call = 0;
     }
     if ((rc = ensure_dev(ctx, &ctx->labels_tmp, &ctx->labels_tmp_cap, (size_t)N))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d + 1, 0, 256 * sizeof(unsigned long long), ctx->stream));
@@ -860,13 +929,16 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
-  const bool rv = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) &&
-                  ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
-  if ((rc = rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
+  const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
+  const bool nv = use_narrow(ctx, K, false, plain);      // narrow shapes (Dz <= 4, 32 < K <= 128): mimo_narrow.hip
+  const bool rv = !nv && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
+  ctx->narrow_call = nv ? 1 : 0;
   rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
   ctx->rowwave_vi_call = false;
+  ctx->narrow_call = 0;
   return rc;
   });
 }
@@ -949,12 +1021,16 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
       ctx->weights_resident = false;
     }
   }
-  const bool rw = !use_small(ctx, K) && use_rowwave(ctx, K, (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0);
-  if ((rc = rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
+  const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
+  const bool nw = use_narrow(ctx, K, true, !wants_tables);
+  const bool rw = !nw && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
+  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_call = rw;
+  ctx->narrow_call = nw ? 2 : 0;
   rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr);
   ctx->rowwave_call = false;
+  ctx->narrow_call = 0;
   if (rc) return rc;
   if (labels_out && !(flags & MIMO_F_DEVICE_OUT)) {
     HIP_TRY(ctx, hipMemcpyAsync(labels_out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1337,6 +1413,10 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   if (use_small(ctx, K)) {
     out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
     out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
+  } else if (use_narrow(ctx, K, gibbs != 0, true)) {
+    out8[0] = MIMO_PLAN_NARROW; out8[1] = gibbs ? 2 : 1;
+    if (gibbs) { out8[4] = 2; out8[5] = 2; }
+    out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, gibbs ? 1 : 0);
   } else if (!gibbs && ctx->n_bad == 0 && ctx->D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     out8[6] = rowwave_grid(a, ctx->num_cu);

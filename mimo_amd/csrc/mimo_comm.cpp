@@ -48,7 +48,11 @@ static Api& api() {
 // returns 0 or a negative MIMO_E_* code; msg receives a short description on failure
 int unique_id(char* out128, char* msg, size_t msglen) {
   Api& a = api();
-  if (!a.ok) { snprintf(msg, msglen, "librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing"); return MIMO_E_UNSUPPORTED; }
+  if (!a.ok) {
+    const char* why = dlerror();          // (a second call would return NULL: the message is consumed by the first)
+    snprintf(msg, msglen, "librccl could not be opened (%s)", why ? why : "symbols missing");
+    return MIMO_E_UNSUPPORTED;
+  }
   ncclUniqueId id;
   const ncclResult_t r = a.GetUniqueId(&id);
   if (r != ncclSuccess) { snprintf(msg, msglen, "ncclGetUniqueId: %s", a.GetErrorString(r)); return MIMO_E_HIP; }

@@ -105,6 +105,47 @@ __device__ __forceinline__ double exp_nonpos_t2048(double x, const double* __res
   return __hiloint2double(__double2hiint(e) + (nh << 20), __double2loint(e));
 }
 
+// The same exponential with ONE integer instruction for the factor 2^(n >> 11) instead of two: table entry i holds the bit
+// pattern of 2^(i/2048) with (i << 9) subtracted from its high word, so that adding (n << 9) — n = 2048 (n >> 11) + i — to
+// the high word lands on hi(2^(i/2048)) + ((n >> 11) << 20): the low bits of n cancel by construction (v_lshl_add_u32 in
+// place of v_ashrrev_i32 + v_lshl_add_u32).  12 instructions with the subtraction of the row maximum; same error bound.
+__device__ __forceinline__ double exp_tab_entry_c(int i) {
+  const double v = exp2((double)i * (1.0 / kExpTab));
+  return __hiloint2double(__double2hiint(v) - (i << 9), __double2loint(v));
+}
+__device__ __forceinline__ double exp_nonpos_t2048c(double x, const double* __restrict__ tab) {
+  x = fmax(x, -707.0);
+  const double t = fma(x, 2954.639443740597, 6755399441055744.0);          // 2048 / ln2, 1.5 * 2^52
+  const int n = __double2loint(t);
+  const double nf = t - 6755399441055744.0;
+  const double r = fma(nf, -3.3845077175778103e-04, x);                    // ln2 / 2048
+  double q = fma(r, 1.0 / 6.0, 0.5);
+  q = fma(r, q, 1.0);
+  const double tv = tab[n & (kExpTab - 1)];
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, 9, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(tv)));
+  return __hiloint2double(hi, __double2loint(tv)) * fma(r, q, 1.0);
+}
+
+// ... in two halves, so that a kernel can put a batch of table reads in flight before it needs the first of them (hipcc
+// otherwise keeps two lookups in flight and waits ~25 cycles after each read: the LDS round trip of every pair of
+// exponentials lay open in narrow_kernel, 31 % of the pipe idle at three waves per SIMD):
+//   exp_c_issue:  reduced argument r and the integer n (table index n & 2047, scale n >> 11);   the caller reads tab[n & 2047]
+//   exp_c_finish: cubic in r times the scaled table entry
+__device__ __forceinline__ void exp_c_issue(double x, double& r, int& n) {
+  x = fmax(x, -707.0);
+  const double t = fma(x, 2954.639443740597, 6755399441055744.0);
+  n = __double2loint(t);
+  r = fma(t - 6755399441055744.0, -3.3845077175778103e-04, x);
+}
+__device__ __forceinline__ double exp_c_finish(double r, int n, double tv) {
+  double q = fma(r, 1.0 / 6.0, 0.5);
+  q = fma(r, q, 1.0);
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, 9, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(tv)));
+  return __hiloint2double(hi, __double2loint(tv)) * fma(r, q, 1.0);
+}
+
 // ------------------------------------------------------------------------------------------
 // Short dependency chains.  The f64 VALU shares its pipe with the f64 MFMA, and the wave of the OTHER
 // workgroup on this SIMD is usually inside a matrix phase: every time this wave has no ready f64

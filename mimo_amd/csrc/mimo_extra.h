@@ -38,4 +38,12 @@ struct KernelArgs;
 bool vi_rowwave_covers(int K, int F16, int ZS);
 hipError_t launch_vi_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
 
+// narrow shapes (F <= 16 features, 32 < K <= 128) on v_mfma_f64_4x4x4_4b (mimo_narrow.hip); theta in the narrow image
+// [NSF V][16]: slice s V + c, entry 4 k + j = Theta[component j V + c][feature 4 s + k]
+int narrow_v(int K);                 // component slots per lane (4 V >= K), 0: not instantiated
+int narrow_nsf(int F);               // contraction steps: ceil(F / 4)
+bool narrow_covers(int K, int F, int D, int ZS, int gibbs);
+int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs);
+hipError_t launch_narrow(const KernelArgs& a, int F, int gibbs, int grid, hipStream_t stream);
+
 }  // namespace mimo

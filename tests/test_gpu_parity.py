@@ -667,7 +667,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(900 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] == "rowwave"
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if D <= 4 and 33 <= K <= 128 else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
@@ -879,7 +879,7 @@ def test_row_owner_softmax_pass(engine, D, K, N):
     rng = np.random.default_rng(4000 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K)["kind"] == ("rowwave-vi" if (D, K) not in ((2, 33), (1, 33)) else "fused")
+    assert engine.plan(K)["kind"] == ("rowwave-vi" if (D, K) not in ((2, 33), (1, 33)) else "narrow")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)
     R = np.exp(L - lse)
@@ -915,3 +915,60 @@ def test_empty_data_on_the_row_owner_kernels(engine):
         lab, G = engine.gibbs_labels(c, b, W, seed=1, sweep=1)
         assert lab.shape == (0,) and not G.n.any() and not G.sxx.any()
         assert not engine.label_stats(np.zeros(0, dtype=np.int32), K).n.any()
+
+
+NARROW_SHAPES = [(2, 50), (2, 64), (2, 33), (2, 100), (2, 128), (1, 50), (1, 97), (1, 128), (3, 50), (3, 64), (3, 96), (3, 127),
+                 (4, 48), (4, 50), (4, 64), (4, 100), (4, 128), (2, 37), (2, 41), (2, 53), (2, 57), (2, 69), (2, 77), (2, 85),
+                 (2, 93), (2, 101), (2, 109), (2, 117), (2, 125)]
+
+
+@pytest.mark.parametrize("D,K", NARROW_SHAPES)
+@pytest.mark.parametrize("N", [1, 17, 5003, 4 * 256 * 16 * 5 + 11])
+def test_narrow_kernels_vs_oracle(engine, D, K, N):
+    """narrow_kernel (mimo_narrow.hip: Dz <= 4 with 32 < K <= 128 — the reference's ILR defaults, examples/ilr/evaluate_sine.py:35 —
+    both products on v_mfma_f64_4x4x4_4b, every instantiated slot count V): the softmax pass (statistics, sum_n lse_n, identical
+    bits on a second launch, asynchronous form, a switched-off component) and the label pass (labels bit-exact for host
+    uniforms and the Philox stream, counts exact, statistics) against the oracle; the generic requests of the same shape
+    still go through the tile kernels and agree."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(7000 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K)["kind"] == "narrow" and engine.plan(K, gibbs=True)["kind"] == "narrow"
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R)
+    S, sc = engine.estep(c, b, W)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    S1, sc1 = engine.estep(c, b, W)
+    assert np.array_equal(S1.sxx, S.sxx) and np.array_equal(S1.sx, S.sx) and np.array_equal(S1.n, S.n) and sc1[0] == sc[0]
+    engine.estep_async(c, b, W)
+    S2, sc2 = engine.estep_wait()
+    assert np.array_equal(S2.sxx, S.sxx) and sc2[0] == sc[0]
+    # label pass
+    u = rng.random(N)
+    lab, G = engine.gibbs_labels(c, b, W, u=u)
+    ref = O.sample_discrete_from_log(L, u)
+    assert np.array_equal(lab, ref)
+    gn, gsx, gsxx = O.packed_stats(Z, O.one_hot(ref, K))
+    assert np.array_equal(G.n, gn) and rel_err(G.sx, gsx) < 1e-11 and rel_err(G.sxx, gsxx) < 1e-11
+    lab_p, Gp = engine.gibbs_labels(c, b, W, seed=5, sweep=3)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(5, np.arange(N), 3))
+    assert np.array_equal(lab_p, ref_p) and np.array_equal(Gp.n, np.bincount(ref_p, minlength=K))
+    lab_q, Gq = engine.gibbs_labels(c, b, W, seed=5, sweep=3)
+    assert np.array_equal(lab_q, lab_p) and np.array_equal(Gq.sxx, Gp.sxx)
+    assert np.array_equal(engine.get_labels(), ref_p)
+    if N <= 6000:
+        Sg, scg = engine.estep(c, b, W, keep_resp=True, entropy_split=True)      # generic request: tile kernels
+        assert rel_err(Sg.sxx, sxx) < 1e-11 and rel_err(engine.get_resp(), R) < 1e-11 and abs(scg[0] - sc[0]) < 1e-11 * max(1., abs(sc[0]))
+        c2 = c.copy(); c2[K // 2] = -np.inf                          # a switched-off component
+        L2 = L.copy(); L2[K // 2] = -np.inf
+        lse2 = logsumexp(L2, axis=0)
+        n2, _, sxx2 = O.packed_stats(Z, np.exp(L2 - lse2))
+        So, sco = engine.estep(c2, b, W)
+        assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * max(1., abs(lse2.sum()))
+        lab_o, Go = engine.gibbs_labels(c2, b, W, seed=1, sweep=1)
+        assert not np.any(lab_o == K // 2) and Go.n[K // 2] == 0 and Go.n.sum() == N
