@@ -75,6 +75,7 @@ struct mimo_ctx {
   int64_t n_bad = 0;
   unsigned long long* cnt_d = nullptr;                    // [1 + 256]: scan count, labels drawn on NaN rows per component
   int32_t* labels_tmp = nullptr; size_t labels_tmp_cap = 0;
+  uint32_t* ls_aux = nullptr;                              // label histogram + slot table of label_stats_slots_kernel
   double* table_tmp = nullptr;  size_t table_tmp_cap = 0;
   int bad_counts_K = 0;         // > 0: cnt_d[1..K] holds the label counts of the NaN rows of the last label pass
 
@@ -251,6 +252,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->do_stats = 1;
   a->diag = ctx->structure != 0;
   a->ntiles = (ctx->N + kTile - 1) / kTile;
+  a->aux = ctx->ls_aux;
 }
 
 // (c, b, W) -> Theta[k][f] -> MFMA A-operand image [K16][F16/4][64] on the device.
@@ -263,14 +265,18 @@ static bool use_small(const mimo_ctx* ctx, int K) {
 
 // small-shape kernel: Theta[G KL][F] row-major over the FULL feature map (feat_index order); a structure hint only
 // decides which entries of W are read (diagonal: W_aa; linear: none — the shared quadratic term stays with the caller)
-static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, double* inline_out) {
   const int D = ctx->D, F = feat_count(D), Kp = small_g(D, K) * small_kl(D, K);
   const size_t count = (size_t)Kp * F;
+  // one lane per row (G = 1): Theta goes into the kernel arguments — no staging buffer to wait for, no transfer to enqueue
+  const bool inl = inline_out && small_g(D, K) == 1 && count <= (size_t)kThetaInline;
   int rc;
-  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
-  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the staging buffer may still be in flight
-  double* img = ctx->theta_h;
+  if (!inl) {
+    if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+    if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the staging buffer may still be in flight
+  }
+  double* img = inl ? inline_out : ctx->theta_h;
   memset(img, 0, count * sizeof(double));
   bool finite = true;
   auto chk = [&](double v) { finite = finite && std::fabs(v) <= 1.7976931348623157e308; return v; };
@@ -298,7 +304,7 @@ static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, c
   }
   if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
   for (int k = K; k < Kp; ++k) img[(size_t)k * F + F - 1] = kPadLogDensity;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (!inl) HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MIMO_OK;
 }
 
@@ -407,8 +413,8 @@ static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, 
   return MIMO_OK;
 }
 
-static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  if (use_small(ctx, K)) return upload_theta_small(ctx, c, b, W, K);
+static int upload_theta(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, KernelArgs* a = nullptr) {
+  if (use_small(ctx, K)) return upload_theta_small(ctx, c, b, W, K, a ? a->theta_inline : nullptr);
   const int D = ctx->D, F16 = ctx->F16;
   const int K16 = ((K + 15) / 16 <= 4) ? 4 : 16;   // every wave streams 1 (K<=64) or up to 4 row blocks; unused ones are zero
   // fused kernels step through F16/4 slices per row block; the chunked E-step through whole chunks
@@ -527,7 +533,6 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const size_t pstride = (size_t)Kpad * a.F16 + 4;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->partials, &ctx->partials_cap, pstride * (size_t)grid))) return rc;
-  if ((rc = ensure_dev(ctx, &ctx->reduced, &ctx->reduced_cap, pstride))) return rc;
   a.partials = ctx->partials;
 
 #ifdef MIMO_STAMPS
@@ -668,14 +673,14 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const bool device_out = (flags & MIMO_F_DEVICE_OUT) != 0;
   if (!want_stats && !scalars && !async) return MIMO_OK;
 
-  HIP_TRY(ctx, launch_reduce(ctx->partials, grid, (int64_t)pstride, ctx->reduced, ctx->stream));
   const size_t slen = (size_t)K * (1 + D + (size_t)D * D);
   // the small-shape kernel always accumulates the full feature map: under a structure hint the entries outside
   // the structure are masked to the zeros the hint promises
   const uint8_t* feat = small ? ctx->feat_full_d : ctx->feat_d;
   const int F = small ? feat_count(D) : ctx->F, mask = small ? ctx->structure : 0;
   if (device_out) {
-    HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? S : nullptr, scalars, ctx->stream, mask));
+    HIP_TRY(ctx, launch_reduce_unpack(ctx->partials, grid, (int64_t)pstride, feat, K, D, F, a.F16, want_stats ? S : nullptr, scalars,
+                                      ctx->stream, mask));
     if (ctx->comm) {     // sharded through this library: sum over the ranks where the caller wants the block
       char msg[256];
       if (want_stats && (rc = mimo_comm::allreduce_sum_f64(ctx->comm, S, slen, ctx->stream, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
@@ -685,14 +690,19 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   }
   if ((rc = ensure_dev(ctx, &ctx->S_d, &ctx->S_cap, slen + 4))) return rc;
   if ((rc = ensure_pinned(ctx, &ctx->S_h, &ctx->S_hcap, slen + 4))) return rc;
+  // Without a communicator and on the full feature map the reduction writes the packed block straight into the pinned host
+  // buffer (device-visible, hipHostMalloc): no device copy of the block, no D2H transfer behind the kernel.
+  static const bool direct_on = [] { const char* e = getenv("MIMO_DIRECT_OUT"); return !e || atoi(e) != 0; }();   // tuning knob
+  const bool direct = direct_on && !ctx->comm && F == feat_count(D);
+  double* dst = direct ? ctx->S_h : ctx->S_d;
   if (ctx->comm && !want_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->S_d, 0, slen * sizeof(double), ctx->stream));
-  HIP_TRY(ctx, launch_unpack(ctx->reduced, feat, K, D, F, a.F16, want_stats ? ctx->S_d : nullptr,
-                             ctx->S_d + slen, ctx->stream, mask));
+  HIP_TRY(ctx, launch_reduce_unpack(ctx->partials, grid, (int64_t)pstride, feat, K, D, F, a.F16, want_stats ? dst : nullptr,
+                                    dst + slen, ctx->stream, mask));
   if (ctx->comm) {       // ONE all-reduce(sum, f64) of [K (1 + Dz + Dz^2) + 3] per pass, behind the kernels on the same stream
     char msg[256];
     if ((rc = mimo_comm::allreduce_sum_f64(ctx->comm, ctx->S_d, slen + 3, ctx->stream, msg, sizeof msg))) return fail(ctx, rc, "%s", msg);
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) HIP_TRY(ctx, hipMemcpyAsync(ctx->S_h, ctx->S_d, (slen + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (flags & MIMO_F_ASYNC) {
     ctx->pending_async = true; ctx->pending_slen = slen; ctx->pending_stats = want_stats;
     return MIMO_OK;
@@ -777,6 +787,11 @@ int mimo_create(mimo_ctx** out, int device) {
     return fail(nullptr, MIMO_E_HIP, "hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->ls_aux), label_stats_aux_words() * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return fail(nullptr, MIMO_E_HIP, "hipMalloc failed");
+  }
   *out = ctx;
   return MIMO_OK;
   });
@@ -789,7 +804,7 @@ int mimo_destroy(mimo_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   drain_profile(ctx);
   if (ctx->comm) { (void)mimo_comm::destroy(ctx->comm); ctx->comm = nullptr; }
-  void* bufs[] = {ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->row_mask, ctx->cnt_d, ctx->labels_tmp, ctx->table_tmp, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
+  void* bufs[] = {ctx->ls_aux, ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->row_mask, ctx->cnt_d, ctx->labels_tmp, ctx->table_tmp, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
                   ctx->logp, ctx->lse, ctx->labels, ctx->u_d, ctx->win, ctx->lin};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (ctx->theta_h) (void)hipHostFree(ctx->theta_h);
@@ -828,9 +843,15 @@ static int scan_nan_rows(mimo_ctx* ctx) {
   if (ctx->N <= 0) return MIMO_OK;
   int rc;
   if (!ctx->cnt_d) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->cnt_d), 257 * sizeof(unsigned long long)));
+  // flat scan first (one coalesced read of Z): data without a NaN — the usual case — is done after it
+  HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, launch_nan_any(ctx->Z, ctx->N * ctx->D, reinterpret_cast<unsigned int*>(ctx->cnt_d), ctx->num_cu, ctx->stream));
+  unsigned long long nb = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&nb, ctx->cnt_d, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (nb == 0) return MIMO_OK;
   HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, launch_nan_scan(const_cast<double*>(ctx->Z), ctx->N, ctx->D, nullptr, ctx->cnt_d, false, ctx->stream));
-  unsigned long long nb = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&nb, ctx->cnt_d, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (nb == 0) return MIMO_OK;
@@ -932,7 +953,7 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
   const bool nv = use_narrow(ctx, K, false, plain);      // narrow shapes (Dz <= 4, 32 < K <= 128): mimo_narrow.hip
   const bool rv = !nv && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
-  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
   ctx->narrow_call = nv ? 1 : 0;
@@ -972,7 +993,7 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
     a.u = ctx->u_d;
     ctx->weights_resident = true;
   }
-  if ((rc = upload_theta(ctx, c, b, W, K))) return rc;
+  if ((rc = upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   return run_fused(ctx, a, kSrcEstep, flags, S, scalars);
   });
@@ -1024,7 +1045,7 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
   const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
   const bool nw = use_narrow(ctx, K, true, !wants_tables);
   const bool rw = !nw && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
-  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K))) return rc;
+  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_call = rw;
   ctx->narrow_call = nw ? 2 : 0;

@@ -13,6 +13,7 @@ hipError_t launch_sample_table(const double* logp, int K, int64_t N, const doubl
 hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int64_t row0, hipStream_t stream);
 
 // rows with missing values (mimo_small.hip): scan (+ zero the rows and write the mask when `write`), masked labels / tables
+hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream);   // flag |= 1 if any element is a NaN
 hipError_t launch_nan_scan(double* Z, int64_t N, int D, double* mask, unsigned long long* count, bool write, hipStream_t stream);
 hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t* out, int64_t N, int K,
                               unsigned long long* bad_counts, hipStream_t stream);
@@ -32,6 +33,9 @@ hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 
 // label statistics (mimo_rowwave.hip): launches of one pass — 1, or the slice groups of the Dz > 16 / large-K kernel
 int label_stats_launches(int K, int D, int structure);
+// ... and the slot-table variant for skewed label vectors (K >= 17, Dz <= 9, N >= 2^17): needs KernelArgs::aux
+bool label_stats_uses_slots(int K, int D, int64_t N);
+size_t label_stats_aux_words();
 
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;

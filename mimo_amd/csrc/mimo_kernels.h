@@ -19,6 +19,8 @@ enum Source : int { kSrcEstep = 0, kSrcWeights = 1, kSrcLabels = 2 };
 // other-mode code (register pressure decides occupancy here); kGeneric keeps every runtime flag.
 enum Mode : int { kFastVI = 0, kFastGibbs = 1, kGeneric = 2, kModeWeights = 3, kModeLabels = 4 };
 
+constexpr int kThetaInline = 40;
+
 struct KernelArgs {
   const double* Z;        // (N, D) row-major observations
   int64_t N;
@@ -46,6 +48,8 @@ struct KernelArgs {
   int write_scalars;      // write the 4 scalar slots of the partial block (0: another launch owns them)
   int diag;               // feature table is a reduced one (diagonal: 2 Dz + 1, linear: Dz + 1 features): table-driven E-step kernels
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
+  double theta_inline[40];  // small-shape kernel with one lane per row (G = 1): Theta itself (kThetaInline doubles at most)
+  uint32_t* aux;          // label_stats_slots_kernel: label histogram + slot table (label_stats_aux_words() words)
 };
 
 // feature count helpers (z~ = [z,1]; features = upper-triangular pairs of z~)
@@ -79,6 +83,9 @@ int stats_group_ncb(int K16);   // feature column blocks one statistics launch c
 hipError_t launch_reduce(const double* partials, int G, int64_t stride, double* out, hipStream_t stream);
 // mask_structure: 0 = write every feature of the table; MIMO_STRUCT_DIAG / _LINEAR = the table is the FULL map but
 // only the entries of that structure are real (small-shape kernel): the others come back as zeros
+// both in one launch (mimo_small.hip)
+hipError_t launch_reduce_unpack(const double* partials, int G, int64_t stride, const uint8_t* feat, int K, int D, int F, int F16,
+                                double* S_packed, double* scalars3, hipStream_t stream, int mask_structure = 0);
 hipError_t launch_unpack(const double* reduced, const uint8_t* feat, int K, int D, int F, int F16,
                          double* S_packed, double* scalars3, hipStream_t stream, int mask_structure = 0);
 

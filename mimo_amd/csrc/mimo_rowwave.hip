@@ -29,6 +29,17 @@
 
 namespace mimo {
 
+// diagnostic builds (-DMIMO_STAMPS, make stamps): cycles per phase of the label-statistics kernels, summed per wave
+#ifdef MIMO_STAMPS
+#define LS_STAMP_INIT unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
+#define LS_STAMP(i) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[i] += t1_ - st_t0; st_t0 = t1_; }
+#define LS_STAMP_STORE if (a.stamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) a.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = st_[i_]; }
+#else
+#define LS_STAMP_INIT
+#define LS_STAMP(i)
+#define LS_STAMP_STORE
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Label pass.  KB = row blocks (16 components each) the accumulators cover; K <= 16 KB.
 // Operand image (host, upload_theta_rowwave): slice e = s KB + rb, lane (i = lane & 15, kk = lane >> 4) holds
@@ -623,9 +634,11 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     }
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+  LS_STAMP_INIT
 
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     wg_sync();                        // the previous tile's readers are done
+    LS_STAMP(0)
 #pragma unroll
     for (int i = 0; i < ZPT; ++i) {
       const int e = tid + kWG * i;
@@ -638,10 +651,13 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     }
     const int l0 = lab[0], l1 = lab[1];
     if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+    LS_STAMP(1)
     wg_sync();
+    LS_STAMP(2)
     if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
     if (RPT > 1 && l1 >= 0) atomicOr(&bitmap[l1 * NW + ((tid + kWG) >> 5)], 1u << (tid & 31));
     wg_sync();
+    LS_STAMP(3)
     // rows of component tid, and the exclusive prefix over the components (where its list starts)
     int cntk = 0;
     {
@@ -666,6 +682,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     start[tid] = off + incl - cntk;
     cnts[tid] = cntk;
     wg_sync();
+    LS_STAMP(4)
     // stable position of each row in its component's list
     auto place = [&](int l, int row) {
       if (l < 0) return;
@@ -678,6 +695,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
     place(l0, tid);
     if (RPT > 1) place(l1, tid + kWG);
     wg_sync();
+    LS_STAMP(5)
     // thread (component myk, part mypart): every P-th row of the component's list, ascending
     const int st = start[myk], cmine = cnts[myk];
     for (int p = mypart; p < cmine; p += P) {
@@ -703,7 +721,9 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
       }
       acc[F - 1] += 1.0;
     }
+    LS_STAMP(6)
   }
+  LS_STAMP_STORE
 
   // per-workgroup partial block [16 K16][F16_total] (+ 4 scalars: none from this pass)
   const int FT = a.F16_total;
@@ -740,6 +760,260 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
   if (P > 1 && Kp < a.K16 * 16) {       // rows of the partial block between Kp and 16 K16 (K = 17 .. 31 -> Kp = 32 covers them; K <= 16 -> Kp = 16 = 16 K16)
     for (int k = Kp + tid; k < a.K16 * 16; k += kWG)
       for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
+  }
+  if (tid == 0 && a.write_scalars) {
+    double* Ps = P_out + (size_t)a.K16 * 16 * FT;
+    Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same pass with the 256 threads of a workgroup assigned to components IN PROPORTION TO THEIR ROWS (K >= 17, Dz <= 9,
+// N >= 2^17).  label_stats_kernel gives every component the same number of threads; a DP-GMM sweep at Kmax = 256 keeps its
+// rows on a few dozen components, so one lane in eight works while the others wait for it (N = 1e7, Dz = 8, K = 256: 378 us with
+// the rows on 32 components against 239 us for uniformly drawn labels; phase stamps of tools/stamps_label_stats.py: list
+// placement 22 %, accumulation 22 %, prefix scan 13 % of the wave time, the rest waiting for the tile).  Here:
+//   label_hist_kernel    counts the labels of the whole launch (integer atomics: order-free),
+//   label_slots_kernel   hands out the 256 slots: one per NON-EMPTY component, the rest in proportion to the counts,
+//   label_stats_slots_kernel  slot (component k, part p of n_k) takes the rows of rank p, p + n_k, .. of ITS component's
+//                        ascending list of the tile; the parts of a component are added in part order at the end.
+// The result is a function of the label vector alone (the slot table is built from it): run-to-run bit-identical.
+// Also new against label_stats_kernel: a row's place in the list is one lookup (per-component prefix of the bitmap's word
+// popcounts) instead of a loop over the words below it; rows on an odd stride read with 8-byte loads; bitmap rows padded off
+// the 64-byte stride that put every component's words into the same banks.
+// Tried and dropped on the way (tools/label_stats_time.py): a kernel that walked the set bits of a component's bitmap
+// directly (no prefix scan, no list): its divergent bit loop cost ~1000 cycles per iteration whatever the body (152 against
+// 87 us, Dz = 8, K = 256, N = 2e6); and 512-thread workgroups over 1024-row tiles with 256 helper slots: indifferent to the
+// skew (309 us either way) but one workgroup per CU, whose five serial phases nothing overlaps (239 us before, uniform labels).
+// ------------------------------------------------------------------------------------------
+constexpr int kLsSlots = kWG;                  // aux layout (uint32): hist[256] | nparts[256] | first slot[256] | slot table[256]
+constexpr int kLsAuxWords = 256 * 4;
+
+__global__ __launch_bounds__(kWG) void label_hist_kernel(const int32_t* __restrict__ labels, int64_t N, int K, uint32_t* __restrict__ aux) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0u;
+  wg_sync();
+  for (int64_t n = (int64_t)blockIdx.x * kWG + threadIdx.x; n < N; n += (int64_t)gridDim.x * kWG) {
+    const int l = labels[n];
+    if (l >= 0 && l < K) atomicAdd(&h[l], 1u);
+  }
+  wg_sync();
+  if (h[threadIdx.x]) atomicAdd(&aux[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kWG) void label_slots_kernel(uint32_t* __restrict__ aux, int K) {
+  __shared__ uint32_t sc[kWG];
+  const int k = threadIdx.x;
+  const uint32_t ck = k < K ? aux[k] : 0u;
+  sc[k] = ck;
+  wg_sync();
+  unsigned long long tot = 0ull;
+  uint32_t ne = 0u;
+  for (int i = 0; i < kWG; ++i) { tot += sc[i]; ne += sc[i] ? 1u : 0u; }
+  // one slot per non-empty component + floor(spare count_k / total) of the spare ones (their sum cannot exceed the spare)
+  const uint32_t nk = ck ? 1u + (uint32_t)(((unsigned long long)(kLsSlots - ne) * ck) / tot) : 0u;
+  wg_sync();
+  sc[k] = nk;
+  wg_sync();
+  uint32_t base = 0u, used = 0u;
+  for (int i = 0; i < kWG; ++i) { if (i < k) base += sc[i]; used += sc[i]; }
+  aux[256 + k] = nk;
+  aux[512 + k] = base;
+  wg_sync();
+  for (uint32_t j = 0; j < nk; ++j) aux[768 + base + j] = (uint32_t)k | (j << 16);
+  if ((uint32_t)k >= used) aux[768 + k] = 0xffffffffu;                 // slots nobody got
+}
+
+constexpr int ls_feat(int DZ, int FS) { return FS == 0 ? (DZ + 1) * (DZ + 2) / 2 : FS == 1 ? 2 * DZ + 1 : DZ + 1; }
+
+template <int DZ, int FS = 0>
+__global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kernel(const KernelArgs a) {
+  constexpr int F = ls_feat(DZ, FS);
+#ifdef MIMO_LS_ODD_STRIDE
+  constexpr int ZS = DZ | 1;
+#else
+  constexpr int ZS = DZ <= 2 ? 2 : DZ <= 6 ? 6 : DZ <= 10 ? 10 : DZ <= 14 ? 14 : 18;   // 16-byte aligned rows, odd stride in 16-byte units
+#endif
+  constexpr int T = kLsTile, NW = T / 32;                  // 512 rows, 16 bitmap words per component
+  constexpr int BS = NW + 4, PS = NW + 8;                  // padded row strides of the bitmap (words: 80 bytes) and of its prefix table (u16: 48 bytes)
+  constexpr int RPT = T / kWG;                             // 2 rows per thread and tile
+  constexpr int ZPT = (T * DZ + kWG - 1) / kWG;
+  __shared__ __align__(16) double Zt[T * ZS > kWG * 8 ? T * ZS : kWG * 8];           // (the epilogue's red[256][8] aliases it)
+  __shared__ __align__(16) uint32_t bitmap[kWG * BS];
+  __shared__ __align__(16) uint16_t wpre[kWG * PS];                                  // set bits below word w of component k
+  __shared__ uint16_t list[T];
+  __shared__ int start[kWG];
+  __shared__ int cnts[kWG];
+  __shared__ int wsum[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T;
+  const uint32_t* aux = a.aux;
+  const uint32_t ent = aux[768 + tid];
+  const bool live = ent != 0xffffffffu;
+  const int myk = live ? (int)(ent & 0xffffu) : 0, mypart = live ? (int)(ent >> 16) : 0;
+  const int nparts = live ? (int)aux[256 + myk] : 1;
+
+  double acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.0;
+
+  double zr[ZPT];
+  int lab[RPT];
+  auto load_tile = [&](int64_t t) {
+    const int64_t base = t * T * DZ, total = N * DZ;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int64_t g = base + tid + (int64_t)kWG * i;
+      zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+      const int64_t n = t * T + tid + kWG * h;
+      const int l = n < N ? a.labels[n] : -1;
+      lab[h] = l < K ? l : -1;            // a label outside [0, K) (a caller's vector) is skipped, never an index
+    }
+  };
+  if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+  LS_STAMP_INIT
+
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    wg_sync();                        // the previous tile's readers are done
+    LS_STAMP(0)
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+      const int e = tid + kWG * i;
+      if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
+    }
+    {
+      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * BS);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
+    }
+    int l01[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) l01[h] = lab[h];
+#ifndef MIMO_LS_WHATIF_NOLOAD          // (diagnostic what-if: every tile re-uses the first tile's rows — no HBM traffic)
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+#endif
+    LS_STAMP(1)
+    wg_sync();
+    LS_STAMP(2)
+#pragma unroll
+    for (int h = 0; h < RPT; ++h)
+      if (l01[h] >= 0) atomicOr(&bitmap[l01[h] * BS + ((tid + kWG * h) >> 5)], 1u << (tid & 31));
+    wg_sync();
+    LS_STAMP(3)
+    // rows of component tid, the prefix of its bitmap words, and the exclusive prefix over the components
+    int cntk = 0;
+    {
+      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * BS);
+      uint4* wp = reinterpret_cast<uint4*>(wpre + tid * PS);
+#pragma unroll
+      for (int w8 = 0; w8 < NW / 8; ++w8) {              // eight words in, eight 16-bit prefixes out
+        const uint4 v0 = bm[2 * w8], v1 = bm[2 * w8 + 1];
+        const uint32_t p0 = cntk;           cntk += __popc(v0.x);
+        const uint32_t p1 = cntk;           cntk += __popc(v0.y);
+        const uint32_t p2 = cntk;           cntk += __popc(v0.z);
+        const uint32_t p3 = cntk;           cntk += __popc(v0.w);
+        const uint32_t p4 = cntk;           cntk += __popc(v1.x);
+        const uint32_t p5 = cntk;           cntk += __popc(v1.y);
+        const uint32_t p6 = cntk;           cntk += __popc(v1.z);
+        const uint32_t p7 = cntk;           cntk += __popc(v1.w);
+        wp[w8] = uint4{p0 | (p1 << 16), p2 | (p3 << 16), p4 | (p5 << 16), p6 | (p7 << 16)};
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int v = __shfl_up(incl, sft);
+      if (lane >= sft) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    start[tid] = off + incl - cntk;
+    cnts[tid] = cntk;
+    wg_sync();
+    LS_STAMP(4)
+    // stable position of each row in its component's list: one prefix lookup + one popcount
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+      const int l = l01[h], row = tid + kWG * h;
+      if (l >= 0) {
+        const int wq = row >> 5;
+        const int rank = (int)wpre[l * PS + wq] + __popc(bitmap[l * BS + wq] & ((1u << (row & 31)) - 1u));
+        list[start[l] + rank] = (uint16_t)row;
+      }
+    }
+    wg_sync();
+    LS_STAMP(5)
+    // slot (component myk, part mypart of nparts): every nparts-th row of the component's list, ascending
+    if (live) {
+      const int st = start[myk], cmine = cnts[myk];
+      for (int p = mypart; p < cmine; p += nparts) {
+        const int row = list[st + p];
+        const double* zp = Zt + row * ZS;
+        double z[DZ];
+#pragma unroll
+        for (int d = 0; d < DZ; ++d) z[d] = zp[d];
+        if constexpr (FS == 0) {
+          int f = 0;
+#pragma unroll
+          for (int i = 0; i < DZ; ++i) {
+#pragma unroll
+            for (int jx = i; jx < DZ; ++jx) { acc[f] = fma(z[i], z[jx], acc[f]); ++f; }
+            acc[f] += z[i]; ++f;
+          }
+        } else if constexpr (FS == 1) {
+#pragma unroll
+          for (int i = 0; i < DZ; ++i) { acc[i] = fma(z[i], z[i], acc[i]); acc[DZ + i] += z[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < DZ; ++i) acc[i] += z[i];
+        }
+        acc[F - 1] += 1.0;
+      }
+    }
+    LS_STAMP(6)
+  }
+  LS_STAMP_STORE
+
+  // per-workgroup partial block [16 K16][F16_total]: the slots of a component are neighbours; part 0 adds them in part order, eight
+  // features at a time, and writes the component's row; a component without rows in the whole launch has no slot: zeros
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P_out = a.partials + (size_t)blockIdx.x * pstride;
+  double* red = Zt;                                      // [256][8]
+  const bool owner = live && mypart == 0;
+#pragma unroll
+  for (int f0 = 0; f0 < F; f0 += 8) {
+    wg_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (f0 + i < F) red[tid * 8 + i] = acc[f0 + i];
+    wg_sync();
+    if (owner) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (f0 + i < F) {
+          double s2 = acc[f0 + i];
+          for (int q = 1; q < nparts; ++q) s2 += red[(tid + q) * 8 + i];
+          acc[f0 + i] = s2;
+        }
+      }
+    }
+  }
+  if (owner) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) P_out[(size_t)myk * FT + f] = acc[f];
+  }
+  if (tid < a.K16 * 16 && (tid >= K || aux[256 + tid] == 0u)) {
+    for (int f = 0; f < F; ++f) P_out[(size_t)tid * FT + f] = 0.0;
   }
   if (tid == 0 && a.write_scalars) {
     double* Ps = P_out + (size_t)a.K16 * 16 * FT;
@@ -1150,12 +1424,34 @@ int label_stats_launches(int K, int D, int structure) {
   return fpt / fpl;
 }
 
+// K >= 17 at Dz <= 9 with at least 2^17 rows: label_stats_slots_kernel (MIMO_LABEL_STATS_SLOTS=0: the round-2 kernel, tuning knob)
+static bool label_stats_slots_on() {
+  static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_SLOTS"); return !e || atoi(e) != 0; }();
+  return on;
+}
+bool label_stats_uses_slots(int K, int D, int64_t N) {
+  return label_stats_slots_on() && K >= 17 && K <= 256 && D >= 1 && D <= 9 && N >= (1 << 17);
+}
+size_t label_stats_aux_words() { return kLsAuxWords; }
+
 int label_stats_grid(const KernelArgs& a, int num_cu) {
   const int tile = a.D <= (a.diag ? 10 : 9) ? kLsTile : kLsWideTile;
   const int64_t tiles = (a.N + tile - 1) / tile;
-  int64_t g = (int64_t)num_cu * 2;
+  int64_t g = (int64_t)num_cu * (label_stats_uses_slots(a.K, a.D, a.N) && a.D <= 2 ? 3 : 2);     // (52 KB of LDS, <= 88 registers: three per CU)
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
+}
+
+template <int FS>
+static void (*pick_label_stats_slots(int D))(const KernelArgs) {
+  switch (D) {
+    case 1: return label_stats_slots_kernel<1, FS>;   case 2: return label_stats_slots_kernel<2, FS>;
+    case 3: return label_stats_slots_kernel<3, FS>;   case 4: return label_stats_slots_kernel<4, FS>;
+    case 5: return label_stats_slots_kernel<5, FS>;   case 6: return label_stats_slots_kernel<6, FS>;
+    case 7: return label_stats_slots_kernel<7, FS>;   case 8: return label_stats_slots_kernel<8, FS>;
+    case 9: return label_stats_slots_kernel<9, FS>;
+  }
+  return nullptr;
 }
 
 template <int FS>
@@ -1207,6 +1503,19 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
   typedef void (*fn_t)(const KernelArgs);
   if (a.D < 1 || a.D > kMaxD || a.K < 1 || a.K > 256) return hipErrorInvalidValue;
   fn_t fn = nullptr;
+  if (label_stats_uses_slots(a.K, a.D, a.N)) {
+    if (!a.aux) return hipErrorInvalidValue;
+    fn = structure == 1 ? pick_label_stats_slots<1>(a.D) : structure == 2 ? pick_label_stats_slots<2>(a.D) : pick_label_stats_slots<0>(a.D);
+    if (!fn) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(a.aux, 0, 256 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    int hg = (int)((a.N + kWG * 16 - 1) / (kWG * 16));
+    if (hg > 1024) hg = 1024;
+    hipLaunchKernelGGL(label_hist_kernel, dim3(hg), dim3(kWG), 0, stream, a.labels, a.N, a.K, a.aux);
+    hipLaunchKernelGGL(label_slots_kernel, dim3(1), dim3(kWG), 0, stream, a.aux, a.K);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);
+    return hipGetLastError();
+  }
   if (structure == 1) fn = pick_label_stats_struct<1>(a.D);
   else if (structure == 2) fn = pick_label_stats_struct<2>(a.D);
   else if (a.D <= 9) fn = pick_label_stats_struct<0>(a.D);

@@ -95,10 +95,12 @@ void small_kernel(const KernelArgs a) {
   // the addresses wave-uniform and the rows live in SGPRs
   double th[KL][F];
   if constexpr (kEstep) {
+    // G = 1: the KL F <= 40 numbers travel in the kernel arguments (no staging copy, no H2D transfer in front of the launch)
+    const double* thp = (G == 1 && KL * F <= kThetaInline) ? a.theta_inline : a.theta;
 #pragma unroll
     for (int c = 0; c < KL; ++c)
 #pragma unroll
-      for (int f = 0; f < F; ++f) th[c][f] = a.theta[(size_t)(g * KL + c) * F + f];
+      for (int f = 0; f < F; ++f) th[c][f] = thp[(size_t)(g * KL + c) * F + f];
   }
   double acc[KL][F];
 #pragma unroll
@@ -451,6 +453,50 @@ __global__ __launch_bounds__(kWG) void nan_scan_kernel(double* __restrict__ Z, i
   if (write) mask[n] = bad ? 0.0 : 1.0;
 }
 
+// Is there a NaN anywhere in the (N, D) block?  The common answer is no, and then this flat scan — 16-byte loads where the
+// buffer is aligned, eight per thread in flight, grid-stride — is all an upload pays (bound by the one read of Z; the row-wise
+// kernel above reads with a stride of D doubles per lane: 0.64 TB/s at D = 16).  Only data that does hold a NaN goes on to it.
+__global__ __launch_bounds__(kWG) void nan_any_kernel(const unsigned long long* __restrict__ Z, int64_t count, unsigned int* __restrict__ flag) {
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  const int64_t tid = (int64_t)blockIdx.x * kWG + threadIdx.x, nthr = (int64_t)gridDim.x * kWG;
+  unsigned long long worst = 0ull;        // max of the exponent + mantissa bits seen: > 0x7ff0.. <=> some element is a NaN
+  const bool aligned = (reinterpret_cast<uintptr_t>(Z) & 15u) == 0;
+  const int64_t pairs = aligned ? count / 2 : 0;
+  const u2* Z2 = reinterpret_cast<const u2*>(Z);
+  int64_t i = tid;
+  for (; i + 7 * nthr < pairs; i += 8 * nthr) {
+    u2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = Z2[i + j * nthr];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned long long a0 = v[j].x & 0x7fffffffffffffffull, a1 = v[j].y & 0x7fffffffffffffffull;
+      worst = worst > a0 ? worst : a0;
+      worst = worst > a1 ? worst : a1;
+    }
+  }
+  for (; i < pairs; i += nthr) {
+    const u2 v = Z2[i];
+    const unsigned long long a0 = v.x & 0x7fffffffffffffffull, a1 = v.y & 0x7fffffffffffffffull;
+    worst = worst > a0 ? worst : a0;
+    worst = worst > a1 ? worst : a1;
+  }
+  for (int64_t e = 2 * pairs + tid; e < count; e += nthr) {     // the odd element, or everything of an unaligned buffer
+    const unsigned long long a0 = Z[e] & 0x7fffffffffffffffull;
+    worst = worst > a0 ? worst : a0;
+  }
+  if (worst > 0x7ff0000000000000ull) atomicOr(flag, 1u);
+}
+
+hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  int64_t g = (int64_t)num_cu * 8, need = (count / 2 + kWG - 1) / kWG;
+  if (g > need) g = need;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(nan_any_kernel, dim3((unsigned)g), dim3(kWG), 0, stream, reinterpret_cast<const unsigned long long*>(Z), count, flag);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kWG) void mask_labels_kernel(const int32_t* __restrict__ labels, const double* __restrict__ mask,
                                                           int32_t* __restrict__ out, int64_t N, int K,
                                                           unsigned long long* __restrict__ bad_counts) {
@@ -484,6 +530,85 @@ hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t
 hipError_t launch_mask_table(const double* table, const double* mask, double* out, int K, int64_t N, hipStream_t stream) {
   if (N <= 0) return hipSuccess;
   hipLaunchKernelGGL(mask_table_kernel, dim3((unsigned)((N + kWG - 1) / kWG)), dim3(kWG), 0, stream, table, mask, out, K, N);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// reduce_partials + unpack_stats in ONE launch (they were 17.7 + 5.3 us behind a 57 us kernel at the C1 shape, with a launch
+// gap between them): 64 consecutive elements of the partial blocks per workgroup, the G blocks split into 16 contiguous slices
+// (one per wave of a 1024-thread workgroup — the two-launch version gave 4 waves 192 dependent steps each at G = 768), every
+// slice summed in 4 interleaved chains, the slices combined as a fixed tree: the association depends on G only, never on
+// timing.  The thread that holds the total of element (k, f) writes it where unpack_stats put it (packed S[K][1 + D + D^2],
+// symmetric copies included); the workgroup that holds the four scalar slots writes scalars[3].
+// ------------------------------------------------------------------------------------------
+constexpr int kRuWG = 1024, kRuSlices = kRuWG / 64;
+__global__ __launch_bounds__(kRuWG) void reduce_unpack_kernel(const double* __restrict__ partials, int G, int64_t stride,
+                                                             const uint8_t* __restrict__ feat, int K, int D, int F, int F16,
+                                                             double* __restrict__ S, double* __restrict__ scalars, int mask_structure) {
+  __shared__ double part[kRuSlices][64];
+  __shared__ double fin[64];
+  const int ex = threadIdx.x & 63, gs = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + ex;
+  const int g0 = (int)((int64_t)G * gs / kRuSlices), g1 = (int)((int64_t)G * (gs + 1) / kRuSlices);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < stride) {
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+      s0 += partials[(int64_t)g * stride + e];
+      s1 += partials[(int64_t)(g + 1) * stride + e];
+      s2 += partials[(int64_t)(g + 2) * stride + e];
+      s3 += partials[(int64_t)(g + 3) * stride + e];
+    }
+    for (; g < g1; ++g) s0 += partials[(int64_t)g * stride + e];
+  }
+  part[gs][ex] = (s0 + s1) + (s2 + s3);
+  wg_sync();
+  if (gs != 0) return;
+  double v = 0.0;
+  {
+    double t[kRuSlices];
+#pragma unroll
+    for (int i = 0; i < kRuSlices; ++i) t[i] = part[i][ex];
+#pragma unroll
+    for (int w = kRuSlices / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) t[i] = t[2 * i] + t[2 * i + 1];
+    v = t[0];
+  }
+  fin[ex] = v;
+  const int Kpad = (K + 15) / 16 * 16;
+  const int64_t nfeat = (int64_t)Kpad * F16;
+  if (S && e < nfeat) {
+    const int k = (int)(e / F16), f = (int)(e - (int64_t)k * F16);
+    if (k < K && f < F) {
+      const int aa = feat[2 * f], bb = feat[2 * f + 1];
+      if (mask_structure == 1 && aa != bb && bb != D) v = 0.0;     // (small-shape kernel under a structure hint: see unpack_stats)
+      if (mask_structure == 2 && bb != D) v = 0.0;
+      double* Sk = S + (int64_t)k * (1 + D + D * D);
+      if (aa == D) Sk[0] = v;
+      else if (bb == D) Sk[1 + aa] = v;
+      else { Sk[1 + D + aa * D + bb] = v; Sk[1 + D + bb * D + aa] = v; }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave from here on: its own LDS stores are visible to it in order)
+  if (scalars && e == nfeat) {
+    const double slse = fin[ex], srl = fin[ex + 1];
+    const bool split = fin[ex + 2] > 0.0;
+    const long long nan_bits = 0x7ff8000000000000LL;
+    scalars[0] = slse;
+    scalars[1] = __longlong_as_double(split ? __double_as_longlong(srl) : nan_bits);
+    scalars[2] = __longlong_as_double(split ? __double_as_longlong(slse - srl) : nan_bits);
+  }
+}
+
+hipError_t launch_reduce_unpack(const double* partials, int G, int64_t stride, const uint8_t* feat, int K, int D, int F, int F16,
+                                double* S_packed, double* scalars3, hipStream_t stream, int mask_structure) {
+  if (S_packed && F < feat_count(D)) {   // reduced feature map: the entries outside it are zeros
+    hipError_t e = hipMemsetAsync(S_packed, 0, sizeof(double) * (size_t)K * (1 + D + (size_t)D * D), stream);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(reduce_unpack_kernel, dim3((unsigned)((stride + 63) / 64)), dim3(kRuWG), 0, stream, partials, G, stride, feat,
+                     K, D, F, F16, S_packed, scalars3, mask_structure);
   return hipGetLastError();
 }
 
