@@ -312,7 +312,7 @@ static int upload_theta_small(mimo_ctx* ctx, const double* c, const double* b, c
 // (+ their statistics) requested.
 static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
   static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE"); return !e || atoi(e) != 0; }();   // tuning knob
-  if (!on || wants_tables || ctx->D > 16) return false;       // (16 rows x Dz <= 256 elements per wave step)
+  if (!on || wants_tables) return false;
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
   return rowwave_covers(K, ctx->F16, ZS) && label_stats_covers(K, ctx->D, ctx->structure);
 }
@@ -320,7 +320,9 @@ static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
 // Theta image of the row-owner label kernel: [NS][KB][64]; component k sits in A-row (k / V) + 4 (k % 4) of row block
 // (k % V) / 4, V = 4 KB, so that an output lane holds a contiguous quarter of the components (gibbs_rowwave_kernel)
 static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, NS = ctx->F16 / 4, KB = rowwave_kb(K), V = 4 * KB;
+  const int D = ctx->D, KB = rowwave_kb(K), V = 4 * KB;
+  const int ZSk = (K + 15) / 16 > 12 ? D + 2 : ((D + 2) | 1);      // as fill_args
+  const int NS = rowwave_image_ns(K, ctx->F16, ZSk);                // (whole chunks where the label kernel streams Theta)
   const size_t count = (size_t)NS * KB * 64;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
@@ -1442,9 +1444,10 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     out8[6] = rowwave_grid(a, ctx->num_cu);
   } else if (gibbs && use_rowwave(ctx, K, false)) {
-    out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 2;
-    out8[4] = 2;                         // Z: label kernel + statistics kernel
-    out8[5] = 2;                         // labels written once, read once
+    const int ll = label_stats_launches(K, ctx->D, ctx->structure);     // (> 1: the sliced statistics of the large shapes)
+    out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 1 + ll;
+    out8[4] = 1 + ll;                    // Z: label kernel + every statistics launch
+    out8[5] = 1 + ll;                    // labels written once, read once per statistics launch
     out8[6] = rowwave_grid(a, ctx->num_cu);
   } else if (fused_covers(a.K16, ncb, kSrcEstep)) {
     out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;

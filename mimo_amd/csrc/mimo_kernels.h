@@ -105,6 +105,7 @@ hipError_t launch_small(const KernelArgs& a, int src, int grid, hipStream_t stre
 size_t rowwave_lds_bytes(int KB, int NS, int ZS);
 int rowwave_kb(int K);
 bool rowwave_covers(int K, int F16, int ZS);
+int rowwave_image_ns(int K, int F16, int ZS);     // contraction steps of the operand image (padded to whole chunks where Theta streams)
 int rowwave_grid(const KernelArgs& a, int num_cu);
 hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
 bool label_stats_covers(int K, int D, int structure);

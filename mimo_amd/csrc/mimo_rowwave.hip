@@ -223,6 +223,203 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same label pass where Theta does not fit LDS (K F16 8 bytes: 327 KB at K = 256, Dz = 16; 590 KB at K = 128, Dz = 32):
+// the operand image STREAMS through a double buffer in chunks of NSC contraction steps (48 KB), the workgroup's eight waves
+// walk the chunks together — one barrier per chunk, i.e. per NSC KB = 96 matrix instructions of every wave — and the next
+// chunk (cyclic: Theta does not change from step to step) is fetched from L2 into registers under the current chunk's
+// products and stored behind them.  The accumulators carry the l values of all components across the chunks, the draw is the
+// one of gibbs_rowwave_kernel.  The feature pair of a step comes from a small LDS table (NS x 4 packed byte offsets) instead of
+// 2 NS address registers.  These shapes ran on the tile kernels' pipelined E-step (wide_estep_kernel: K = 128, Dz = 16 at 49 % of
+// the FP64 rate in the label pass against 74 % for the row-owner kernel at K = 64).
+// L2 -> LDS traffic: the whole image per 128 rows (Dz = 16, K = 256: 2.5 KB per row, 25 GB per 1e7 rows — a quarter of the
+// pass's matrix time at the 10 TB/s the L2s deliver, and hidden under it).
+// ------------------------------------------------------------------------------------------
+constexpr int stream_nsc(int KB) { return KB <= 2 ? 48 : KB <= 4 ? 24 : KB <= 6 ? 16 : KB <= 8 ? 12 : KB <= 14 ? 8 : 6; }   // (NSC KB: a multiple of 16)
+
+template <int KB, int ZI>
+__global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const KernelArgs a, int NSP) {
+  constexpr int V = 4 * KB, NCH = KB / 2, NSC = stream_nsc(KB);
+  constexpr int CH = NSC * KB * 64;                   // doubles per chunk
+  constexpr int NLD = CH / (2 * kRowWaveWG);          // 16-byte loads per thread and chunk
+  static_assert(KB % 2 == 0 && KB >= 2 && KB <= 16 && CH % (2 * kRowWaveWG) == 0, "row blocks per wave / chunk geometry");
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int ZS = a.ZS;
+  double* buf = reinterpret_cast<double*>(smem);      // [2][CH]
+  double* etab = buf + 2 * CH;                        // [kExpTab]
+  double* Zall = etab + kExpTab;                      // [8 waves][16][ZS]
+  uint32_t* ftab = reinterpret_cast<uint32_t*>(Zall + (size_t)(kRowWaveWG / 64) * 16 * ZS);   // [NSP][4] packed byte offsets of a step's feature pair
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, j = lane & 15;
+  const int D = a.D, K = a.K;
+  const int64_t N = a.N;
+  const int nch = NSP / NSC;                          // chunks per pass over the image (host: NSP is a multiple of NSC)
+  double* Zw = Zall + (size_t)wave * 16 * ZS;
+
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  for (int e = tid; e < NSP * 4; e += kRowWaveWG) {
+    const int f = e;                                  // feature 4 s + q; beyond the table: the zero slot of z~
+    const uint32_t fa = f < a.F16 ? a.feat[2 * f] : (uint32_t)(D + 1), fb = f < a.F16 ? a.feat[2 * f + 1] : (uint32_t)(D + 1);
+    ftab[e] = 8u * fa | (8u * fb) << 16;
+  }
+  {                                                   // chunk 0 -> buffer 0 (the loop's first barrier publishes it)
+    const d2* src = reinterpret_cast<const d2*>(a.theta) + tid;
+    d2* dst = reinterpret_cast<d2*>(buf) + tid;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) dst[i * kRowWaveWG] = src[i * kRowWaveWG];
+  }
+
+  const int64_t nsteps = (N + 127) / 128;             // workgroup steps: 8 waves x 16 rows
+  int zoff[ZI];
+#pragma unroll
+  for (int i = 0; i < ZI; ++i) {
+    const int e = lane + 64 * i, r = e / D;
+    zoff[i] = e < 16 * D ? r * ZS + (e - r * D) : -1;
+  }
+  double zr[ZI];
+  auto load_z = [&](int64_t t) {
+    const int64_t base = (t * 8 + wave) * 16 * D, total = N * D;
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) {
+      const int64_t gidx = base + lane + 64 * i;
+      zr[i] = (zoff[i] >= 0 && gidx < total) ? a.Z[gidx] : 0.0;
+    }
+  };
+  if ((int64_t)blockIdx.x < nsteps) load_z(blockIdx.x);
+
+  const char* zb = reinterpret_cast<const char*>(Zw + j * ZS);
+  auto feature = [&](int s) -> double {
+    const uint32_t u = ftab[4 * s + q];
+    return *reinterpret_cast<const double*>(zb + (u & 0xffffu)) * *reinterpret_cast<const double*>(zb + (u >> 16));
+  };
+  double ubatch = 0.0;
+  int uphase = 0;
+  int gc = 0;                                          // chunks done: chunk gc lives in buffer gc & 1
+
+  for (int64_t t = blockIdx.x; t < nsteps; t += gridDim.x) {
+    const int64_t n = (t * 8 + wave) * 16 + j;
+    const bool valid = n < N;
+#pragma unroll
+    for (int i = 0; i < ZI; ++i)
+      if (zoff[i] >= 0) Zw[zoff[i]] = zr[i];
+    if (q == 0) {
+      Zw[j * ZS + D] = valid ? 1.0 : 0.0;     // rows past N: every feature 0, l = 0, never written
+      Zw[j * ZS + D + 1] = 0.0;
+    }
+    if (t + gridDim.x < nsteps) load_z(t + gridDim.x);
+
+    d4 acc[KB];
+#pragma unroll
+    for (int rb = 0; rb < KB; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < nch; ++c, ++gc) {
+      wg_sync();                               // chunk gc stands in its buffer; everybody is done with the other one
+      const double* bc = buf + (gc & 1) * CH + lane;
+      // the next chunk of the cyclic walk: global -> registers now, registers -> the other buffer behind the products
+      d2 stg[NLD];
+      {
+        const int cn = c + 1 < nch ? c + 1 : 0;
+        const d2* src = reinterpret_cast<const d2*>(a.theta + (size_t)cn * CH) + tid;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stg[i] = src[i * kRowWaveWG];
+      }
+      constexpr int PF = 4;
+      double ring[PF];
+#pragma unroll
+      for (int e = 0; e < PF; ++e) ring[e] = bc[e * 64];
+      const int s0 = c * NSC;
+      double bq = feature(s0);
+#pragma unroll
+      for (int s2 = 0; s2 < NSC; ++s2) {
+        const double bcur = bq;
+        if (s2 + 1 < NSC) bq = feature(s0 + s2 + 1);
+#pragma unroll
+        for (int rb = 0; rb < KB; ++rb) {
+          const int e = s2 * KB + rb;
+          const double av = ring[e % PF];
+          if (e + PF < NSC * KB) ring[e % PF] = bc[(e + PF) * 64];
+          acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
+        }
+      }
+      {
+        d2* dst = reinterpret_cast<d2*>(buf + ((gc + 1) & 1) * CH) + tid;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) dst[i * kRowWaveWG] = stg[i];
+      }
+    }
+
+    // ---- draw: lane (q, j) holds components q V .. q V + V - 1 of row j, x[4 rb + r] = acc[rb][r] (as gibbs_rowwave_kernel)
+    __builtin_amdgcn_s_setprio(2);
+    double m;
+    {
+      double mv[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+#pragma unroll
+      for (int rb = 1; rb < KB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[r] = fmax(mv[r], acc[rb][r]);
+      m = fmax(fmax(mv[0], mv[1]), fmax(mv[2], mv[3]));
+      m = fmax(m, __shfl_xor(m, 16));
+      m = fmax(m, __shfl_xor(m, 32));
+    }
+    double base[NCH + 1];
+    base[0] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      double x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048(acc[2 * c + (i >> 2)][i & 3] - m, etab);
+#pragma unroll
+      for (int i = 1; i < 8; ++i) x[i] += x[i - 1];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[2 * c + (i >> 2)][i & 3] = x[i];
+      base[c + 1] = x[7];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) base[c + 1] += base[c];
+    const double cum = base[NCH];
+    double incl = cum;
+    {
+      double v = __shfl_up(incl, 16);  if (q >= 1) incl += v;
+      v = __shfl_up(incl, 32);         if (q >= 2) incl += v;
+    }
+    double excl = __shfl_up(incl, 16);
+    if (q == 0) excl = 0.0;
+    const double ctot = __shfl(incl, 48 + j);
+    double uu;
+    if (a.u) {
+      uu = valid ? a.u[n] : 0.0;
+    } else {
+      if (uphase == 0)        // four workgroup steps at a time: lane (q, j) draws row j of this wave's step t + q gridDim.x
+        ubatch = philox_uniform(a.seed, (uint64_t)(a.row0 + ((t + (int64_t)q * gridDim.x) * 8 + wave) * 16 + j), a.sweep);
+      uu = __shfl(ubatch, uphase * 16 + j);
+      uphase = (uphase + 1) & 3;
+    }
+    const double tl = uu * ctot - excl;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const double tc = tl - base[c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cnt += tc > acc[2 * c + (i >> 2)][i & 3] ? 1 : 0;
+    }
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    const int label = cnt < K ? cnt : K - 1;
+    if (q == 0 && valid) a.labels[n] = label;
+    __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+// contraction steps of the streamed image: F16 / 4 padded to whole chunks
+int stream_ns_pad(int KB, int F16) { const int nsc = stream_nsc(KB), ns = F16 / 4; return (ns + nsc - 1) / nsc * nsc; }
+size_t stream_lds_bytes(int KB, int F16, int ZS) {
+  return sizeof(double) * ((size_t)2 * stream_nsc(KB) * KB * 64 + kExpTab + (size_t)(kRowWaveWG / 64) * 16 * ZS)
+         + sizeof(uint32_t) * (size_t)stream_ns_pad(KB, F16) * 4;
+}
+
 size_t rowwave_lds_bytes(int KB, int NS, int ZS) {
   return sizeof(double) * ((size_t)(NS * KB + 4) * 64 + kExpTab + (size_t)(kRowWaveWG / 64) * 16 * ZS);
 }
@@ -245,11 +442,22 @@ static int rowwave_min_k() {
 
 // K <= 256 (from rowwave_min_k) at Dz <= 9 (F16 <= 64); Dz 10 .. 16 (F16 <= 160) while the operand image fits LDS next to
 // the exp table: K <= 64, and K <= 128 up to Dz = 12 (the instantiations below)
-bool rowwave_covers(int K, int F16, int ZS) {
+static bool rowwave_resident(int K, int F16, int ZS) {
   if (K < rowwave_min_k() || K > 256 || F16 > 160) return false;
   const int kb = rowwave_kb(K);
   if (F16 > 64 && !(kb <= 4 || (kb <= 8 && F16 <= 96))) return false;
   return rowwave_lds_bytes(kb, F16 / 4, ZS) <= 160 * 1024;
+}
+// ... and beyond that, up to Dz = 32 (F16 <= 576), with Theta streamed through LDS (MIMO_ROWWAVE_STREAM=0: off, tuning knob)
+static bool rowwave_streams(int K, int F16, int ZS) {
+  static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE_STREAM"); return !e || atoi(e) != 0; }();
+  if (!on || K < rowwave_min_k() || K > 256 || F16 > 576 || rowwave_resident(K, F16, ZS)) return false;
+  return stream_lds_bytes(rowwave_kb(K), F16, ZS) <= 160 * 1024;
+}
+bool rowwave_covers(int K, int F16, int ZS) { return rowwave_resident(K, F16, ZS) || rowwave_streams(K, F16, ZS); }
+// contraction steps the operand image must hold for (K, F16): F16 / 4, or whole chunks of the streamed walk
+int rowwave_image_ns(int K, int F16, int ZS) {
+  return rowwave_streams(K, F16, ZS) ? stream_ns_pad(rowwave_kb(K), F16) : F16 / 4;
 }
 
 typedef void (*rowwave_fn)(const KernelArgs);
@@ -300,7 +508,32 @@ int rowwave_grid(const KernelArgs& a, int num_cu) {
   return (int)(g < 1 ? 1 : g);
 }
 
+typedef void (*stream_fn)(const KernelArgs, int);
+template <int ZI>
+static stream_fn pick_stream(int kb) {
+  switch (kb) {
+    case 2: return gibbs_stream_kernel<2, ZI>;    case 4: return gibbs_stream_kernel<4, ZI>;
+    case 6: return gibbs_stream_kernel<6, ZI>;    case 8: return gibbs_stream_kernel<8, ZI>;
+    case 10: return gibbs_stream_kernel<10, ZI>;  case 12: return gibbs_stream_kernel<12, ZI>;
+    case 14: return gibbs_stream_kernel<14, ZI>;  case 16: return gibbs_stream_kernel<16, ZI>;
+  }
+  return nullptr;
+}
+
 hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream) {
+  if (rowwave_streams(a.K, a.F16, a.ZS)) {
+    const int kb = rowwave_kb(a.K);
+    stream_fn fn = 16 * a.D <= 256 ? pick_stream<4>(kb) : pick_stream<8>(kb);
+    if (!fn || a.D > 32) return hipErrorInvalidValue;
+    const size_t lds = stream_lds_bytes(kb, a.F16, a.ZS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int64_t need = (a.N + 127) / 128;
+    int g = grid;
+    if (g > need) g = (int)(need < 1 ? 1 : need);
+    hipLaunchKernelGGL(fn, dim3(g), dim3(kRowWaveWG), lds, stream, a, stream_ns_pad(kb, a.F16));
+    return hipGetLastError();
+  }
   const int kb = rowwave_kb(a.K);
   rowwave_fn fn = pick_rowwave(kb, a.F16);
   if (!fn) return hipErrorInvalidValue;

@@ -704,7 +704,7 @@ def test_sliced_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(1300 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] in ("two-stage", "fused")
+    assert engine.plan(K, gibbs=True)["kind"] in ("two-stage", "fused", "rowwave")     # (rowwave: Theta streamed through LDS)
     L = O.canonical_eval(Z, c, b, W)
     lab_p, Sp = engine.gibbs_labels(c, b, W, seed=9, sweep=2)
     ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(9, np.arange(N), 2))
@@ -972,3 +972,29 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
         assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * max(1., abs(lse2.sum()))
         lab_o, Go = engine.gibbs_labels(c2, b, W, seed=1, sweep=1)
         assert not np.any(lab_o == K // 2) and Go.n[K // 2] == 0 and Go.n.sum() == N
+
+
+@pytest.mark.parametrize("D,K", [(16, 128), (12, 200), (20, 72), (16, 256), (32, 40), (24, 128)])
+def test_streamed_label_kernel_many_steps(engine, D, K):
+    """gibbs_stream_kernel (the row-owner label kernel with Theta streamed through a double buffer in LDS: shapes whose operand
+    image does not fit) over several workgroup steps per workgroup — the cyclic walk of the chunks across step boundaries, both
+    buffer parities: labels bit-exact for host uniforms and the Philox stream, statistics of the sweep, identical bits on a
+    second launch.  (tests of one step per workgroup: test_sliced_label_statistics.)"""
+    from oracle import mimo_oracle as O
+    N = 128 * 256 * 2 + 77
+    rng = np.random.default_rng(2100 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    assert engine.plan(K, gibbs=True)["kind"] == "rowwave"
+    L = O.canonical_eval(Z, c, b, W)
+    u = rng.random(N)
+    lab, S = engine.gibbs_labels(c, b, W, u=u)
+    ref = O.sample_discrete_from_log(L, u)
+    assert np.array_equal(lab, ref)
+    n, sx, sxx = O.packed_stats(Z, O.one_hot(ref, K))
+    assert np.array_equal(S.n, n) and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    lab_p, Sp = engine.gibbs_labels(c, b, W, seed=3, sweep=7)
+    ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(3, np.arange(N), 7))
+    assert np.array_equal(lab_p, ref_p)
+    lab_q, Sq = engine.gibbs_labels(c, b, W, seed=3, sweep=7)
+    assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx)
