@@ -200,10 +200,13 @@ def main():
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--no-sample", action="store_true",
                     help="drop the reference's per-iteration likelihood.params = posterior.rvs() (sample_likelihood=False)")
-    ap.add_argument("--dry-run-engine", default="",
-                    help="TEST HOOK (tests/test_bench_launch.py): 'module:Class' of an engine double; the ranks then run "
-                         "on the CPU over gloo, the JSON line is marked dry_run and carries no measurement")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="length of the sustained leg after the timed steps (>= 10 s: a 5-second utilisation sampler must see it)")
     args = ap.parse_args()
+    # TEST HOOK, deliberately not a command-line argument of the measurement script: tests/test_bench_launch.py sets
+    # MIMO_BENCH_DRY_RUN_ENGINE='module:Class' (an engine double under tests/); the ranks then run on the CPU over gloo and the
+    # JSON line is marked dry_run and carries no measurement
+    args.dry_run_engine = os.environ.get("MIMO_BENCH_DRY_RUN_ENGINE", "")
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None and "RANK" not in os.environ:
@@ -300,15 +303,19 @@ def main():
     kinfo = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches_per_step": v["launches"] / max(args.steps, 1)}
              for k, v in kinfo.items()}
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rank_ms = [elapsed / args.steps * 1e3]
+    if dist is not None:          # the slowest rank's time is the step time; every rank's own time goes into the line
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) / args.steps * 1e3 for v in t.cpu()]
+        elapsed = float(t.max().item())
 
     sustained = None
     if not args.no_sustained and not dry and dist is None:
-        # the same step for >= 3 s after the timed steps: a 20-launch burst says nothing about sustained FP64 clocks
-        ts, t_end, it = [], time.perf_counter() + 3.0, args.warmup + args.steps
+        # the same step for >= 10 s after the timed steps: a 20-launch burst says nothing about sustained FP64 clocks, and an
+        # independent 5-second utilisation sampler has to see the load at least once
+        ts, t_end, it = [], time.perf_counter() + max(args.sustained_seconds, 0.0), args.warmup + args.steps
         while time.perf_counter() < t_end or len(ts) < 5:
             torch.cuda.synchronize()
             a = time.perf_counter()
@@ -341,9 +348,12 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "ms_per_step_per_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "allreduce_bytes_per_step": (8 * (K * (1 + D + D * D) + 4)) if dist is not None else 0,
             "allreduce_route": (("libmimo_hip RCCL communicator" if getattr(engine, "_native", False) else
-                                 "torch.distributed all_reduce (" + dist.get_backend() + ")") if dist is not None else None),
+                                 "torch.distributed (" + dist.get_backend() + ")")
+                                + (", all-gather + sum in rank order" if getattr(engine, "_rank_order", False) else ", all_reduce(sum)")
+                                if dist is not None else None),
             "config": {"workload": desc, "rows_per_gpu": N, "Dz": D, "K": K,
                        "step": "one iteration of the public driver loop ("
                                + ("gibbs_iteration" if mode == "gibbs" else "meanfield_iteration, sample_likelihood=%s" % sample)

@@ -19,7 +19,8 @@ from mimo_amd.mixtures import BayesianMixtureOfLinearGaussians
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=20000)
-    ap.add_argument("--experts", type=int, default=16)
+    ap.add_argument("--experts", type=int, default=16,
+                    help="truncation level (the reference's evaluate_sine.py defaults to 50: --experts 50)")
     ap.add_argument("--iters", type=int, default=150)
     args = ap.parse_args()
     npr.seed(1337)
@@ -40,6 +41,9 @@ def main():
     model.resample(x, y, maxiter=25, progress_bar=False)                   # a short Gibbs run as initialisation
     vlb = model.meanfield_coordinate_descent(x, y, randomize=False, maxiter=args.iters, tol=1e-6, progress_bar=False)
     print(f"ELBO: {vlb[0]:.2f} -> {vlb[-1]:.2f} in {len(vlb)} iterations")
+    eng = model.engine
+    if hasattr(eng, "plan"):          # which kernel family ran the passes (50 experts, the reference's default: the narrow kernels)
+        print(f"kernels: softmax pass '{eng.plan(K)['kind']}', label pass '{eng.plan(K, gibbs=True)['kind']}'")
 
     grid = np.linspace(-6., 6., 25)[:, None]
     mu, var, std = model.meanfield_prediction(grid)

@@ -245,7 +245,8 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
  *                  softmax_k(c_k): n_bad times that vector is the gating part, computed by the caller.
  * Linear-Gaussian experts: the rule applies to the joint row z = [x, y] (a NaN anywhere drops the row from the
  * statistics, lingauss.py:103-104); the reference's log-density only zeroes rows where x AND y hold a NaN
- * (lingauss.py:150-151) and evaluates the others on nan_to_num'ed values — that corner is not reproduced. */
+ * (lingauss.py:150-151) and evaluates the others on element-wise nan_to_num'ed values: the host mirror puts those values in
+ * place of the library's whole-row value for the few rows concerned (mimo_amd/mixtures/ilr.py, nan_rows_table). */
 int mimo_nan_info(mimo_ctx* ctx, int64_t* n_bad, double* row_mask_out, int K, int64_t* label_counts);
 
 /* ---- sharding over the GPUs of a node (one process per GPU) ----------------------------------

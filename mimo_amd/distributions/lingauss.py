@@ -32,6 +32,20 @@ def residual_quadratic(As, lmbdas, affine, input_dim):
     return c0, b, W
 
 
+def canonical_rows(c, b, W, Z):
+    """(K, n) table c_k + b_k.z - 1/2 z'W_k z for a handful of rows Z (n, Dz) on the host — the rows with a NaN, whose
+    log-density follows the reference's element-wise rules (below) instead of the engine's whole-row rule."""
+    Z = np.asarray(Z, dtype=float)
+    return c[:, None] + b @ Z.T - 0.5 * np.einsum('nd,kde,ne->kn', Z, W, Z)
+
+
+def nan_row_sets(x, y):
+    """(rows with a NaN in x or y, NaN-in-x flags, NaN-in-y flags of those rows)."""
+    bx, by = np.isnan(x).any(axis=1), np.isnan(y).any(axis=1)
+    bad = np.flatnonzero(bx | by)
+    return bad, bx[bad], by[bad]
+
+
 def split_joint_stats(S, dx, affine):
     """Blocks of the engine's packed statistics over z = [x, y]:
     returns (xk, xxTk) for the input density and (yxTk, x~x~Tk, yyTk) for the experts."""
@@ -134,17 +148,30 @@ class StackedLinearGaussiansWithPrecision:
     def _bind(self, x, y):
         x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
         y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
-        # rows with a NaN in x or y are dropped from the statistics like in the reference (lingauss.py:103-104); their
-        # log-density is the normaliser-only value (the reference does that only when x AND y hold a NaN,
-        # lingauss.py:150-151, and evaluates the other rows on nan_to_num'ed values: that corner is not reproduced)
+        # rows with a NaN in x or y are dropped from the statistics like in the reference (lingauss.py:103-104); the engine
+        # gives them the whole-row value (z = 0); log_likelihood below puts the reference's element-wise value in their place
         return _engine.bind(self.engine, joint_rows(x, y))
+
+    def nan_rows_loglik(self, x, y, bx, by, zero_when_both=True):
+        """The reference's log-density of rows that hold a NaN (lingauss.py:330-345): x and y go through nan_to_num ELEMENT by
+        element — the other elements of the row keep their values —, and the data part mu'Lambda y - 1/2 y'Lambda y is set
+        to 0 only where x AND y hold a NaN (`zero_when_both`), which is the canonical form at y = 0."""
+        x0, y0 = np.nan_to_num(np.array(x, dtype=float)), np.nan_to_num(np.array(y, dtype=float))
+        if zero_when_both:
+            y0[bx & by] = 0.
+        return canonical_rows(*self.canonical(), np.hstack((x0, y0)))
 
     def log_likelihood(self, x, y):
         if not (isinstance(x, np.ndarray) and isinstance(y, np.ndarray)):
             return list(map(self.log_likelihood, x, y))
         eng = self._bind(x, y)
         eng.estep(*self.canonical(), stats=False, keep_logp=True)
-        return eng.get_logp(self.size)
+        L = eng.get_logp(self.size)
+        if getattr(eng, 'n_bad', 0):
+            x2, y2 = np.reshape(x, (-1, self.input_dim)), np.reshape(y, (-1, self.output_dim))
+            bad, bx, by = nan_row_sets(x2, y2)
+            L[:, bad] = self.nan_rows_loglik(x2[bad], y2[bad], bx, by)
+        return L
 
     def weighted_statistics(self, x, y, weights):
         """Stats([sum r y x~', sum r x~ x~', sum r y y', n]) (lingauss.py:306-322)."""

@@ -146,7 +146,7 @@ class HipEngine:
         key = None
         if weights is not None:
             wv = _f64(weights).reshape(-1)
-            key = (wv.__array_interface__['data'][0], wv.shape[0], content_fingerprint(wv), id(self._keepalive), self.N,
+            key = (wv.__array_interface__['data'][0], wv.shape[0], content_fingerprint(wv, exact=True), id(self._keepalive), self.N,
                    getattr(self, '_upload_count', 0))
             hit = getattr(self, '_xxw_cache', None)
             if hit is not None and hit[0] == key:
@@ -307,7 +307,7 @@ class HipEngine:
             if w.shape[0] != self.N:
                 raise ValueError(f"row_weights has {w.shape[0]} entries, data has {self.N} rows")
             # the drivers pass the same weight vector every iteration: it stays on the device while its content does
-            wkey = (w.__array_interface__['data'][0], w.shape[0], content_fingerprint(w), id(self._keepalive), self.N)
+            wkey = (w.__array_interface__['data'][0], w.shape[0], content_fingerprint(w, exact=True), id(self._keepalive), self.N)
             resident = getattr(self, '_w_key', None) == wkey
             rc = self._lib.mimo_estep_weighted(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(w),
                                                flags | (_lib.F_WEIGHTS_RESIDENT if resident else 0), _ptr(S), _ptr(sc))
@@ -441,8 +441,8 @@ class HipEngine:
         self._check(self._lib.mimo_random_resp_stats(self._ctx, K, int(seed), 0, _ptr(S)))
         self._K = K
         S = SuffStats.from_packed(S, K, self.D)
-        if getattr(self, 'n_bad', 0):
-            S.n_rows = S.n + self._nan_label_counts(K)
+        if getattr(self, 'n_bad', 0):        # the share of the rows with NaN: their random responsibilities (the table is resident)
+            S.n_rows = S.n + np.sum(self.get_resp(K)[:, self.nan_rows()], axis=1)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
     def sample_from_log(self, logp=None, K=None, u=None, seed=0, sweep=0, return_lognorms=False):
@@ -533,21 +533,41 @@ def philox_uniforms(seed, rows, sweep):
 # data binding used by the reference-shaped array methods (log_likelihood(x), weighted_statistics
 # (x, w), ...): the array last bound stays resident, so passing the SAME array again costs nothing.
 # ---------------------------------------------------------------------------------------------
-_FULL_HASH_BYTES = 1 << 21       # arrays up to 2 MB are fingerprinted in full
+_FULL_HASH_BYTES = 1 << 21       # arrays up to 2 MB are fingerprinted in full with a CRC
+_FULL_SUM_BYTES = 1 << 24        # ... up to 16 MB in full with a 64-bit word checksum (memory-bound: a few ms)
 _SAMPLE_ELEMS = 8192
 
 
-def content_fingerprint(Z):
-    """Cheap fingerprint of an array's CONTENT, so that an in-place edit between two calls (centring, whitening,
+def _exact_mode():
+    import os
+    return os.environ.get("MIMO_BIND_EXACT", "0") == "1"
+
+
+def _word_checksum(Z):
+    """Checksum over EVERY 8-byte word of a C-contiguous array: wrapping sum and xor of the words — two reductions at memory
+    bandwidth, no temporary; any edit of a single element changes it (a permutation of elements would not)."""
+    w = np.ascontiguousarray(Z).reshape(-1).view(np.uint8)
+    n8 = w.size // 8
+    u = w[:8 * n8].view(np.uint64)
+    import zlib
+    return (int(np.add.reduce(u, dtype=np.uint64)), int(np.bitwise_xor.reduce(u)), zlib.crc32(w[8 * n8:]))
+
+
+def content_fingerprint(Z, exact=None):
+    """Fingerprint of an array's CONTENT, so that an in-place edit between two calls (centring, whitening,
     a reused buffer filled with the next data set — the reference re-reads its arguments on every call, and itself
-    edits caller arrays in place, gaussian.py:513) is seen and the device copy refreshed.  Small arrays (<= 2 MB):
-    CRC of every byte.  Large arrays: CRC of ~8192 evenly strided elements plus the first and last rows — O(1),
-    catches every edit that touches the whole array or a contiguous block of it, not a change of a few isolated
-    elements (call engine.unbind() after such a surgical edit)."""
+    edits caller arrays in place, gaussian.py:513) is seen and the device copy refreshed.  Arrays up to 2 MB: CRC of
+    every byte; up to 16 MB: a checksum over every 8-byte word (sees any single edit, a few ms).  Beyond that the
+    default is a sample — CRC of ~8192 evenly strided elements plus the first and last rows: O(1), catches every edit that
+    touches the whole array or a contiguous block of it, not a change of a few isolated elements — unless `exact` (or the
+    environment variable MIMO_BIND_EXACT=1) asks for the full word checksum (0.2 s at 1.28 GB: once per driver call, not
+    per sweep).  engine.unbind() forces a re-upload whatever the fingerprint says."""
     import zlib
     Z = np.asarray(Z)
     if Z.nbytes <= _FULL_HASH_BYTES:
         return zlib.crc32(np.ascontiguousarray(Z).view(np.uint8).reshape(-1))
+    if Z.flags.c_contiguous and (Z.nbytes <= _FULL_SUM_BYTES or (_exact_mode() if exact is None else exact)):
+        return _word_checksum(Z)
     if Z.flags.c_contiguous:
         flat = Z.reshape(-1)
         step = max(1, flat.shape[0] // _SAMPLE_ELEMS)
@@ -561,21 +581,21 @@ def content_fingerprint(Z):
     return zlib.crc32(np.ascontiguousarray(Z[-1]).view(np.uint8).reshape(-1), h)
 
 
-def _bind_key(Z):
-    return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str, content_fingerprint(Z))
+def _bind_key(Z, exact=None):
+    return (Z.__array_interface__['data'][0], Z.shape, Z.strides, Z.dtype.str, content_fingerprint(Z, exact))
 
 
-def bind(engine, Z, structure='full'):
+def bind(engine, Z, structure='full', exact=None):
     """Make `Z` ((N,Dz) float64 host array) the engine's resident data set, uploading it only if it is not the
-    array bound last — identity = address + shape + a content fingerprint (`content_fingerprint`), so an in-place
-    edit of the bound array re-uploads it and drops the cached sum z z' — and select the structure of the
-    precision blocks the caller is going to pass."""
+    array bound last — identity = address + shape + a content fingerprint (`content_fingerprint`: exact up to 16 MB,
+    sampled beyond unless `exact=True` / MIMO_BIND_EXACT=1), so an in-place edit of the bound array re-uploads it and
+    drops the cached sum z z' — and select the structure of the precision blocks the caller is going to pass."""
     if hasattr(engine, 'set_structure'):
         engine.set_structure(structure)
     Z = np.asarray(Z)
     if Z.ndim == 1:
         Z = Z.reshape(-1, 1)
-    key = _bind_key(Z)
+    key = _bind_key(Z, exact)
     if getattr(engine, "_bound_key", None) != key:
         engine.upload(Z)                 # (also invalidates the cached pooled second moment)
         engine._bound_key = key

@@ -291,6 +291,8 @@ class BayesianMixtureOfGaussians:
 
     def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
         c, b, W = self.likelihood.canonical()
+        if hasattr(eng, 'check_replicated_once'):      # sharded: every rank drew these blocks from ITS host generator
+            eng.check_replicated_once(c, b, W, what="component / gating parameters drawn for the label pass")
         if label_rng == 'host':
             u = npr.random(size=(1, eng.N))
             return eng.gibbs_labels(c, b, W, u=u, stats=stats, return_labels=return_labels)

@@ -12,7 +12,9 @@ from tqdm import tqdm
 from mimo_amd import engine as _engine
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
-from mimo_amd.distributions.lingauss import split_joint_stats, joint_rows
+from scipy.special import logsumexp
+
+from mimo_amd.distributions.lingauss import split_joint_stats, joint_rows, canonical_rows, nan_row_sets
 from mimo_amd.mixtures.gmm import canonical_inner, random_start, LazyTable
 
 
@@ -72,20 +74,49 @@ class MixtureOfLinearGaussians:
         y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
         return _engine.bind(self.engine, joint_rows(x, y))
 
+    def nan_rows_table(self, eng, x, y):
+        """None, or (rows, (K, n) table) for the rows that hold a NaN — the reference's element-wise rules instead of the engine's
+        whole-row value (z = 0).  Inside log_complete_likelihood (ilr.py:71-75 of the reference) the input density runs first:
+        a row with a NaN in x gets its normaliser only (gaussian.py:512-520) — and nan_to_num's x IN PLACE, so the experts'
+        density that runs next sees no NaN in x, zeroes nothing, and evaluates every row on the nan_to_num'ed (x, y)."""
+        if not getattr(eng, 'n_bad', 0):
+            return None
+        x = np.asarray(x, dtype=float).reshape(-1, self.input_dim)
+        y = np.asarray(y, dtype=float).reshape(-1, self.output_dim)
+        bad, bx, by = nan_row_sets(x, y)
+        cb, bb, Wb = self.basis.canonical()
+        basis = canonical_rows(cb, bb, Wb, np.nan_to_num(x[bad]))
+        basis[:, bx] = cb[:, None]
+        models = self.models.nan_rows_loglik(x[bad], y[bad], bx, by, zero_when_both=False)
+        with np.errstate(divide='ignore'):
+            return bad, basis + models + np.log(self.gating.probs)[:, None]
+
     def log_complete_likelihood(self, x, y):
         eng = self._bind(x, y)
         eng.estep(*self.canonical(), stats=False, keep_logp=True)
-        return eng.get_logp(self.size)
+        L = eng.get_logp(self.size)
+        fix = self.nan_rows_table(eng, x, y)
+        if fix is not None:
+            L[:, fix[0]] = fix[1]
+        return L
 
     def log_likelihood(self, x, y):
         eng = self._bind(x, y)
         eng.estep(*self.canonical(), stats=False, keep_lse=True)
-        return eng.get_lse()
+        lse = eng.get_lse()
+        fix = self.nan_rows_table(eng, x, y)
+        if fix is not None:
+            lse[fix[0]] = logsumexp(fix[1], axis=0)
+        return lse
 
     def responsibilities(self, x, y):
         eng = self._bind(x, y)
         eng.estep(*self.canonical(), stats=False, keep_resp=True)
-        return eng.get_resp(self.size)
+        R = eng.get_resp(self.size)
+        fix = self.nan_rows_table(eng, x, y)
+        if fix is not None:
+            R[:, fix[0]] = np.exp(fix[1] - logsumexp(fix[1], axis=0))
+        return R
 
     def rvs(self, size=1):
         z = self.gating.rvs(size)
@@ -199,6 +230,8 @@ class BayesianMixtureOfLinearGaussians:
 
     def _draw_labels(self, eng, label_rng, seed, sweep, stats=True, return_labels=True):
         c, b, W = self.likelihood.canonical()
+        if hasattr(eng, 'check_replicated_once'):      # sharded: every rank drew these blocks from ITS host generator
+            eng.check_replicated_once(c, b, W, what="basis / model / gating parameters drawn for the label pass")
         if label_rng == 'host':
             return eng.gibbs_labels(c, b, W, u=npr.random(size=(1, eng.N)), stats=stats,
                                     return_labels=return_labels)
@@ -212,17 +245,31 @@ class BayesianMixtureOfLinearGaussians:
         eng = self._bind(xx, yy)
         c, b, W = self.likelihood.canonical()
         u = npr.random(size=(1, eng.N))
+        fix = self.likelihood.nan_rows_table(eng, xx, yy)      # rows with a NaN: the reference's element-wise rules (few rows, host)
+
+        def redraw(labels):
+            if fix is not None:
+                rows, Lb = fix
+                cum = np.cumsum(np.exp(Lb - logsumexp(Lb, axis=0)), axis=0)          # mimo/utils/stats.py:8-21 on those columns
+                labels[rows] = np.sum(u[0, rows] * cum[-1] > cum, axis=0).astype(labels.dtype)
+            return labels
         if not lazy:
             labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False, keep_logp=True)
-            return eng.get_logp(self.size), labels
+            L = eng.get_logp(self.size)
+            if fix is not None:
+                L[:, fix[0]] = fix[1]
+            return L, redraw(labels)
         labels, _ = eng.gibbs_labels(c, b, W, u=u, stats=False)
         c, b, W = np.array(c), np.array(b), np.array(W)
 
         def table():
             e = self._bind(xx, yy)
             e.estep(c, b, W, stats=False, keep_logp=True)
-            return e.get_logp(len(c))
-        return LazyTable(table, (len(c), eng.N)), labels
+            L = e.get_logp(len(c))
+            if fix is not None:
+                L[:, fix[0]] = fix[1]
+            return L
+        return LazyTable(table, (len(c), eng.N)), redraw(labels)
 
     def _as2d(self, x, y):
         return (np.asarray(x, dtype=float).reshape(-1, self.input_dim),

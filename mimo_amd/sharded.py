@@ -17,8 +17,18 @@ with one rank at C2 (40 steps, alternating): 6.90 ms per step without a collecti
 installation exercises; the native one exists for hosts without PyTorch (include/mimo_hip.h).  Labels / responsibilities stay on the owning rank; the Philox counter uses
 the global row index, so labels do not depend on the number of ranks.
 
+The sum over the ranks is taken in RANK ORDER by default: the blocks are all-gathered and added
+block 0 first on every rank, so the association — and with it every bit of a sweep — does not depend on the collective
+library's choice of algorithm or channel count (MIMO_SHARDED_RANK_ORDER=0: a plain all_reduce(sum)).
+
+Gibbs sweeps draw the K parameter blocks on EVERY rank from the host generator; the ranks only stay consistent if those
+streams are identical.  `assert_replicated` (called by the drivers on the first sweep of a run) compares a checksum of the
+drawn canonical parameters across the ranks and raises instead of letting a mis-seeded rank diverge silently.
+
 ShardedEngine has the HipEngine interface, so the mixture drivers run unchanged on top of it.
 """
+import os
+
 import numpy as np
 
 from mimo_amd.engine import SuffStats
@@ -40,7 +50,8 @@ class ShardedEngine:
         self._xx_global = None
         self._nccl = dist.get_backend(group) == "nccl"
         self._native = False
-        import os
+        self._rank_order = os.environ.get("MIMO_SHARDED_RANK_ORDER", "1") != "0"
+        self._checked = False
         if self._nccl and hasattr(inner, "comm_init") and os.environ.get("MIMO_SHARDED_NATIVE", "0") == "1":
             try:
                 self._attach_native(inner)
@@ -67,12 +78,38 @@ class ShardedEngine:
         self._native = True
 
     def _nan_share(self, S):
-        """(native route) the NaN rows' share of the gating counts is a host-side sum over THIS rank's rows."""
+        """The NaN rows' share of the gating counts is a host-side sum over THIS rank's rows: when any rank holds such rows,
+        every rank joins one more (K-sized) sum — with or without NaN rows of its own."""
         if S is None or not self._any_nan():       # (one cached scalar all-reduce per data set)
             return S
         local = np.zeros_like(S.n) if getattr(S, 'n_rows', None) is None else S.n_rows - S.n
-        S.n_rows = S.n + self._allreduce_array(local)     # every rank joins, with or without NaN rows of its own
+        S.n_rows = S.n + self._allreduce_array(local)
         return S
+
+    def assert_replicated(self, *arrays, what="parameters"):
+        """Raise if `arrays` (host arrays every rank is supposed to hold identically: the parameter blocks a Gibbs sweep drew
+        from the host generator) differ between the ranks.  Two 2-element reductions (max and min of a checksum)."""
+        import torch
+        h = 0.0
+        for i, a in enumerate(arrays):
+            a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+            h += float(np.dot(a, np.cos(np.arange(a.size) + i)))      # (order-sensitive, cheap; NaN propagates)
+        t = torch.tensor([h, -h], dtype=torch.float64)
+        if self._nccl:
+            t = t.to(f"cuda:{self.device}")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+        hi, neg_lo = (float(v) for v in t.cpu())
+        if not (hi == -neg_lo):
+            raise RuntimeError(
+                f"rank {self.rank}: the {what} differ between the ranks (checksums span [{-neg_lo!r}, {hi!r}]). A sharded Gibbs "
+                "sweep draws the component blocks on every rank from the host generator: seed numpy.random identically on "
+                "all ranks, or pass the same seeded `param_rng` everywhere.")
+
+    def check_replicated_once(self, *arrays, what="parameters"):
+        """`assert_replicated` on the first call only (the drivers call it every sweep)."""
+        if not self._checked:
+            self._checked = True
+            self.assert_replicated(*arrays, what=what)
 
     def _any_nan(self):
         if getattr(self, '_any_nan_cache', None) is None:
@@ -94,6 +131,7 @@ class ShardedEngine:
         self.inner.set_row_offset(self._row0)
         self._xx_global = None
         self._any_nan_cache = None
+        self._checked = False
 
     def set_row_offset(self, row0):
         self._row0 = int(row0)
@@ -128,28 +166,49 @@ class ShardedEngine:
         return self.inner.get_labels()
 
     # ---- the exchange step -------------------------------------------------------------------------
+    def _sum_ranks(self, t):
+        """Sum of tensor `t` over the ranks, in place.  Rank order (default): all-gather, then block 0 + block 1 + ... on
+        every rank — an association that does not depend on the transport."""
+        if not self._rank_order or self.world == 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            return t
+        import torch
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(parts, t, group=self.group)
+        t.copy_(parts[0])
+        for r in range(1, self.world):
+            t.add_(parts[r])
+        return t
+
     def _allreduce_array(self, arr):
         """Sum a host float64 array over the ranks (through a device tensor when the backend is RCCL,
         which only reduces device memory)."""
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        t = torch.from_numpy(np.array(arr, dtype=np.float64))
         if self._nccl:
-            d = t.to(f"cuda:{self.device}")
-            self._dist.all_reduce(d, op=self._dist.ReduceOp.SUM, group=self.group)
-            return d.cpu().numpy()
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.numpy()
+            return self._sum_ranks(t.to(f"cuda:{self.device}")).cpu().numpy()
+        return self._sum_ranks(t).numpy()
 
     def _allreduce_host(self, S, extra):
+        """One sum over the ranks of the packed block + `extra` (+ the K shares of the rows with NaN where any rank has such
+        rows: the gating update counts them, engine.SuffStats.n_rows)."""
         K, D = S.sx.shape
+        nan = self._any_nan()
+        share = [np.zeros(K) if getattr(S, 'n_rows', None) is None else S.n_rows - S.n] if nan else []
+        extra = np.asarray(extra, dtype=float)
         if S.sxx is None:      # 'linear' structure: n, sum r z and the pooled second moment of the local rows
             m = K * (1 + D)
-            out = self._allreduce_array(np.concatenate([S.n, S.sx.ravel(), np.asarray(S.sxx_total, dtype=float).ravel(),
-                                                        np.asarray(extra, dtype=float)]))
-            return (SuffStats(out[:K].copy(), out[K:m].reshape(K, D).copy(), None, out[m:m + D * D].reshape(D, D).copy()),
-                    out[m + D * D:])
-        out = self._allreduce_array(np.concatenate([S.packed().ravel(), np.asarray(extra, dtype=float)]))
-        return SuffStats.from_packed(out[:K * (1 + D + D * D)], K, D), out[K * (1 + D + D * D):]
+            out = self._allreduce_array(np.concatenate([S.n, S.sx.ravel(), np.asarray(S.sxx_total, dtype=float).ravel(), extra] + share))
+            G = SuffStats(out[:K].copy(), out[K:m].reshape(K, D).copy(), None, out[m:m + D * D].reshape(D, D).copy())
+            rest = out[m + D * D:]
+        else:
+            out = self._allreduce_array(np.concatenate([S.packed().ravel(), extra] + share))
+            G = SuffStats.from_packed(out[:K * (1 + D + D * D)], K, D)
+            rest = out[K * (1 + D + D * D):]
+        if nan:
+            G.n_rows = G.n + rest[len(extra):]
+            rest = rest[:len(extra)]
+        return G, rest
 
     # ---- 'linear' structure (one precision for all components) on the device path ---------------------------
     def _linear(self):
@@ -188,10 +247,10 @@ class ShardedEngine:
         return self._buf, n - 4
 
     def _reduce_to_host(self, buf, wait=True):
-        """All-reduce the device block and bring it to pinned host memory, behind the kernels on this object's stream."""
+        """Sum the device block over the ranks and bring it to pinned host memory, behind the kernels on this object's stream."""
         import torch
         with torch.cuda.stream(self._stream):
-            self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._sum_ranks(buf)
             self._host.copy_(buf, non_blocking=True)
         if wait:
             self._stream.synchronize()
@@ -217,7 +276,7 @@ class ShardedEngine:
             return self._allreduce_host(S, sc) if stats else (None, self._allreduce_scalars(sc))
         linear = self._linear()
         if self._device_path and stats and not (keep_resp or keep_logp or keep_lse or entropy_split) \
-                and (not linear or self._tied(W)):
+                and (not linear or self._tied(W)) and not self._any_nan():
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)
             if linear:
@@ -241,7 +300,7 @@ class ShardedEngine:
             self.inner.estep_async(c, b, W)
             self._pending, self._pending_sync = 'native', False
             return
-        if not self._device_path or (self._linear() and not self._tied(W)):
+        if not self._device_path or (self._linear() and not self._tied(W)) or self._any_nan():
             self._pending = self.estep(c, b, W)
             self._pending_sync = True
             return
@@ -280,7 +339,7 @@ class ShardedEngine:
             return labels, self._nan_share(S)
         linear = self._linear()
         if self._device_path and stats and u is None and not return_labels and not keep_logp \
-                and (not linear or self._tied(W)):
+                and (not linear or self._tied(W)) and not self._any_nan():
             K = np.asarray(c).shape[0]
             buf, slen = self._device_buffer(K)
             if linear:
@@ -311,7 +370,7 @@ class ShardedEngine:
         """Random initial responsibilities on every shard (Philox counters use the global row: the draw does not
         depend on the number of ranks), statistics summed over the ranks."""
         if self._native:
-            return self.inner.random_resp_stats(K, seed)
+            return self._nan_share(self.inner.random_resp_stats(K, seed))
         S, _ = self._allreduce_host(self.inner.random_resp_stats(K, seed), [])
         return S
 

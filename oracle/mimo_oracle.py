@@ -443,19 +443,30 @@ def lingauss_log_partition(x, As, lmbdas, affine=True):
     return out
 
 
-def lingauss_log_likelihood(x, y, As, lmbdas, affine=True):
-    """lingauss.py:330-345 (no NaN rows)."""
+def lingauss_log_likelihood(x, y, As, lmbdas, affine=True, x_already_cleaned=False):
+    """lingauss.py:330-345.  Rows with a NaN: x and y go through nan_to_num element by element (on copies here; the
+    reference edits the caller's arrays in place), and the data part is set to 0 only where x AND y hold a NaN (:332-333,
+    :344).  `x_already_cleaned`: the call inside log_complete_likelihood (ilr.py:71-75), where the input density has run
+    first and nan_to_num'ed x IN PLACE — the experts' density then finds no NaN in x and zeroes no row."""
     K, dy = lmbdas.shape[0], lmbdas.shape[1]
+    bx = np.isnan(np.atleast_2d(x)).any(axis=1)
+    by = np.isnan(np.atleast_2d(y)).any(axis=1)
+    bads = np.zeros_like(by) if x_already_cleaned else np.logical_and(bx, by)
+    x = np.nan_to_num(np.array(x, dtype=float)).reshape((-1, As.shape[2] - (1 if affine else 0)))
+    y = np.nan_to_num(np.array(y, dtype=float)).reshape((-1, dy))
     mu = lingauss_predict(x, As, affine)
     log_lik = np.einsum('knd,kdl,nl->kn', mu, lmbdas, y, optimize=True)\
         - 0.5 * np.einsum('nd,kdl,nl->kn', y, lmbdas, y, optimize=True)
+    log_lik[:, bads] = 0.
     log_lik += - lingauss_log_partition(x, As, lmbdas, affine)\
         + np.expand_dims(np.log(np.power(2. * np.pi, - dy / 2.)) * np.ones(K), axis=1)
     return log_lik
 
 
 def lingauss_weighted_statistics(x, y, weights, affine=True):
-    """lingauss.py:306-322 -> (yxTk, xxTk, yyTk, nk)."""
+    """lingauss.py:306-322 -> (yxTk, xxTk, yyTk, nk); rows with a NaN in x or y are dropped together with their weights (:308-310)."""
+    idx = np.logical_and(~np.isnan(x).any(axis=1), ~np.isnan(y).any(axis=1))
+    x, y, weights = x[idx], y[idx], weights[:, idx]
     if affine:
         x = np.hstack((x, np.ones((x.shape[0], 1))))
     contract = 'nd,kn,nl->kdl'
@@ -629,8 +640,8 @@ def gmm_vi_iteration(x, prior, gprior, gating_type, resp):
 
 
 def ilr_log_complete_likelihood(x, y, mus, lmbdas, As, lmbdas_y, probs, affine=True):
-    """ilr.py:71-75."""
-    return gauss_log_likelihood(x, mus, lmbdas) + lingauss_log_likelihood(x, y, As, lmbdas_y, affine)\
+    """ilr.py:71-75 (the input density runs first and cleans x in place: see lingauss_log_likelihood)."""
+    return gauss_log_likelihood(x, mus, lmbdas) + lingauss_log_likelihood(x, y, As, lmbdas_y, affine, x_already_cleaned=True)\
         + np.expand_dims(np.log(probs), axis=1)
 
 

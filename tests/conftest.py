@@ -32,8 +32,10 @@ ILR_CASES = ["ilr_c4_dx8_dy4_k16_stick", "ilr_dx1_dy1_k6_dir"]
 GIBBS_CASES = ["gibbs_c1_trace", "gibbs_stick_trace"]
 # one full-K fixture per BASELINE config whose K is capped above (C3: K = 256, C4: K = 64, C5: K = 128), generated from the
 # reference by `make_golden.py fullk`
-GMM_FULLK_CASES = ["gmm_c3_d8_k256_stick", "gmm_c5_d32_k128_dir"]
-ILR_FULLK_CASES = ["ilr_c4_dx8_dy4_k64_stick"]
+# ... and N = 4099 per config: tile tails across many workgroups against REFERENCE output; the
+# reference's ILR default shape (examples/ilr/evaluate_sine.py:35: 50 experts over dx = dy = 1) at N = 257 and N = 4099
+GMM_FULLK_CASES = ["gmm_c3_d8_k256_stick", "gmm_c5_d32_k128_dir", "gmm_c2_d16_k16_n4099", "gmm_c3_d8_k32_n4099"]
+ILR_FULLK_CASES = ["ilr_c4_dx8_dy4_k64_stick", "ilr_c4_dx8_dy4_k16_n4099", "ilr_dx1_dy1_k50_stick", "ilr_dx1_dy1_k50_n4099"]
 
 
 def gating_of(g, prefix):

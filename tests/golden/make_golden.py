@@ -759,7 +759,69 @@ def nan_rows_case(name, N, D, K, seed, n_bad=9):
     print(name, "ok")
 
 
+def nan_rows_ilr_case(name, N, dx, dy, K, seed):
+    """Method-level behaviour of the reference's linear-Gaussian mixture on rows that hold a NaN in x, in y, or in both
+    (fresh copies per call): lingauss.py:150-151 zeroes the data part of a row only when x AND y hold a NaN and evaluates
+    the other rows on nan_to_num'ed values; inside log_complete_likelihood (ilr.py:71-75) the input density has already
+    nan_to_num'ed x IN PLACE when the experts' density runs, so there no row is zeroed at all; the statistics drop every row
+    with a NaN in x or y (lingauss.py:103-104, 306-310)."""
+    npr.seed(seed)
+    X = make_data(N, dx)
+    Atrue = npr.randn(4, dy, dx)
+    Y = np.ascontiguousarray(np.einsum('ndl,nl->nd', Atrue[npr.randint(4, size=N)], X) + 0.3 * npr.randn(N, dy))
+    dc = dx + 1
+    gating = make_gating(K, 'dirichlet')
+    bprior = StackedNormalWisharts(size=K, dim=dx, mus=np.zeros((K, dx)), kappas=1e-2 * np.ones((K,)),
+                                   psis=np.stack(K * [1e2 * np.eye(dx)]), nus=(dx + 1.) * np.ones((K,)) + 1e-16)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior)
+    mprior = StackedMatrixNormalWisharts(K, dc, dy, Ms=np.zeros((K, dy, dc)), Ks=np.stack(K * [1e-2 * np.eye(dc)]),
+                                         psis=np.stack(K * [np.eye(dy)]), nus=(dy + 1.) * np.ones((K,)) + 1e-16)
+    models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dc, dy, mprior, affine=True)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis, models=models)
+    resp0 = npr.rand(K, N)
+    resp0 /= np.sum(resp0, axis=0)
+    ilr.meanfield_update_parameters(X.copy(), Y.copy(), resp0)        # a sensible point estimate (from the complete data)
+    bad = np.sort(npr.choice(N, size=12, replace=False))
+    Xn, Yn = X.copy(), Y.copy()
+    for i, r in enumerate(bad):
+        kind = i % 3                       # 0: NaN in x only, 1: in y only, 2: in both
+        if kind in (0, 2):
+            Xn[r, i % dx] = np.nan         # (one element: the others of the row keep their values under nan_to_num)
+        if kind in (1, 2):
+            Yn[r, i % dy] = np.nan
+    out = dict(X=Xn, Y=Yn, bad=bad, K=np.array(K), resp0=resp0)
+    put(out, "lik", dict(mus=ilr.basis.likelihood.mus, lmbdas=ilr.basis.likelihood.lmbdas,
+                         As=ilr.models.likelihood.As, lmbdas_y=ilr.models.likelihood.lmbdas,
+                         probs=ilr.gating.likelihood.probs))
+    out["A1_basis_loglik"] = ilr.basis.likelihood.log_likelihood(Xn.copy())
+    out["A5_loglik"] = ilr.models.likelihood.log_likelihood(Xn.copy(), Yn.copy())
+    out["A7_lcl"] = ilr.likelihood.log_complete_likelihood(Xn.copy(), Yn.copy())
+    out["A7_resp"] = ilr.likelihood.responsibilities(Xn.copy(), Yn.copy())
+    out["A7_ll"] = ilr.likelihood.log_likelihood(Xn.copy(), Yn.copy())
+    ms = ilr.models.likelihood.weighted_statistics(Xn.copy(), Yn.copy(), resp0)
+    put(out, "mstats0", dict(yxTk=ms[0], xxTk=ms[1], yyTk=ms[2], nk=ms[3]))
+    bs = ilr.basis.likelihood.weighted_statistics(Xn.copy(), resp0)
+    put(out, "bstats0", dict(xk=bs[0], nk=bs[1], xxTk=bs[2]))
+    u = npr.random(size=(1, N))
+    with FixedUniforms(u):
+        _, labels = ilr.resample_labels(Xn.copy(), Yn.copy())
+    out["u"], out["labels"] = u, labels
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "nan_ilr":
+        nan_rows_ilr_case("nan_rows_ilr_dx2_dy1_k6", N=300, dx=2, dy=1, K=6, seed=1363)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n4099":
+        # SURVEY.md section 8(c): N = 4099 per config (tile tails across many workgroups against REFERENCE output), K capped
+        gmm_case("gmm_c2_d16_k16_n4099", N=4099, D=16, K=16, kind='dirichlet', seed=1364, vi_iters=3)
+        gmm_case("gmm_c3_d8_k32_n4099", N=4099, D=8, K=32, kind='stick', seed=1365, vi_iters=3)
+        ilr_case("ilr_c4_dx8_dy4_k16_n4099", N=4099, dx=8, dy=4, K=16, kind='stick', seed=1366, vi_iters=3)
+        ilr_case("ilr_dx1_dy1_k50_stick", N=257, dx=1, dy=1, K=50, kind='stick', seed=1367, vi_iters=5)
+        ilr_case("ilr_dx1_dy1_k50_n4099", N=4099, dx=1, dy=1, K=50, kind='stick', seed=1368, vi_iters=3)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nan":
         nan_rows_case("nan_rows_gmm_d3_k5", N=400, D=3, K=5, seed=1361)
         nan_rows_case("nan_rows_gmm_d16_k70", N=300, D=16, K=70, seed=1362, n_bad=20)

@@ -668,3 +668,51 @@ def check_nan_rows(name, engine, tol=1e-9):
     # bayesian.py:296 with gaussian.py:468-469, and the statistics call then fails on the shapes)
     vlb = model.meanfield_coordinate_descent(X.copy(), randomize=False, maxiter=5, tol=0., progress_bar=False)
     assert np.all(np.isfinite(vlb)) and np.all(np.diff(vlb) > -1e-8 * abs(vlb[-1]))
+
+
+def check_nan_rows_ilr(name, engine, tol=1e-9):
+    """Rows with a NaN in x, in y, or in both through the linear-Gaussian mixture's reference-shaped methods, against the reference's
+    outputs (lingauss.py:103-104, 150-151, 306-310, 330-345; ilr.py:71-84, 161-164): element-wise nan_to_num in the experts'
+    density, its data part zeroed only where x AND y hold a NaN — and nowhere inside log_complete_likelihood, where the input
+    density has nan_to_num'ed x in place by then —, every such row dropped from the statistics."""
+    from mimo_amd.distributions import (Dirichlet, CategoricalWithDirichlet, StackedNormalWisharts, StackedGaussiansWithNormalWisharts,
+                                        StackedMatrixNormalWisharts, StackedLinearGaussiansWithMatrixNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfLinearGaussians
+    g = load_golden(name)
+    X, Y, K = g["X"], g["Y"], int(g["K"])
+    dx, dy = X.shape[1], Y.shape[1]
+    gating = CategoricalWithDirichlet(dim=K, prior=Dirichlet(dim=K, alphas=np.ones(K)))
+    bprior = StackedNormalWisharts(size=K, dim=dx, mus=np.zeros((K, dx)), kappas=1e-2 * np.ones(K),
+                                   psis=np.stack(K * [1e2 * np.eye(dx)]), nus=(dx + 1.) * np.ones(K) + 1e-16)
+    basis = StackedGaussiansWithNormalWisharts(size=K, dim=dx, prior=bprior, engine=engine)
+    mprior = StackedMatrixNormalWisharts(K, dx + 1, dy, Ms=np.zeros((K, dy, dx + 1)), Ks=np.stack(K * [1e-2 * np.eye(dx + 1)]),
+                                         psis=np.stack(K * [np.eye(dy)]), nus=(dy + 1.) * np.ones(K) + 1e-16)
+    models = StackedLinearGaussiansWithMatrixNormalWisharts(K, dx + 1, dy, mprior, affine=True, engine=engine)
+    ilr = BayesianMixtureOfLinearGaussians(size=K, input_dim=dx, output_dim=dy, gating=gating, basis=basis, models=models,
+                                           engine=engine)
+    ilr.basis.likelihood.params = (g["lik_mus"], g["lik_lmbdas"])
+    ilr.models.likelihood.params = (g["lik_As"], g["lik_lmbdas_y"])
+    ilr.gating.likelihood.params = g["lik_probs"].copy()
+    bx, by = np.isnan(X).any(axis=1), np.isnan(Y).any(axis=1)
+    assert (bx & ~by).any() and (~bx & by).any() and (bx & by).any() and np.array_equal(np.flatnonzero(bx | by), g["bad"])
+    assert rel_err(ilr.basis.likelihood.log_likelihood(X.copy()), g["A1_basis_loglik"]) < tol
+    assert rel_err(ilr.models.likelihood.log_likelihood(X.copy(), Y.copy()), g["A5_loglik"]) < tol
+    assert rel_err(ilr.likelihood.log_complete_likelihood(X.copy(), Y.copy()), g["A7_lcl"]) < tol
+    assert rel_err(ilr.likelihood.responsibilities(X.copy(), Y.copy()), g["A7_resp"]) < tol
+    assert rel_err(ilr.likelihood.log_likelihood(X.copy(), Y.copy()), g["A7_ll"]) < tol
+    ms = ilr.models.likelihood.weighted_statistics(X.copy(), Y.copy(), g["resp0"])
+    for a, b in zip(ms, (g["mstats0_yxTk"], g["mstats0_xxTk"], g["mstats0_yyTk"], g["mstats0_nk"])):
+        assert rel_err(a, b) < tol
+    bs = ilr.basis.likelihood.weighted_statistics(X.copy(), g["resp0"])
+    assert rel_err(bs[0], g["bstats0_xk"]) < tol and rel_err(bs[1], g["bstats0_nk"]) < tol and rel_err(bs[2], g["bstats0_xxTk"]) < tol
+    import mimo_amd.mixtures.ilr as ilr_mod
+    u = g["u"]
+    orig = ilr_mod.npr.random
+    ilr_mod.npr.random = lambda size=None: u.reshape(size)           # the uniforms the reference drew
+    try:
+        for lazy in (True, False):
+            table, labels = ilr.resample_labels(X.copy(), Y.copy(), lazy=lazy)
+            assert np.array_equal(labels, g["labels"])
+            assert rel_err(np.asarray(table), g["A7_lcl"]) < tol
+    finally:
+        ilr_mod.npr.random = orig

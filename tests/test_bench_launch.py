@@ -1,7 +1,7 @@
 """CPU: `python bench.py --gpus 2` outside a distributed launcher starts its own ranks (torch.distributed.run on
 127.0.0.1) and relays rank 0's JSON line as the last line of stdout — the form in which the driver runs the scaling
 bench.  Dry run: the ranks sit on the CPU over gloo with the oracle-backed engine double (a TEST HOOK of bench.py,
-`--dry-run-engine`); the line is marked dry_run and carries no measurement, but every rank walks the real step loop
+the environment variable MIMO_BENCH_DRY_RUN_ENGINE — not a command-line argument of the measurement script); the line is marked dry_run and carries no measurement, but every rank walks the real step loop
 (public driver iteration, sharded engine, all-reduce, barrier + max-over-ranks timing)."""
 import json
 import os
@@ -22,8 +22,8 @@ def _run(args, env_extra=None):
 
 @pytest.mark.parametrize("config", ["c2", "c3"])
 def test_bench_self_launches_its_ranks(config):
-    p = _run(["--gpus", "2", "--rows", "3000", "--steps", "2", "--warmup", "1", "--config", config,
-              "--dry-run-engine", "oracle_engine:OracleEngine", "--no-cpu-baseline"])
+    p = _run(["--gpus", "2", "--rows", "3000", "--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline"],
+             {"MIMO_BENCH_DRY_RUN_ENGINE": "oracle_engine:OracleEngine"})
     assert p.returncode == 0, p.stderr[-2000:]
     last = [ln for ln in p.stdout.splitlines() if ln.strip()][-1]
     d = json.loads(last)
@@ -31,13 +31,21 @@ def test_bench_self_launches_its_ranks(config):
     assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["ms_per_step"] > 0
     K, D = d["config"]["K"], d["config"]["Dz"]
     assert d["allreduce_bytes_per_step"] == 8 * (K * (1 + D + D * D) + 4)
+    pr = d["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 2 and pr["max"] == max(pr["all"]) and abs(pr["max"] - d["ms_per_step"]) < 1e-9
+    assert "rank order" in d["allreduce_route"]
     if config == "c2":
         assert d["elbo_first_last"][1] >= d["elbo_first_last"][0]      # the bound rises over the sharded iterations
 
 
 def test_bench_propagates_a_failing_rank():
-    p = _run(["--gpus", "2", "--rows", "1000", "--steps", "1", "--warmup", "0", "--dry-run-engine", "no_such_module:X"])
+    p = _run(["--gpus", "2", "--rows", "1000", "--steps", "1", "--warmup", "0"], {"MIMO_BENCH_DRY_RUN_ENGINE": "no_such_module:X"})
     assert p.returncode != 0
+
+
+def test_the_dry_run_hook_is_not_a_command_line_argument():
+    p = _run(["--gpus", "2", "--rows", "1000", "--dry-run-engine", "oracle_engine:OracleEngine"])
+    assert p.returncode != 0 and "unrecognized arguments" in p.stderr
 
 
 def test_world_size_mismatch_is_an_error():

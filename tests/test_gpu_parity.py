@@ -493,6 +493,10 @@ def test_example_scripts_run_on_the_gpu():
     assert "evaluations/s" in out
     out = run("examples/ilr_sine.py", "--rows", "5000", "--experts", "12", "--iters", "60")
     assert float(re.search(r"RMSE against the noiseless curve: ([0-9.]+)", out).group(1)) < 0.5, out
+    # the reference's default truncation (examples/ilr/evaluate_sine.py:35: 50 experts over dx = dy = 1): the narrow kernels
+    out = run("examples/ilr_sine.py", "--rows", "5000", "--experts", "50", "--iters", "40")
+    assert "softmax pass 'narrow', label pass 'narrow'" in out, out
+    assert float(re.search(r"RMSE against the noiseless curve: ([0-9.]+)", out).group(1)) < 0.5, out
 
 
 def test_full_size_properties(engine):
@@ -796,11 +800,15 @@ def test_lazy_log_prob_table(engine):
     assert rel_err(lp_eager, model.likelihood.log_complete_likelihood(X)) < 1e-14
 
 
-def test_native_rccl_communicator_one_rank(engine):
+@pytest.mark.parametrize("ordered", [False, True])
+def test_native_rccl_communicator_one_rank(engine, ordered, monkeypatch):
     """mimo_comm_init: the library's own RCCL communicator (no torch.distributed).  One rank is all a one-GPU box can
     run: the collective is issued on the context's stream behind the kernels, so every entry point must return the very
-    numbers it returns without it — synchronous, asynchronous, device-out, Gibbs and the small-shape kernel."""
+    numbers it returns without it — synchronous, asynchronous, device-out, Gibbs and the small-shape kernel.  `ordered`:
+    the rank-ordered sum (ncclAllGather + the in-order add kernel) forced on for the one rank; otherwise ncclAllReduce."""
     from mimo_amd.engine import HipEngine
+    if ordered:
+        monkeypatch.setenv("MIMO_COMM_RANK_ORDER_FORCE", "1")
     rng = np.random.default_rng(5)
     eng = HipEngine(0)
     try:
@@ -836,6 +844,12 @@ def test_rows_with_nan(engine, name):
     assert engine.n_bad == len(g["bad"]) and torch.isnan(t).any()
     engine.upload(np.nan_to_num(g["X"]))
     assert engine.n_bad == 0
+
+
+def test_rows_with_nan_in_a_linear_gaussian_mixture(engine):
+    """lingauss.py:150-151 / ilr.py:71-75 of the reference: element-wise nan_to_num in the experts' density; reference fixture."""
+    import model_checks as mc
+    mc.check_nan_rows_ilr("nan_rows_ilr_dx2_dy1_k6", engine)
 
 
 def test_row_weights_stay_resident(engine):

@@ -151,3 +151,9 @@ def test_sample_discrete_from_log_and_random_start_on_the_double():
 @pytest.mark.parametrize("name", ["nan_rows_gmm_d3_k5", "nan_rows_gmm_d16_k70"])
 def test_rows_with_nan(name):
     mc.check_nan_rows(name, OracleEngine())
+
+
+def test_rows_with_nan_in_a_linear_gaussian_mixture():
+    """the reference's element-wise NaN rules of the experts' density (lingauss.py:150-151, ilr.py:71-75), host classes over the
+    oracle-backed engine double against outputs of the reference"""
+    mc.check_nan_rows_ilr("nan_rows_ilr_dx2_dy1_k6", OracleEngine())

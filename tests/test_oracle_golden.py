@@ -268,3 +268,20 @@ def test_rows_with_nan_follow_the_reference(name):
     assert np.array_equal(O.sample_discrete_from_log(lcl, g["u"]), g["labels"])
     assert rel_err(O.categorical_weighted_statistics(g["A2_resp"]), g["counts"]) < TOL
     assert np.array_equal(O.categorical_statistics(g["labels"], K), g["lcounts"])
+
+
+def test_rows_with_nan_in_a_linear_gaussian_mixture_follow_the_reference():
+    """lingauss.py:103-104, 150-151, 306-310, 330-345 and ilr.py:71-84, 161-164 of the reference on rows with a NaN in x, in y, or in
+    both: the oracle's restatement against outputs of the reference (fixture nan_rows_ilr_dx2_dy1_k6)."""
+    g = load_golden("nan_rows_ilr_dx2_dy1_k6")
+    X, Y, K = g["X"], g["Y"], int(g["K"])
+    assert rel_err(O.gauss_log_likelihood(X, g["lik_mus"], g["lik_lmbdas"]), g["A1_basis_loglik"]) < TOL
+    assert rel_err(O.lingauss_log_likelihood(X, Y, g["lik_As"], g["lik_lmbdas_y"]), g["A5_loglik"]) < TOL
+    lcl = O.ilr_log_complete_likelihood(X, Y, g["lik_mus"], g["lik_lmbdas"], g["lik_As"], g["lik_lmbdas_y"], g["lik_probs"])
+    assert rel_err(lcl, g["A7_lcl"]) < TOL and rel_err(O.responsibilities(lcl), g["A7_resp"]) < TOL
+    from scipy.special import logsumexp
+    assert rel_err(logsumexp(lcl, axis=0), g["A7_ll"]) < TOL
+    ms = O.lingauss_weighted_statistics(X, Y, g["resp0"])
+    for a, b in zip(ms, (g["mstats0_yxTk"], g["mstats0_xxTk"], g["mstats0_yyTk"], g["mstats0_nk"])):
+        assert rel_err(a, b) < TOL
+    assert np.array_equal(O.sample_discrete_from_log(lcl, g["u"]), g["labels"])

@@ -238,3 +238,110 @@ def test_two_rank_svi_and_predict():
     one.upload(np.ascontiguousarray(X[:, :1]))
     mu, _, _ = one.predict(c, b, W, M, Q, Cc)
     assert np.allclose(np.concatenate([res[0][4], res[1][4]]), mu, rtol=1e-12, atol=1e-14)
+
+
+def _worker_order(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        from mimo_amd.sharded import ShardedEngine
+        eng = ShardedEngine(OracleEngine())
+        # blocks whose sum depends on the association: magnitudes 1e16 / 1 / -1e16
+        blocks = [np.array([1e16, 1.0, 3.0]), np.array([1.0, 1e16, -1e16]), np.array([-1e16, -1e16, 1e16 + 2.0])]
+        out = eng._allreduce_array(blocks[rank])
+        # replication check: identical arrays pass, a rank-dependent array raises on every rank
+        eng.assert_replicated(np.arange(5.0), np.ones((2, 2)))
+        try:
+            eng.assert_replicated(np.arange(5.0) + rank)
+            raised = False
+        except RuntimeError as exc:
+            raised = "differ between the ranks" in str(exc)
+        q.put((rank, out, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_sum_is_taken_in_rank_order_and_divergence_is_caught():
+    """The sum over the ranks is ((block 0 + block 1) + block 2) on every rank, bit for bit (all-gather + ordered add: the
+    association does not depend on the transport), and `assert_replicated` raises on every rank when the host-drawn
+    parameters differ between the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_order, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blocks = [np.array([1e16, 1.0, 3.0]), np.array([1.0, 1e16, -1e16]), np.array([-1e16, -1e16, 1e16 + 2.0])]
+    expect = (blocks[0] + blocks[1]) + blocks[2]
+    assert not np.array_equal(expect, blocks[0] + (blocks[1] + blocks[2]))        # the test vectors do tell the orders apart
+    for r in range(3):
+        assert np.array_equal(res[r][1], expect) and res[r][2]
+
+
+def _worker_nan(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        from mimo_amd.sharded import ShardedEngine, shard_rows
+        rng = np.random.default_rng(5)
+        N, D, K = 400, 3, 5
+        X = rng.standard_normal((N, D)) * 2.
+        X[[210, 333, 399], 1] = np.nan                  # rows with NaN on the SECOND shard only
+        A = rng.standard_normal((K, D, D)); W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+        b, c = rng.standard_normal((K, D)), rng.standard_normal(K)
+        lo, hi = shard_rows(N, rank, world)
+        eng = ShardedEngine(OracleEngine(), row_offset=lo)
+        eng.upload(np.ascontiguousarray(X[lo:hi]))
+        S, sc = eng.estep(c, b, W)
+        lab, G = eng.gibbs_labels(c, b, W, seed=3, sweep=1)
+        R = eng.random_resp_stats(K, seed=2)
+        q.put((rank, S.n.copy(), S.gating_counts.copy(), G.n.copy(), G.gating_counts.copy(), sc[0], R.gating_counts.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_nan_rows_on_one_rank_only():
+    """Rows with NaN on one shard only: the gating counts every rank ends up with — statistics of the complete
+    rows + the share of the NaN rows — equal the single-process engine's, for the softmax pass, the label pass and the
+    random start; the ranks that hold no such rows still join the extra sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_nan, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle_engine import OracleEngine
+    rng = np.random.default_rng(5)
+    N, D, K = 400, 3, 5
+    X = rng.standard_normal((N, D)) * 2.
+    X[[210, 333, 399], 1] = np.nan
+    A = rng.standard_normal((K, D, D)); W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+    b, c = rng.standard_normal((K, D)), rng.standard_normal(K)
+    eng = OracleEngine(); eng.upload(X)
+    S, sc = eng.estep(c, b, W)
+    lab, G = eng.gibbs_labels(c, b, W, seed=3, sweep=1)
+    assert S.n_rows is not None and abs(S.gating_counts.sum() - N) < 1e-9 and G.gating_counts.sum() == N
+    for r in range(2):
+        assert np.allclose(res[r][1], S.n, rtol=1e-12) and np.allclose(res[r][2], S.gating_counts, rtol=1e-12)
+        assert np.array_equal(res[r][3], G.n) and np.array_equal(res[r][4], G.gating_counts)
+        assert abs(res[r][5] - sc[0]) < 1e-9 * abs(sc[0])
+        assert abs(res[r][6].sum() - N) < 1e-9
+    assert np.array_equal(res[0][2], res[1][2])

@@ -1,6 +1,15 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/: kernel-trace stats, then PMC counters in separate passes
 # (never combined with sys/hip tracing).  Usage on the GPU box: bash tools/profile.sh <tag> <config> [bench args]
+# MULTI-RANK profiles (an 8-GPU node): wrap EACH RANK's python directly and export the rendezvous by hand — never the
+# self-launching parent (`bench.py --gpus N` without RANK / WORLD_SIZE starts torch.distributed.run as a child; rocprofv3's
+# preloaded library would initialise the GPU in the parent, and the launcher's re-exec is then the forbidden exec):
+#   for r in 0 1 2 3 4 5 6 7; do
+#     RANK=$r LOCAL_RANK=$r WORLD_SIZE=8 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 \
+#       rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rank$r -- python3 bench.py --gpus 8 --config c5 &
+#   done; wait
+# (bench.py sees RANK / WORLD_SIZE and joins the group instead of launching; the JSON line of rank 0 carries n_ranks_seen,
+#  ms_per_step_per_rank {min, max, all} and the all-reduce route.)
 set -u
 TAG=${1:-r02}; CFG=${2:-c2}; shift; shift || true
 REPO=$(pwd)
