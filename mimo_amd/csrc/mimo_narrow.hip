@@ -77,12 +77,16 @@ constexpr int narrow_waves(int V, int NSF, int MODE) { return narrow_occ(V, NSF,
 #ifdef MIMO_NARROW_FORCE_LEAN
 constexpr bool narrow_lean(int, int, int) { return MIMO_NARROW_FORCE_LEAN != 0; }
 #else
-constexpr bool narrow_lean(int V, int NSF, int MODE) { return (narrow_occ(V, NSF, MODE) & 8) != 0; }
+constexpr bool narrow_lean(int V, int NSF, int MODE) { return NSF > 4 || (narrow_occ(V, NSF, MODE) & 8) != 0; }
 #endif
 
 template <int V, int NSF, int MODE, int ZI>   // MODE 0: softmax + statistics (fast mean-field / EM pass), 1: label draw
 __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_kernel(const KernelArgs a) {
   constexpr bool LEAN = narrow_lean(V, NSF, MODE);
+  // NSF > 4 (more than 16 features: Dz >= 5, few components): the operand factors of a step come from a small LDS table of
+  // packed byte offsets inside the step loops instead of 4 NSF address registers and 2 NSF operand registers
+  constexpr bool FT = NSF > 4;
+  constexpr int NP = FT ? 1 : NSF;
   constexpr int EB = LEAN ? 1 : kNarrowEB;                    // exponentials per batch (1: inline, hipcc schedules them)
   extern __shared__ __align__(16) unsigned char smem[];
   const int ZS = a.ZS;
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   double* etab = Th + (size_t)(NSF * V + kNarrowPF) * 16;     // [kExpTab]; the epilogue's scratch aliases it
   double* Zall = etab + kExpTab;                              // [4 waves][16][ZS]
   double* sred = Zall + (size_t)4 * 16 * ZS;                  // [4]
+  uint32_t* ftab = reinterpret_cast<uint32_t*>(sred + 4);     // [NSF][4] (FT only)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   for (int e = tid; e < NSF * V * 16; e += kNarrowWG) Th[e] = a.theta[e];
   for (int e = tid; e < kNarrowPF * 16; e += kNarrowWG) Th[NSF * V * 16 + e] = 0.0;
   for (int e = tid; e < kExpTab; e += kNarrowWG) etab[e] = exp_tab_entry_c(e);
+  if constexpr (FT)
+    for (int e = tid; e < 4 * NSF; e += kNarrowWG) ftab[e] = 8u * a.feat[2 * e] | (8u * a.feat[2 * e + 1]) << 16;
   wg_sync();
 
   const int64_t nsteps = (N + 15) / 16;
@@ -127,12 +134,23 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   // feature 4 s + lo of row 4 b + hi (z~ = [z, 1, 0]: padded features read the zero slot)
   const double* row0 = Zw + (4 * b + lo) * ZS;
   const double* row1 = Zw + (4 * b + hi) * ZS;
-  const double* ea[NSF];
-  const double* eb[NSF];
-  const double* sa[MODE == 0 ? NSF : 1];
-  const double* sb[MODE == 0 ? NSF : 1];
+  const double* ea[NP];
+  const double* eb[NP];
+  const double* sa[MODE == 0 ? NP : 1];
+  const double* sb[MODE == 0 ? NP : 1];
+  const char* z0b = reinterpret_cast<const char*>(row0);
+  const char* z1b = reinterpret_cast<const char*>(row1);
+  auto feat0 = [&](int s) -> double {          // FT: feature 4 s + hi of row 4 b + lo
+    const uint32_t u = ftab[4 * s + hi];
+    return *reinterpret_cast<const double*>(z0b + (u & 0xffffu)) * *reinterpret_cast<const double*>(z0b + (u >> 16));
+  };
+  auto feat1 = [&](int s) -> double {          // FT: feature 4 s + lo of row 4 b + hi
+    const uint32_t u = ftab[4 * s + lo];
+    return *reinterpret_cast<const double*>(z1b + (u & 0xffffu)) * *reinterpret_cast<const double*>(z1b + (u >> 16));
+  };
 #pragma unroll
-  for (int s = 0; s < NSF; ++s) {
+  for (int s = 0; s < NP; ++s) {
+    if constexpr (FT) break;
     ea[s] = row0 + a.feat[2 * (4 * s + hi)];
     eb[s] = row0 + a.feat[2 * (4 * s + hi) + 1];
     if constexpr (MODE == 0) {
@@ -165,13 +183,15 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       Zw[lane * ZS + D + 1] = 0.0;
     }
   };
-  double fa[NSF], fb[NSF], ga[MODE == 0 ? NSF : 1], gb[MODE == 0 ? NSF : 1];      // operand factors of the step in hand
+  double fa[NP], fb[NP], ga[MODE == 0 ? NP : 1], gb[MODE == 0 ? NP : 1];      // operand factors of the step in hand
   auto read_factors = [&]() {
+    if constexpr (!FT) {
 #pragma unroll
-    for (int s = 0; s < NSF; ++s) { fa[s] = *ea[s]; fb[s] = *eb[s]; }
-    if constexpr (MODE == 0) {
+      for (int s = 0; s < NP; ++s) { fa[s] = *ea[s]; fb[s] = *eb[s]; }
+      if constexpr (MODE == 0) {
 #pragma unroll
-      for (int s = 0; s < NSF; ++s) { ga[s] = *sa[s]; gb[s] = *sb[s]; }
+        for (int s = 0; s < NP; ++s) { ga[s] = *sa[s]; gb[s] = *sb[s]; }
+      }
     }
   };
   if (!LEAN && wv < nsteps) {
@@ -184,18 +204,20 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   for (int64_t t = wv; t < nsteps; t += nwaves) {
     const int64_t n1 = t * 16 + 4 * b + hi;           // the row this lane normalises / draws for
     const bool valid = n1 < N;
-    double av[NSF], bv[MODE == 0 ? NSF : 1];
+    double av[NP], bv[MODE == 0 ? NP : 1];
     if constexpr (LEAN) {                               // stage this step's rows and read its factors right away
       stage_z(t);
       if (t + nwaves < nsteps) load_z(t + nwaves);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       read_factors();
     }
+    if constexpr (!FT) {
 #pragma unroll
-    for (int s = 0; s < NSF; ++s) av[s] = fa[s] * fb[s];
-    if constexpr (MODE == 0) {
+      for (int s = 0; s < NP; ++s) av[s] = fa[s] * fb[s];
+      if constexpr (MODE == 0) {
 #pragma unroll
-      for (int s = 0; s < NSF; ++s) bv[s] = ga[s] * gb[s];
+        for (int s = 0; s < NP; ++s) bv[s] = ga[s] * gb[s];
+      }
     }
     // ---- the next step's rows go to the LDS block now (this step's factors are in registers)
     const bool more = !LEAN && t + nwaves < nsteps;
@@ -212,14 +234,23 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       double ring[kNarrowPF];
 #pragma unroll
       for (int e = 0; e < kNarrowPF; ++e) ring[e] = thl[e * 16];
+      double aq = 0.0;
+      if constexpr (FT) aq = feat0(0);
 #pragma unroll
       for (int s = 0; s < NSF; ++s) {
+        double acur;
+        if constexpr (FT) {
+          acur = aq;
+          if (s + 1 < NSF) aq = feat0(s + 1);        // (one step ahead: the LDS round trip hides under this step's products)
+        } else {
+          acur = av[s];
+        }
 #pragma unroll
         for (int c = 0; c < V; ++c) {
           const int e = s * V + c;
           const double tv = ring[e % kNarrowPF];
           if (!(MIMO_NARROW_WHATIF & 2)) ring[e % kNarrowPF] = thl[(e + kNarrowPF) * 16];     // (the last reads take the zero slices behind the image)
-          acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s], tv, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(acur, tv, acc[c], 0, 0, 0);
         }
       }
     }
@@ -268,19 +299,31 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       inv = fma(fma(-ssum, inv, 1.0), inv, inv);
       inv = fma(fma(-ssum, inv, 1.0), inv, inv);
       if (lo == 0 && valid) { sc_lse += m; sc_prod *= ssum; }
+      if constexpr (!FT) {
 #pragma unroll
-      for (int s = 0; s < NSF; ++s) bv[s] *= inv;       // r = e / sum e: the normaliser rides on the feature operand
+        for (int s = 0; s < NP; ++s) bv[s] *= inv;      // r = e / sum e: the normaliser rides on the feature operand
+      }
       __builtin_amdgcn_s_setprio(0);
       if (more) {                                       // the next step's operand factors: in flight under the second product
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         read_factors();
       }
       // ---- S += R' . Phi ------------------------------------------------------------------------------------
+      double bq = 0.0;
+      if constexpr (FT) bq = feat1(0) * inv;
 #pragma unroll
-      for (int s = 0; s < NSF; ++s)
+      for (int s = 0; s < NSF; ++s) {
+        double bcur;
+        if constexpr (FT) {
+          bcur = bq;
+          if (s + 1 < NSF) bq = feat1(s + 1) * inv;
+        } else {
+          bcur = bv[s];
+        }
 #pragma unroll
         for (int c = 0; c < V; ++c)
-          sacc[c][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[c], bv[s], sacc[c][s], 0, 0, 0);
+          sacc[c][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[c], bcur, sacc[c][s], 0, 0, 0);
+      }
       if (++since_flush == 64) {          // (4 V)^64 <= 128^64 = 2^448 stays inside the float64 range
         sc_lse += log(sc_prod);
         sc_prod = 1.0;
@@ -422,23 +465,32 @@ int narrow_v(int K) {
 int narrow_nsf(int F) { return (F + 3) / 4; }
 
 size_t narrow_lds_bytes(int V, int NSF, int ZS) {
-  return sizeof(double) * ((size_t)(NSF * V + kNarrowPF) * 16 + kExpTab + (size_t)4 * 16 * ZS + 4);
+  return sizeof(double) * ((size_t)(NSF * V + kNarrowPF) * 16 + kExpTab + (size_t)4 * 16 * ZS + 4) + sizeof(uint32_t) * 4 * (size_t)NSF;
 }
 
 typedef void (*narrow_fn)(const KernelArgs);
 
+// instantiated: up to 16 features (NSF <= 4) for Dz <= 4 (ZI = 1: the 16 x Dz <= 64 elements of a step in one load per lane) with
+// every slot count; more features (the table-driven loops) for Dz = 5 .. 16 (ZI = 4) while the V NSF accumulators fit: V NSF <= 96
+constexpr int kNarrowMaxAcc = 96, kNarrowMaxVWide = 8;
 template <int V, int NSF>
 static narrow_fn pick_narrow_mode(int gibbs, int zi) {
-  if (zi == 1) return gibbs ? narrow_kernel<V, NSF, 1, 1> : narrow_kernel<V, NSF, 0, 1>;
+  if constexpr (NSF <= 4) {
+    if (zi == 1) return gibbs ? narrow_kernel<V, NSF, 1, 1> : narrow_kernel<V, NSF, 0, 1>;
+  } else if constexpr (V <= kNarrowMaxVWide && V * NSF <= kNarrowMaxAcc) {
+    if (zi == 4) return gibbs ? narrow_kernel<V, NSF, 1, 4> : narrow_kernel<V, NSF, 0, 4>;
+  }
   return nullptr;
 }
 template <int V>
 static narrow_fn pick_narrow_nsf(int nsf, int gibbs, int zi) {
   switch (nsf) {
-    case 1: return pick_narrow_mode<V, 1>(gibbs, zi);
-    case 2: return pick_narrow_mode<V, 2>(gibbs, zi);
-    case 3: return pick_narrow_mode<V, 3>(gibbs, zi);
-    case 4: return pick_narrow_mode<V, 4>(gibbs, zi);
+#define MIMO_NN(n) case n: return pick_narrow_mode<V, n>(gibbs, zi);
+    MIMO_NN(1) MIMO_NN(2) MIMO_NN(3) MIMO_NN(4)
+    // ceil(F / 4) of the full maps of Dz = 5 .. 16 (F = 21 .. 153) and of the reduced maps beyond 16 features
+    MIMO_NN(5) MIMO_NN(6) MIMO_NN(7) MIMO_NN(8) MIMO_NN(9) MIMO_NN(12) MIMO_NN(14) MIMO_NN(17) MIMO_NN(20) MIMO_NN(23)
+    MIMO_NN(27) MIMO_NN(30) MIMO_NN(34) MIMO_NN(39)
+#undef MIMO_NN
   }
   return nullptr;
 }
@@ -460,7 +512,18 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   static const bool on = [] { const char* e = getenv("MIMO_NARROW"); return !e || atoi(e) != 0; }();
   static const int kmin = [] { const char* e = getenv("MIMO_NARROW_MIN_K"); return e ? atoi(e) : 33; }();
   static const int kmax = [] { const char* e = getenv("MIMO_NARROW_MAX_K"); return e ? atoi(e) : 128; }();
-  if (!on || K < kmin || K > kmax || K > 128 || F > 16 || D > 4) return false;
+  static const bool wide_on = [] { const char* e = getenv("MIMO_NARROW_WIDE"); return !e || atoi(e) != 0; }();
+  static const int wide_kmax = [] { const char* e = getenv("MIMO_NARROW_WIDE_MAX_K"); return e ? atoi(e) : 0; }();
+  if (!on) return false;
+  if (F > 16) {                 // few components, many features: the table-driven loops (Dz = 5 .. 16)
+    // measured against the row-owner / tile kernels (tools/wide_sweep.py, N = 2e6, profiles/r03_wide_sweep.txt): K <= 16 wins wherever
+    // the accumulators fit (Dz = 8: K = 4 276 -> 96 us, K = 16 271 -> 193; Dz = 16: K = 4 629 -> 256, K = 8 625 -> 349), K = 24 up
+    // to Dz = 8 (248 against 274 us), K = 32 no longer (Dz = 8: 351 against 268)
+    const int kmax_w = wide_kmax > 0 ? wide_kmax : (D <= 8 ? 24 : 16);
+    if (!wide_on || K < 1 || K > kmax_w || D < 5 || D > 16) return false;
+  } else if (K < kmin || K > kmax || K > 128 || D > 4) {
+    return false;
+  }
   const int V = narrow_v(K), nsf = narrow_nsf(F);
   if (!V || !pick_narrow(V, nsf, gibbs, narrow_zi(D))) return false;
   return narrow_lds_bytes(V, nsf, ZS) <= 64 * 1024;

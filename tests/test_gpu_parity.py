@@ -671,7 +671,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(900 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if D <= 4 and 33 <= K <= 128 else "rowwave")
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
@@ -893,7 +893,8 @@ def test_row_owner_softmax_pass(engine, D, K, N):
     rng = np.random.default_rng(4000 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K)["kind"] == ("rowwave-vi" if (D, K) not in ((2, 33), (1, 33)) else "narrow")
+    narrow = (D, K) in ((2, 33), (1, 33)) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16))      # (few components at Dz >= 5: the table-driven narrow kernels)
+    assert engine.plan(K)["kind"] == ("narrow" if narrow else "rowwave-vi")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)
     R = np.exp(L - lse)
@@ -936,7 +937,12 @@ NARROW_SHAPES = [(2, 50), (2, 64), (2, 33), (2, 100), (2, 128), (1, 50), (1, 97)
                  (2, 93), (2, 101), (2, 109), (2, 117), (2, 125)]
 
 
-@pytest.mark.parametrize("D,K", NARROW_SHAPES)
+# ... and few components over many features (Dz = 5 .. 16, K <= 16: the table-driven loops; every contraction length once)
+NARROW_WIDE_SHAPES = [(5, 16), (5, 24), (8, 23), (6, 17), (6, 8), (7, 12), (8, 4), (8, 16), (9, 7), (10, 8), (11, 16), (12, 4), (12, 13), (13, 9), (14, 12),
+                      (15, 5), (15, 8), (16, 1), (16, 4), (16, 8), (9, 16), (6, 3), (16, 2), (14, 2)]
+
+
+@pytest.mark.parametrize("D,K", NARROW_SHAPES + NARROW_WIDE_SHAPES)
 @pytest.mark.parametrize("N", [1, 17, 5003, 4 * 256 * 16 * 5 + 11])
 def test_narrow_kernels_vs_oracle(engine, D, K, N):
     """narrow_kernel (mimo_narrow.hip: Dz <= 4 with 32 < K <= 128 — the reference's ILR defaults, examples/ilr/evaluate_sine.py:35 —
@@ -978,6 +984,8 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
     if N <= 6000:
         Sg, scg = engine.estep(c, b, W, keep_resp=True, entropy_split=True)      # generic request: tile kernels
         assert rel_err(Sg.sxx, sxx) < 1e-11 and rel_err(engine.get_resp(), R) < 1e-11 and abs(scg[0] - sc[0]) < 1e-11 * max(1., abs(sc[0]))
+        if K == 1:
+            return
         c2 = c.copy(); c2[K // 2] = -np.inf                          # a switched-off component
         L2 = L.copy(); L2[K // 2] = -np.inf
         lse2 = logsumexp(L2, axis=0)
