@@ -227,6 +227,14 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
                  const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
                  const double* y, const double* P, const double* ld,
                  double* mu, double* covar, double* nlpd);
+/* The same with flags: MIMO_F_DEVICE_IN — y is a device pointer; MIMO_F_DEVICE_OUT — mu, covar (and nlpd) are device
+ * pointers the kernel writes directly, and the call returns without waiting (the results are ordered on the context's
+ * stream like every other launch: mimo_set_stream / the caller's next stream operation).  With both flags nothing but
+ * the K parameter blocks crosses PCIe: at N = 4e6, dx = dy = 1 the host-array form spends 120 of its 125 ms there. */
+int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                       const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
+                       const double* y, const double* P, const double* ld,
+                       double* mu, double* covar, double* nlpd, int flags);
 
 /* ---- rows with missing values ------------------------------------------------------------------
  * A data row that holds a NaN is treated the way the reference's Gaussian family treats it: it is LEFT OUT of every

@@ -47,6 +47,8 @@ SIGNATURES = {
     "mimo_host_digamma": (C.c_double, [C.c_double]),
     "mimo_predict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mimo_predict_flags": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mimo_get_resp": (C.c_int, [_vp, _vp]),
     "mimo_get_logp": (C.c_int, [_vp, _vp]),
     "mimo_get_lse": (C.c_int, [_vp, _vp]),

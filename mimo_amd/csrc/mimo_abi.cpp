@@ -94,7 +94,7 @@ struct mimo_ctx {
   bool prof = false;
   struct ProfEvent { hipEvent_t e0, e1; int name; };
   std::vector<ProfEvent> pending;
-  static constexpr int kProfNames = 8;
+  static constexpr int kProfNames = 16;
   const char* prof_name[kProfNames] = {nullptr};
   double prof_name_ms[kProfNames] = {0.0};
   int64_t prof_name_n[kProfNames] = {0};
@@ -110,9 +110,11 @@ static int rs_pad() {
   return v;
 }
 // weight-tile row padding (doubles); MIMO_LS_PAD overrides for bank-conflict experiments
-static int ls_pad() {
-  static const int v = [] { const char* e = getenv("MIMO_LS_PAD"); return e ? atoi(e) : 2; }();
-  return v;
+// (default 2; 1 for the Dz >= 14, 49 <= K <= 64 shapes of the single-pass kernels — C2: kernel 6.62 -> 6.57 ms, measured with
+//  tools/pad_sweep.sh; elsewhere 1 and 2 are within +-2 % of each other, tools/pad_shapes.sh)
+static int ls_pad(int K16, int D) {
+  static const int v = [] { const char* e = getenv("MIMO_LS_PAD"); return e ? atoi(e) : 0; }();
+  return v > 0 ? v : (K16 == 4 && D >= 14 && D <= kMaxFusedD) ? 1 : 2;
 }
 #ifdef MIMO_STAMPS
 static unsigned long long* g_stamps = nullptr;
@@ -246,7 +248,7 @@ static void fill_args(mimo_ctx* ctx, int K, KernelArgs* a) {
   a->F16_total = ctx->F16;
   a->cb0 = 0;
   a->write_scalars = 1;
-  a->LS = a->K16 * 16 + ls_pad();
+  a->LS = a->K16 * 16 + ls_pad(a->K16, ctx->D);
   a->feat = ctx->feat_d;
   a->row0 = ctx->row0;
   a->do_stats = 1;
@@ -1200,7 +1202,15 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
                  const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
                  const double* y, const double* P, const double* ld,
                  double* mu, double* covar, double* nlpd) {
+  return mimo_predict_flags(ctx, c, b, W, K, M, Q, Cc, dy, affine, mode, y, P, ld, mu, covar, nlpd, 0);
+}
+
+int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
+                       const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
+                       const double* y, const double* P, const double* ld,
+                       double* mu, double* covar, double* nlpd, int flags) {
   return guarded(ctx, [&]() -> int {
+  const bool dev_in = (flags & MIMO_F_DEVICE_IN) != 0, dev_out = (flags & MIMO_F_DEVICE_OUT) != 0;
   int rc = bind(ctx); if (rc) return rc;
   if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "mimo_predict: no data resident (call mimo_upload)");
   if (!c || !b || !W || !M || !Q || !Cc || !mu || !covar || K < 1 || (mode != 0 && mode != 1))
@@ -1212,7 +1222,7 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
   const size_t ng = (size_t)K * (1 + dx + (size_t)dx * dx), nM = (size_t)K * dy * dc, nQ = (size_t)K * dc * dc,
                nC = (size_t)K * dy * dy;
   const size_t nparam = ng + nM + nQ + 2 * nC + K;
-  const size_t nout = (size_t)N * (dy + (size_t)dy * dy + 1), nin = want_nlpd ? (size_t)N * dy : 0;
+  const size_t nout = dev_out ? 0 : (size_t)N * (dy + (size_t)dy * dy + 1), nin = (want_nlpd && !dev_in) ? (size_t)N * dy : 0;
   // parameters | outputs | y, all in the staged-weights workspace
   if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, nparam + nout + nin + 1))) return rc;
   std::vector<double> h(nparam);
@@ -1233,16 +1243,30 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
   a.Z = ctx->Z; a.N = N; a.dx = dx; a.dc = dc; a.dy = dy; a.K = K; a.mode = mode;
   a.gate = d; a.M = d + ng; a.Q = a.M + nM; a.Cc = a.Q + nQ; a.P = a.Cc + nC; a.ld = a.P + nC;
   double* out = d + nparam;
-  a.mu = out; a.covar = out + (size_t)N * dy; a.nlpd = want_nlpd ? a.covar + (size_t)N * dy * dy : nullptr;
+  if (dev_out) {
+    a.mu = mu; a.covar = covar; a.nlpd = want_nlpd ? nlpd : nullptr;
+  } else {
+    a.mu = out; a.covar = out + (size_t)N * dy; a.nlpd = want_nlpd ? a.covar + (size_t)N * dy * dy : nullptr;
+  }
   if (want_nlpd) {
-    double* yd = out + nout;
-    HIP_TRY(ctx, hipMemcpyAsync(yd, y, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    a.y = yd;
+    if (dev_in) {
+      a.y = y;
+    } else {
+      double* yd = out + nout;
+      HIP_TRY(ctx, hipMemcpyAsync(yd, y, nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      a.y = yd;
+    }
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // h (pageable) must be consumed before it goes away
   bool unsupported = false;
-  HIP_TRY(ctx, launch_predict(a, ctx->stream, &unsupported));
+  rc = timed_launch(ctx, "predict_kernel", [&]() -> int {
+    HIP_TRY(ctx, launch_predict(a, ctx->stream, &unsupported));
+    return MIMO_OK;
+  });
+  if (rc) return rc;
   if (unsupported) return fail(ctx, MIMO_E_UNSUPPORTED, "mimo_predict: dy=%d (max %d) or dx=%d not supported", dy, kMaxPredictDy, dx);
+  if (ctx->prof) ctx->prof_n += 1;
+  if (dev_out) return MIMO_OK;
   if (N > 0) {
     HIP_TRY(ctx, hipMemcpyAsync(mu, a.mu, (size_t)N * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(covar, a.covar, (size_t)N * dy * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

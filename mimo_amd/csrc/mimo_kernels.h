@@ -68,7 +68,7 @@ inline int diag_feat_index(int D, int a, int b) { return a == D ? 2 * D : (b == 
 inline int lin_feat_count(int D) { return D + 1; }
 inline int lin_feat_pad16(int D) { return (lin_feat_count(D) + 15) / 16 * 16; }
 
-size_t fused_lds_bytes(const KernelArgs& a);
+size_t fused_lds_bytes(const KernelArgs& a, int src);
 int fused_grid(const KernelArgs& a, int num_cu, int src);
 // returns hipSuccess or an error; sets *unsupported when (K, D, src) has no kernel
 hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stream, bool* unsupported);

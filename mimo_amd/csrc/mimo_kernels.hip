@@ -105,7 +105,9 @@ void fused_kernel(const KernelArgs a) {
   double* Lt = Ph + T * a.RS;                    // [T][LS]   l -> e -> r per (row, component)
   double* red = Lt + T * a.LS;                   // [16]      block-reduction scratch
   double* etab = red + 16;                       // [64]      2^(j/64) for exp_nonpos
-  uint8_t* fe = reinterpret_cast<uint8_t*>(etab + 64);  // [F16][2]
+  // Dz >= 14 (E-step modes, one row block per wave): the 2048-entry exp table (mimo_tile.h); else 64 entries
+  constexpr bool E2K = DS >= 14 && RBW == 1 && MODE <= kGeneric;
+  uint8_t* fe = reinterpret_cast<uint8_t*>(etab + (E2K ? kExpTab : 64));  // [F16][2]
   int* labs = reinterpret_cast<int*>(red);       // [32] labels of the tile's rows (red is idle until the epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,7 +122,11 @@ void fused_kernel(const KernelArgs a) {
   // statistics modes may cover only the column blocks [cb0, cb0 + NCB) of a larger feature set
   const uint8_t* featp = a.feat + (SRC == kSrcEstep ? 0 : 32 * a.cb0);
   for (int e = tid; e < F16 * 2; e += kWG) fe[e] = featp[e];
-  if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+  if constexpr (E2K) {
+    for (int e = tid; e < kExpTab; e += kWG) etab[e] = exp_tab_entry_c(e);
+  } else {
+    if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+  }
 
   // Theta in MFMA A-operand layout: lane (i = lane&15, kk = lane>>4) of slice s of row-block rb holds
   // Theta[16 rb + i][4 s + kk]; the image is prepared on the host so each slice is one coalesced
@@ -391,7 +397,7 @@ void fused_kernel(const KernelArgs a) {
       // ---- 4. normalise over k: 8 lanes per datum, 2*K16 consecutive components per lane ----------
       __builtin_amdgcn_s_setprio(2);
       if constexpr (RBW == 1)
-        normalise_tile<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
+        normalise_tile<RBW, MODE, E2K>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp, out_lse,
                                   sc_lse, sc_rl, sc_prod, labs, pbatch, (int64_t)gridDim.x * T);
       else
         normalise_tile_chunked<RBW, MODE>(a, Lt, LS, etab, K, K16, N, n0, wave, lane, gibbs, out_logp, out_resp,
@@ -1058,8 +1064,10 @@ __global__ void unpack_stats(const double* __restrict__ red, const uint8_t* __re
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
-size_t fused_lds_bytes(const KernelArgs& a) {
-  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + 64) + (size_t)a.F16 * 2;
+// (src = kSrcEstep at Dz = 14 .. 16 with K <= 64 on the full map: the instantiations with the 2048-entry exp table, fused_kernel E2K)
+size_t fused_lds_bytes(const KernelArgs& a, int src) {
+  const bool e2k = src == kSrcEstep && !a.diag && a.D >= 14 && a.D <= kMaxFusedD && a.K16 <= 4;
+  return sizeof(double) * ((size_t)kTile * (a.ZS + a.RS + a.LS) + 16 + (e2k ? kExpTab : 64)) + (size_t)a.F16 * 2;
 }
 
 // row blocks per wave: the fused E-step kernels exist for 1 and 4; the statistics modes and the chunked
@@ -1227,7 +1235,7 @@ constexpr int kMaxWGPerCU = 4;
 int fused_grid(const KernelArgs& a, int num_cu, int src) {
   int per_cu = 0;
   if (fused_fn fn = resolve_fused(a, src)) {
-    const size_t lds = fused_lds_bytes(a);
+    const size_t lds = fused_lds_bytes(a, src);
     if (lds <= 160 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) == hipSuccess) {
@@ -1242,7 +1250,7 @@ int fused_grid(const KernelArgs& a, int num_cu, int src) {
     const bool regs2 = rbw_for(a.K16) == 1 || a.F16 / 16 <= 3 || a.K16 <= 8;
     KernelArgs t = a;
     if (t.F16 / 16 > kChunkNCB) { t.F16 = 16 * kChunkNCB; t.RS = t.F16 + 1; }   // per-launch feature tile
-    per_cu = (regs2 && fused_lds_bytes(t) <= 80 * 1024) ? 2 : 1;
+    per_cu = (regs2 && fused_lds_bytes(t, kModeWeights) <= 80 * 1024) ? 2 : 1;
   }
   int cap = kMaxWGPerCU;
   if (const char* e = getenv("MIMO_WG_PER_CU")) cap = atoi(e) > 0 ? atoi(e) : cap;   // tuning knob
@@ -1259,7 +1267,7 @@ hipError_t launch_fused(const KernelArgs& a, int src, int grid, hipStream_t stre
   *unsupported = false;
   fused_fn fn = resolve_fused(a, src);
   if (!fn) { *unsupported = true; return hipSuccess; }
-  const size_t lds = fused_lds_bytes(a);
+  const size_t lds = fused_lds_bytes(a, src);
   if (lds > 160 * 1024) { *unsupported = true; return hipSuccess; }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,6 +1,11 @@
 // Device-side pieces of the tile kernels shared by mimo_kernels.hip and mimo_pipe.hip: the Philox batch of the label draw,
 // the compile-time feature map, the per-datum normalisation of an LDS-resident L tile, the diagnostic phase stamps.
 #pragma once
+// Exponential of the tile kernels' normalise phase: 64-entry table + quintic (exp_nonpos, 15 instructions), or — E2K, the
+// single-pass E-step kernels at Dz >= 14 — the 2048-entry table with the pre-compensated scale (exp_nonpos_t2048c, 12
+// instructions, 16 KB of LDS more per workgroup).  Dz >= 14 runs two workgroups per CU with either table (54 - 64 KB + 16 KB <= 80 KB);
+// below, the larger table costs the third workgroup and more than it gives (measured, round 3: C2 kernel 6.71 -> 6.60 ms with it,
+// C4 — Dz = 12, three workgroups — 2.13 -> 2.24 ms).
 #include "mimo_device.h"
 
 #include <math.h>
@@ -86,7 +91,7 @@ __device__ __forceinline__ void build_features_static(const double (&z)[D + 2], 
 // 8 lanes per datum, 2*K16 consecutive components per lane (<= 8 here: RBW = 1), fully unrolled.
 // Softmax -> r written back in place, or inverse-CDF categorical draw -> label (LDS + HBM).
 // ------------------------------------------------------------------------------------------
-template <int RBW, int MODE>
+template <int RBW, int MODE, bool E2K = false>
 __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __restrict__ Lt, const int LS,
                                                const double* __restrict__ etab, const int K, const int K16,
                                                const int64_t N, const int64_t n0, const int wave, const int lane,
@@ -126,7 +131,7 @@ __device__ __forceinline__ void normalise_tile(const KernelArgs& a, double* __re
           // (a component switched off by c_k = -inf carries l = -1e300: its e is exp(-707) = 8e-308, not 0, and
           // e * l would add -8e-8 per datum to sum_k r l — its term is 0 * (-inf) := 0, like the padding's)
           if constexpr (MODE == kGeneric) lsave[c] = (c < CPP && k0 + c < K && x[c] > kOffLogDensity) ? x[c] : 0.0;
-          x[c] = exp_nonpos(x[c] - m, etab);              // masked / padding slots -> 0
+          x[c] = E2K ? exp_nonpos_t2048c(x[c] - m, etab) : exp_nonpos(x[c] - m, etab);      // masked / padding slots -> 0
         }
         double sel = 0.0;
         if constexpr (MODE == kGeneric) {   // sum_k e l only feeds the entropy split of the ELBO (scalars[1..2])

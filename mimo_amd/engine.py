@@ -501,6 +501,29 @@ class HipEngine:
             _ptr(ld) if y is not None else None, _ptr(mu), _ptr(covar), _ptr(nlpd) if y is not None else None))
         return mu, covar, nlpd
 
+    def predict_device(self, c, b, W, M, Q, Cc, mu_ptr, covar_ptr, affine=True, mode='average', y_ptr=None, P=None, ld=None,
+                       nlpd_ptr=None):
+        """mimo_predict_flags with device pointers for the outputs (and for y): mu (N, dy), covar (N, dy, dy) and nlpd (N) are
+        written on the device — nothing but the K parameter blocks crosses PCIe — and the call returns without waiting; the
+        results are ordered on the engine's stream (set_stream).  Pointers: e.g. torch tensors' data_ptr()."""
+        c, b, W, K = self._params(c, b, W)
+        M, Q, Cc = _f64(M), _f64(Q), _f64(Cc)
+        dy, dc = M.shape[1], self.D + (1 if affine else 0)
+        if M.shape != (K, dy, dc) or Q.shape != (K, dc, dc) or Cc.shape != (K, dy, dy):
+            raise ValueError(f"predictive blocks {M.shape}, {Q.shape}, {Cc.shape} do not match K={K}, dy={dy}, dc={dc}")
+        if mode not in ('average', 'mode'):
+            raise NotImplementedError(mode)
+        with_y = y_ptr is not None
+        if with_y:
+            P, ld = _f64(P), _f64(ld)
+            if P.shape != (K, dy, dy) or ld.shape != (K,) or nlpd_ptr is None:
+                raise ValueError("nlpd needs y, P (K,dy,dy), ld (K,) and an output pointer")
+        self._check(self._lib.mimo_predict_flags(
+            self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(M), _ptr(Q), _ptr(Cc), dy, 1 if affine else 0,
+            0 if mode == 'average' else 1, C.c_void_p(y_ptr) if with_y else None, _ptr(P) if with_y else None,
+            _ptr(ld) if with_y else None, C.c_void_p(mu_ptr), C.c_void_p(covar_ptr), C.c_void_p(nlpd_ptr) if with_y else None,
+            _lib.F_DEVICE_OUT | (_lib.F_DEVICE_IN if with_y else 0)))
+
     # -- copy-outs ------------------------------------------------------------------------
     def get_resp(self, K=None):
         out = np.empty((int(K if K is not None else self._K), self.N))

@@ -92,6 +92,33 @@ def test_predict_kernel_vs_oracle(engine, N, dx, dy, K, affine):
         assert none is None and np.array_equal(mu2, mu) and np.array_equal(covar2, covar)
 
 
+def test_predict_with_device_resident_outputs(engine):
+    """mimo_predict_flags(MIMO_F_DEVICE_IN | MIMO_F_DEVICE_OUT): inputs attached as a device tensor, y and the outputs device tensors —
+    the same numbers as the host-array form, nothing but the parameter blocks crossing PCIe."""
+    import torch
+    from oracle import mimo_oracle as O
+    rng = np.random.default_rng(77)
+    N, dx, dy, K = 5003, 3, 2, 9
+    Z, c, b, W = _random_problem(rng, N, dx, K)
+    dc = dx + 1
+    M = rng.standard_normal((K, dy, dc))
+    A = rng.standard_normal((K, dc, dc)); Q = A @ A.transpose(0, 2, 1) / dc + 0.1 * np.eye(dc)
+    B = rng.standard_normal((K, dy, dy)); Cc = B @ B.transpose(0, 2, 1) / dy + 0.2 * np.eye(dy)
+    P = np.linalg.inv(Cc); ld = np.linalg.slogdet(P)[1]
+    y = rng.standard_normal((N, dy))
+    engine.upload(Z)
+    mu0, cov0, nl0 = engine.predict(c, b, W, M, Q, Cc, y=y, P=P, ld=ld)
+    Zd = torch.from_numpy(Z).cuda()
+    engine.upload(Zd)
+    yd = torch.from_numpy(y).cuda()
+    mu = torch.empty((N, dy), dtype=torch.float64, device="cuda"); cov = torch.empty((N, dy, dy), dtype=torch.float64, device="cuda")
+    nl = torch.empty(N, dtype=torch.float64, device="cuda")
+    engine.predict_device(c, b, W, M, Q, Cc, mu.data_ptr(), cov.data_ptr(), y_ptr=yd.data_ptr(), P=P, ld=ld, nlpd_ptr=nl.data_ptr())
+    engine.estep(c, b, W, stats=False)          # (a synchronous call on the same stream: the prediction before it is done)
+    assert np.array_equal(mu.cpu().numpy(), mu0) and np.array_equal(cov.cpu().numpy(), cov0) and np.array_equal(nl.cpu().numpy(), nl0)
+    engine.upload(Z)
+
+
 def test_predict_rejects_bad_shapes(engine):
     rng = np.random.default_rng(0)
     Z, c, b, W = _random_problem(rng, 64, 2, 3)
