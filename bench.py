@@ -51,6 +51,10 @@ CONFIGS = {
            5_000_000, 12, 64, "ilr"),
     "c5": ("C5: mean-field VB GMM, N=1e7 per GPU, D=32, K=128 (two-stage path: E-step writing the responsibility table + statistics per column group)",
            10_000_000, 32, 128, "vi"),
+    # not a BASELINE config: the shape the reference's own ILR examples default to (examples/ilr/evaluate_sine.py:35: 50 experts over
+    # dx = dy = 1, i.e. Dz = 2) at scale — the narrow kernels on the 4x4x4 matrix instruction
+    "sine": ("ILR defaults of the reference's examples at scale: mixture of 50 linear-Gaussian experts, x in R -> y in R, N=1e7 per GPU, "
+             "mean-field VB", 10_000_000, 2, 50, "ilr"),
 }
 
 
@@ -70,7 +74,7 @@ def make_data(N, D, K, seed, device, ilr=False):
     g.manual_seed(seed)
     Kt = min(K, 32)
     hg = np.random.Generator(np.random.Philox(1337))          # identical centres on every rank
-    dx = 8 if ilr else D
+    dx, dyo = ((8, 4) if D == 12 else (D // 2, D - D // 2)) if ilr else (D, 0)
     centres = torch.tensor(hg.normal(0.0, 6.0, size=(Kt, dx)), device=device)
     A = hg.normal(size=(Kt, dx, dx))
     cov = A @ A.transpose(0, 2, 1) / dx + 0.1 * np.eye(dx)
@@ -79,8 +83,8 @@ def make_data(N, D, K, seed, device, ilr=False):
     X = torch.empty((N, D), dtype=torch.float64, device=device)
     chunk = 1_000_000
     if ilr:
-        Ak = torch.tensor(hg.normal(size=(Kt, 4, dx)) / np.sqrt(dx), device=device)
-        ck = torch.tensor(hg.normal(size=(Kt, 4)), device=device)
+        Ak = torch.tensor(hg.normal(size=(Kt, dyo, dx)) / np.sqrt(dx), device=device)
+        ck = torch.tensor(hg.normal(size=(Kt, dyo)), device=device)
     for s in range(0, N, chunk):
         zz = z[s:s + chunk]
         eps = torch.randn((zz.numel(), dx), dtype=torch.float64, generator=g, device=device)
@@ -88,7 +92,7 @@ def make_data(N, D, K, seed, device, ilr=False):
         X[s:s + chunk, :dx] = x
         if ilr:
             y = torch.einsum('nde,ne->nd', Ak[zz], x) + ck[zz] \
-                + 0.3 * torch.randn((zz.numel(), 4), dtype=torch.float64, generator=g, device=device)
+                + 0.3 * torch.randn((zz.numel(), dyo), dtype=torch.float64, generator=g, device=device)
             X[s:s + chunk, dx:] = y
     return X
 
@@ -106,7 +110,7 @@ def build_model(cfg, engine):
     else:
         gating = CategoricalWithDirichlet(K, Dirichlet(K, np.ones(K)))
     if mode == "ilr":
-        dx, dy = 8, 4
+        dx, dy = (8, 4) if D == 12 else (D // 2, D - D // 2)
         bprior = StackedNormalWisharts(K, dx, np.zeros((K, dx)), 1e-2 * np.ones(K),
                                        np.stack(K * [1e2 * np.eye(dx)]), (dx + 1.) * np.ones(K) + 1e-16)
         basis = StackedGaussiansWithNormalWisharts(K, dx, bprior, engine=engine)

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
 
   for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
   for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
-  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp_tab_entry_c(e);
   wg_sync();
 
   // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < ZI (16 D <= 144 up to Dz = 9, <= 256 up to 16)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     for (int c = 0; c < NCH; ++c) {
       double x[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048(acc[2 * c + (i >> 2)][i & 3] - m, etab);
+      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048c(acc[2 * c + (i >> 2)][i & 3] - m, etab);
 #pragma unroll
       for (int i = 1; i < 8; ++i) x[i] += x[i - 1];
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const Kerne
   const int nch = NSP / NSC;                          // chunks per pass over the image (host: NSP is a multiple of NSC)
   double* Zw = Zall + (size_t)wave * 16 * ZS;
 
-  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp_tab_entry_c(e);
   for (int e = tid; e < NSP * 4; e += kRowWaveWG) {
     const int f = e;                                  // feature 4 s + q; beyond the table: the zero slot of z~
     const uint32_t fa = f < a.F16 ? a.feat[2 * f] : (uint32_t)(D + 1), fb = f < a.F16 ? a.feat[2 * f + 1] : (uint32_t)(D + 1);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const Kerne
     for (int c = 0; c < NCH; ++c) {
       double x[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048(acc[2 * c + (i >> 2)][i & 3] - m, etab);
+      for (int i = 0; i < 8; ++i) x[i] = exp_nonpos_t2048c(acc[2 * c + (i >> 2)][i & 3] - m, etab);
 #pragma unroll
       for (int i = 1; i < 8; ++i) x[i] += x[i - 1];
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void vi_rowwave_kernel(const KernelA
 
   for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
   for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
-  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp_tab_entry_c(e);
   wg_sync();
 
   const int64_t nsteps = (N + 15) / 16;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void vi_rowwave_kernel(const KernelA
     for (int rb = 0; rb < KB; ++rb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[rb][r] = exp_nonpos_t2048(acc[rb][r] - m, etab);
+        acc[rb][r] = exp_nonpos_t2048c(acc[rb][r] - m, etab);
         sv[r] += acc[rb][r];
       }
     double ssum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
@@ -1014,6 +1014,12 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
 // Also new against label_stats_kernel: a row's place in the list is one lookup (per-component prefix of the bitmap's word
 // popcounts) instead of a loop over the words below it; rows on an odd stride read with 8-byte loads; bitmap rows padded off
 // the 64-byte stride that put every component's words into the same banks.
+// What the slot table cannot fix: the labels of a real C3 sweep (tools/c3_label_stats.py) sit on 34 components above 1 % — and on 205
+// more with a handful of rows each, so 239 of the 256 slots are taken before any helper is handed out (369 us with this kernel, 372 us
+// with label_stats_kernel, N = 1e7).  Taking the slots away from components under 1 row in 1024 and adding their rare rows straight
+// into the partial block in global memory was tried: a row costs a dependent L2 round trip per feature there, and the busiest owner
+// thread holds every tile's barrier (4.4 ms).  Those rows need accumulators next to the CU — LDS has no room for 205 x 48 doubles
+// next to the tile — or a sorted second pass; neither is built.
 // Tried and dropped on the way (tools/label_stats_time.py): a kernel that walked the set bits of a component's bitmap
 // directly (no prefix scan, no list): its divergent bit loop cost ~1000 cycles per iteration whatever the body (152 against
 // 87 us, Dz = 8, K = 256, N = 2e6); and 512-thread workgroups over 1024-row tiles with 256 helper slots: indifferent to the

@@ -86,7 +86,7 @@ void small_kernel(const KernelArgs a) {
   double* const out_resp = MODE == kGeneric ? a.resp : nullptr;
   double* const out_lse = MODE == kGeneric ? a.lse : nullptr;
 #if MIMO_SMALL_EXP2048
-  for (int e = tid; e < kExpTab; e += kWG) etab[e] = exp2((double)e * (1.0 / kExpTab));
+  for (int e = tid; e < kExpTab; e += kWG) etab[e] = exp_tab_entry_c(e);
 #else
   if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
 #endif
@@ -185,7 +185,7 @@ void small_kernel(const KernelArgs a) {
       double e[KL];
 #pragma unroll
 #if MIMO_SMALL_EXP2048
-      for (int c = 0; c < KL; ++c) e[c] = exp_nonpos_t2048(l[c] - m, etab);
+      for (int c = 0; c < KL; ++c) e[c] = exp_nonpos_t2048c(l[c] - m, etab);
 #else
       for (int c = 0; c < KL; ++c) e[c] = exp_nonpos(l[c] - m, etab);
 #endif

@@ -26,6 +26,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.log
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_lds.log
 cd $REPO
-python3 tools/summarize_profile.py $OUT $CFG > $OUT/summary.txt 2>&1
+MIMO_PROFILE_TAG=$TAG python3 tools/summarize_profile.py $OUT $CFG > $OUT/summary.txt 2>&1
 tail -1 $OUT/trace_bench.json > $OUT/bench_line.json
 echo "--- $CFG"; head -8 $OUT/summary.txt; tail -2 $OUT/summary.txt
