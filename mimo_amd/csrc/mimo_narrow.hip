@@ -1,7 +1,8 @@
 // gfx950 kernels for the NARROW shapes of the path: few features per component (F = (Dz+1)(Dz+2)/2 <= 16, i.e. Dz <= 4 —
 // or a reduced feature map) with MANY components, 32 < K <= 128 — the shapes the reference's own ILR examples default to
 // (examples/ilr/evaluate_sine.py:35, evaluate_chirp.py:38, evaluate_cmb.py:36, evaluate_step_poly.py:35: 50 experts over
-// dx = dy = 1, i.e. Dz = 2; evaluate_sinc.py:35: 100) — and, with the same code, few components (K <= 16) at any Dz <= 16.
+// dx = dy = 1, i.e. Dz = 2; evaluate_sinc.py:35: 100) — and, with the same code, few components (K <= 16) at any Dz <= 16,
+// K <= 8 up to Dz = 32 (softmax pass).
 //
 // Through the 16-padded v_mfma_f64_16x16x4 tiles such a pass pays for 16 features where 3 .. 15 exist (Dz = 2, K = 64:
 // 20 % of the float64 peak).  Here both products run on v_mfma_f64_4x4x4_4b_f64 (4 blocks of 4 x 4 x 4; measured with
@@ -69,7 +70,8 @@ constexpr int kQuadLast = 0xFF;     // [3, 3, 3, 3]
 #ifdef MIMO_NARROW_FORCE_WAVES
 constexpr int narrow_waves(int, int, int) { return MIMO_NARROW_FORCE_WAVES; }
 #else
-constexpr int narrow_waves(int V, int NSF, int MODE) { return narrow_occ(V, NSF, MODE) & 7; }
+// (the table covers NSF <= 4 — its key does not separate larger NSF; the table-driven loops take what the allocator gives them)
+constexpr int narrow_waves(int V, int NSF, int MODE) { return NSF > 4 ? 1 : narrow_occ(V, NSF, MODE) & 7; }
 #endif
 // ... and which of the two loop bodies: "lean" (bit 3 of the table entry) keeps the exponentials inline and reads the operand
 // factors at the top of a step — fewer live registers, what the large slot counts need; the other one batches the table reads
@@ -472,13 +474,17 @@ typedef void (*narrow_fn)(const KernelArgs);
 
 // instantiated: up to 16 features (NSF <= 4) for Dz <= 4 (ZI = 1: the 16 x Dz <= 64 elements of a step in one load per lane) with
 // every slot count; more features (the table-driven loops) for Dz = 5 .. 16 (ZI = 4) while the V NSF accumulators fit: V NSF <= 96
-constexpr int kNarrowMaxAcc = 96, kNarrowMaxVWide = 8;
+constexpr int kNarrowMaxAcc = 96, kNarrowMaxVWide = 8, kNarrowMaxAccXWide = 200;
 template <int V, int NSF>
 static narrow_fn pick_narrow_mode(int gibbs, int zi) {
   if constexpr (NSF <= 4) {
     if (zi == 1) return gibbs ? narrow_kernel<V, NSF, 1, 1> : narrow_kernel<V, NSF, 0, 1>;
-  } else if constexpr (V <= kNarrowMaxVWide && V * NSF <= kNarrowMaxAcc) {
+  } else if constexpr (NSF <= 39 && V <= kNarrowMaxVWide && V * NSF <= kNarrowMaxAcc) {
     if (zi == 4) return gibbs ? narrow_kernel<V, NSF, 1, 4> : narrow_kernel<V, NSF, 0, 4>;
+  } else if constexpr (NSF > 39 && V <= 2 && V * NSF <= kNarrowMaxAccXWide) {
+    // Dz = 17 .. 32 (ZI = 8), softmax + statistics pass with K <= 8: one wave per SIMD, the accumulators take the second
+    // half of the unified register file (a label pass with so few components has no label-statistics kernel behind it)
+    if (zi == 8 && !gibbs) return narrow_kernel<V, NSF, 0, 8>;
   }
   return nullptr;
 }
@@ -490,6 +496,9 @@ static narrow_fn pick_narrow_nsf(int nsf, int gibbs, int zi) {
     // ceil(F / 4) of the full maps of Dz = 5 .. 16 (F = 21 .. 153) and of the reduced maps beyond 16 features
     MIMO_NN(5) MIMO_NN(6) MIMO_NN(7) MIMO_NN(8) MIMO_NN(9) MIMO_NN(12) MIMO_NN(14) MIMO_NN(17) MIMO_NN(20) MIMO_NN(23)
     MIMO_NN(27) MIMO_NN(30) MIMO_NN(34) MIMO_NN(39)
+    // Dz = 17 .. 32 (F = 171 .. 561)
+    MIMO_NN(43) MIMO_NN(48) MIMO_NN(53) MIMO_NN(58) MIMO_NN(64) MIMO_NN(69) MIMO_NN(75) MIMO_NN(82) MIMO_NN(88) MIMO_NN(95)
+    MIMO_NN(102) MIMO_NN(109) MIMO_NN(117) MIMO_NN(124) MIMO_NN(132) MIMO_NN(141)
 #undef MIMO_NN
   }
   return nullptr;
@@ -504,7 +513,7 @@ static narrow_fn pick_narrow(int V, int nsf, int gibbs, int zi) {
   return nullptr;
 }
 
-static int narrow_zi(int D) { return 16 * D <= 64 ? 1 : 4; }
+static int narrow_zi(int D) { return 16 * D <= 64 ? 1 : D <= 16 ? 4 : 8; }
 
 // Which (K, feature count F, Dz) the narrow kernels take (full structure or a reduced map alike: they read the feature
 // table).  MIMO_NARROW=0 switches the route off, MIMO_NARROW_MIN_K / MIMO_NARROW_MAX_K move its K range (tuning knobs).
@@ -519,8 +528,10 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
     // measured against the row-owner / tile kernels (tools/wide_sweep.py, N = 2e6, profiles/r03_wide_sweep.txt): K <= 16 wins wherever
     // the accumulators fit (Dz = 8: K = 4 276 -> 96 us, K = 16 271 -> 193; Dz = 16: K = 4 629 -> 256, K = 8 625 -> 349), K = 24 up
     // to Dz = 8 (248 against 274 us), K = 32 no longer (Dz = 8: 351 against 268)
-    const int kmax_w = wide_kmax > 0 ? wide_kmax : (D <= 8 ? 24 : 16);
-    if (!wide_on || K < 1 || K > kmax_w || D < 5 || D > 16) return false;
+    // Dz = 17 .. 32 (profiles/r03_wide_sweep_dz17_32.txt, against the two-stage tile kernels that pay for 16 components): K <= 4
+    // Dz=17 1514 -> 290 us, Dz=24 2253 -> 538, Dz=32 3095 -> 1525 (one wave per SIMD from Dz = 26); K = 8 Dz=20 1633 -> 632, Dz=26 2304 -> 1219
+    const int kmax_w = wide_kmax > 0 ? wide_kmax : (D <= 8 ? 24 : D <= 16 ? 16 : 8);
+    if (!wide_on || K < 1 || K > kmax_w || D < 5 || D > 32 || (D > 16 && gibbs)) return false;
   } else if (K < kmin || K > kmax || K > 128 || D > 4) {
     return false;
   }

@@ -235,10 +235,17 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
 // L2 -> LDS traffic: the whole image per 128 rows (Dz = 16, K = 256: 2.5 KB per row, 25 GB per 1e7 rows — a quarter of the
 // pass's matrix time at the 10 TB/s the L2s deliver, and hidden under it).
 // ------------------------------------------------------------------------------------------
+#ifndef MIMO_STREAM_TAIL
+// 0: all padded steps computed, 1: a (wave-uniform) guard per step, 2: the guarded loop for a partial last chunk only.  One box,
+// N = 2e6, label pass + statistics in us (profiles/r03_stream_tail_variants.txt), variants 0 / 1 / 2: Dz=16, K=128 1924 / 1746 / 1807;
+// Dz=20, K=64 1653 / 1521 / 1549; Dz=24, K=64 2143 / 2020 / 2071; Dz=16, K=256 3381 / 3278 / 6364 (the two loop bodies of variant 2
+// spill there); shapes without padding Dz=32, K=128 6232 / 6180 / 6476, Dz=12, K=192 1992 / 2050 / 2184
+#define MIMO_STREAM_TAIL 1
+#endif
 constexpr int stream_nsc(int KB) { return KB <= 2 ? 48 : KB <= 4 ? 24 : KB <= 6 ? 16 : KB <= 8 ? 12 : KB <= 14 ? 8 : 6; }   // (NSC KB: a multiple of 16)
 
 template <int KB, int ZI>
-__global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const KernelArgs a, int NSP) {
+__global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const KernelArgs a, int NSP, int NS) {
   constexpr int V = 4 * KB, NCH = KB / 2, NSC = stream_nsc(KB);
   constexpr int CH = NSC * KB * 64;                   // doubles per chunk
   constexpr int NLD = CH / (2 * kRowWaveWG);          // 16-byte loads per thread and chunk
@@ -330,19 +337,33 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_stream_kernel(const Kerne
 #pragma unroll
       for (int e = 0; e < PF; ++e) ring[e] = bc[e * 64];
       const int s0 = c * NSC;
+      // steps of this chunk that carry features (wave-uniform): the image is padded to whole chunks with zero rows, and the
+      // products of the padding — up to a fifth of the pass at Dz = 16, K = 96 / 128 or Dz = 20, K = 64 — are skipped
+      const int lim = NS - s0;
       double bq = feature(s0);
+      auto products = [&](auto guarded) {
 #pragma unroll
-      for (int s2 = 0; s2 < NSC; ++s2) {
-        const double bcur = bq;
-        if (s2 + 1 < NSC) bq = feature(s0 + s2 + 1);
+        for (int s2 = 0; s2 < NSC; ++s2) {
+          if (!decltype(guarded)::value || s2 < lim) {
+            const double bcur = bq;
+            if (s2 + 1 < NSC) bq = feature(s0 + s2 + 1);
 #pragma unroll
-        for (int rb = 0; rb < KB; ++rb) {
-          const int e = s2 * KB + rb;
-          const double av = ring[e % PF];
-          if (e + PF < NSC * KB) ring[e % PF] = bc[(e + PF) * 64];
-          acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < KB; ++rb) {
+              const int e = s2 * KB + rb;
+              const double av = ring[e % PF];
+              if (e + PF < NSC * KB) ring[e % PF] = bc[(e + PF) * 64];
+              acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
+            }
+          }
         }
-      }
+      };
+#if MIMO_STREAM_TAIL == 0
+      products(std::false_type{});
+#elif MIMO_STREAM_TAIL == 1
+      products(std::true_type{});
+#else
+      if (lim >= NSC) products(std::false_type{}); else products(std::true_type{});
+#endif
       {
         d2* dst = reinterpret_cast<d2*>(buf + ((gc + 1) & 1) * CH) + tid;
 #pragma unroll
@@ -508,7 +529,7 @@ int rowwave_grid(const KernelArgs& a, int num_cu) {
   return (int)(g < 1 ? 1 : g);
 }
 
-typedef void (*stream_fn)(const KernelArgs, int);
+typedef void (*stream_fn)(const KernelArgs, int, int);
 template <int ZI>
 static stream_fn pick_stream(int kb) {
   switch (kb) {
@@ -531,7 +552,7 @@ hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t strea
     const int64_t need = (a.N + 127) / 128;
     int g = grid;
     if (g > need) g = (int)(need < 1 ? 1 : need);
-    hipLaunchKernelGGL(fn, dim3(g), dim3(kRowWaveWG), lds, stream, a, stream_ns_pad(kb, a.F16));
+    hipLaunchKernelGGL(fn, dim3(g), dim3(kRowWaveWG), lds, stream, a, stream_ns_pad(kb, a.F16), a.F16 / 4);
     return hipGetLastError();
   }
   const int kb = rowwave_kb(a.K);

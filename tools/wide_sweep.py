@@ -5,14 +5,14 @@ import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-Ds = (5, 6, 8, 10, 12, 14, 16)
-Ks = (1, 2, 4, 8, 12, 16, 24, 32)
+Ds = tuple(int(x) for x in os.environ.get("WIDE_SWEEP_DS", "5,6,8,10,12,14,16").split(","))
+Ks = tuple(int(x) for x in os.environ.get("WIDE_SWEEP_KS", "1,2,4,8,12,16,24,32").split(","))
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     from mimo_amd.engine import HipEngine
     N = int(float(sys.argv[1]))
     eng = HipEngine(0)
     rng = np.random.default_rng(0)
-    for mode in ("vi", "gibbs"):
+    for mode in os.environ.get("WIDE_SWEEP_MODES", "vi,gibbs").split(","):
         print(f"{mode} narrow_wide={os.environ.get('MIMO_NARROW_WIDE', '1')} max_k={os.environ.get('MIMO_NARROW_WIDE_MAX_K', 'default')}: us per pass / route (N = {N}); rows Dz, columns K = {Ks}")
         for D in Ds:
             Z = rng.standard_normal((N, D)); eng.upload(Z)
