@@ -376,8 +376,19 @@ static bool use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain) {
 
 // Theta image of the narrow kernels: [NSF][V][16]; slice s V + c, entry 4 kk + j = Theta[component j V + c][feature 4 s + kk]
 // (an output lane holds a contiguous quarter of the components: narrow_kernel)
-static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, NSF = narrow_nsf(ctx->F), V = narrow_v(K);
+// Grouped variant (narrow_dt): the steps follow the rows of the upper triangle, feature (a, b) at narrow_group_pos.
+static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, bool gibbs) {
+  const int D = ctx->D, dt = narrow_dt(K, ctx->F, D, gibbs ? 1 : 0), NSF = narrow_steps(K, ctx->F, D, gibbs ? 1 : 0), V = narrow_v(K);
+  std::vector<int> gpos;                // grouped: 4 step + index of every feature of the full map
+  if (dt) {
+    gpos.assign((size_t)ctx->F, 0);
+    for (int aa = 0; aa <= D; ++aa)
+      for (int bb = aa; bb <= D; ++bb) {
+        int st, j;
+        narrow_group_pos(D, aa, bb, &st, &j);
+        gpos[feat_index(D, aa, bb)] = 4 * st + j;
+      }
+  }
   const size_t count = (size_t)NSF * V * 16;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
@@ -388,7 +399,8 @@ static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, 
   bool finite = true;
   auto put = [&](int k, int f, double v) {
     finite = finite && std::fabs(v) <= 1.7976931348623157e308;
-    img[((size_t)(f / 4) * V + k % V) * 16 + 4 * (f % 4) + k / V] = v;
+    const int g = dt ? gpos[f] : f;
+    img[((size_t)(g / 4) * V + k % V) * 16 + 4 * (g % 4) + k / V] = v;
   };
   for (int k = 0; k < K; ++k) {
     const double* bk = b + (size_t)k * D;
@@ -957,7 +969,7 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
   const bool nv = use_narrow(ctx, K, false, plain);      // narrow shapes (Dz <= 4, 32 < K <= 128): mimo_narrow.hip
   const bool rv = !nv && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
-  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, false) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
   ctx->narrow_call = nv ? 1 : 0;
@@ -1049,7 +1061,7 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
   const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
   const bool nw = use_narrow(ctx, K, true, !wants_tables);
   const bool rw = !nw && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
-  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, true) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_call = rw;
   ctx->narrow_call = nw ? 2 : 0;

@@ -47,6 +47,11 @@ hipError_t launch_vi_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
 int narrow_v(int K);                 // component slots per lane (4 V >= K), 0: not instantiated
 int narrow_nsf(int F);               // contraction steps: ceil(F / 4)
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs);
+// the grouped variant (full feature map, Dz = 5 .. 32; rows of the upper triangle padded to whole steps): Dz if it serves the
+// shape, else 0; contraction steps of the image either way; position of feature (a, b) in the grouped order
+int narrow_dt(int K, int F, int D, int gibbs);
+int narrow_steps(int K, int F, int D, int gibbs);
+void narrow_group_pos(int D, int a, int b, int* step, int* j);
 int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs);
 hipError_t launch_narrow(const KernelArgs& a, int F, int gibbs, int grid, hipStream_t stream);
 

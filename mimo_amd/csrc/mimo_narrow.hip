@@ -42,6 +42,9 @@ constexpr int kNarrowPF = MIMO_NARROW_PF;        // Theta slices in flight
 #ifndef MIMO_NARROW_EB
 #define MIMO_NARROW_EB 8
 #endif
+#ifndef MIMO_NARROW_CHAINS
+#define MIMO_NARROW_CHAINS 0     // 0: four chains for one slot over >= 64 steps, else one; 1, 2, 4: forced (tuning builds)
+#endif
 constexpr int kNarrowEB = MIMO_NARROW_EB;   // exponentials (table reads) in flight
 
 namespace {
@@ -82,8 +85,29 @@ constexpr bool narrow_lean(int, int, int) { return MIMO_NARROW_FORCE_LEAN != 0; 
 constexpr bool narrow_lean(int V, int NSF, int MODE) { return NSF > 4 || (narrow_occ(V, NSF, MODE) & 8) != 0; }
 #endif
 
-template <int V, int NSF, int MODE, int ZI>   // MODE 0: softmax + statistics (fast mean-field / EM pass), 1: label draw
+// The GROUPED feature order of the Dz-templated variant (DT = Dz >= 5, full map): row a of the upper triangle of z~ z~' —
+// the pairs (a, a), (a, a + 1), .., (a, Dz) — padded to whole steps of four, so that a step is (a, b0) and the lane's feature of
+// it is z~[a] z~[b0 + j], j = its index inside the step.  A lane then keeps TWO register copies of its row — z~[i] and the copy
+// shifted by j, z~[i + j] (slots Dz + 1 .. Dz + 3 of the row are zero) — and every operand of both products is one
+// register-register product with compile-time indices: 2 (Dz + 2) LDS reads per product and 16-row step instead of the ~2.5 per
+// matrix instruction of the table-driven loops (which are bound by exactly that: LDS bandwidth, 56 - 64 cycles per step at V = 1).
+template <int D>
+struct NarrowGroup {
+  static constexpr int nst() { int n = 0; for (int r = 0; r <= D; ++r) n += (D + 1 - r + 3) / 4; return n; }
+  int a[nst() > 0 ? nst() : 1], b0[nst() > 0 ? nst() : 1];
+  constexpr NarrowGroup() : a{}, b0{} {
+    int s = 0;
+    for (int r = 0; r <= D; ++r)
+      for (int b = r; b <= D; b += 4) { a[s] = r; b0[s] = b; ++s; }
+  }
+};
+constexpr int narrow_group_steps(int D) { int n = 0; for (int r = 0; r <= D; ++r) n += (D + 1 - r + 3) / 4; return n; }
+constexpr int narrow_group_zs(int D) { return (D + 4) | 1; }      // row stride of the grouped variant: z, 1, three zero slots
+
+template <int V, int NSF, int MODE, int ZI, int DT = 0>   // MODE 0: softmax + statistics (fast mean-field / EM pass), 1: label draw
 __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_kernel(const KernelArgs a) {
+  static_assert(DT == 0 || (DT >= 5 && NSF == narrow_group_steps(DT)), "grouped variant: NSF = steps of the grouped order");
+  constexpr NarrowGroup<DT> GR{};
   constexpr bool LEAN = narrow_lean(V, NSF, MODE);
   // NSF > 4 (more than 16 features: Dz >= 5, few components): the operand factors of a step come from a small LDS table of
   // packed byte offsets inside the step loops instead of 4 NSF address registers and 2 NSF operand registers
@@ -91,7 +115,7 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   constexpr int NP = FT ? 1 : NSF;
   constexpr int EB = LEAN ? 1 : kNarrowEB;                    // exponentials per batch (1: inline, hipcc schedules them)
   extern __shared__ __align__(16) unsigned char smem[];
-  const int ZS = a.ZS;
+  const int ZS = DT ? narrow_group_zs(DT) : a.ZS;
   double* Th = reinterpret_cast<double*>(smem);               // [NSF V + PF][16]
   double* etab = Th + (size_t)(NSF * V + kNarrowPF) * 16;     // [kExpTab]; the epilogue's scratch aliases it
   double* Zall = etab + kExpTab;                              // [4 waves][16][ZS]
@@ -108,8 +132,10 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   for (int e = tid; e < NSF * V * 16; e += kNarrowWG) Th[e] = a.theta[e];
   for (int e = tid; e < kNarrowPF * 16; e += kNarrowWG) Th[NSF * V * 16 + e] = 0.0;
   for (int e = tid; e < kExpTab; e += kNarrowWG) etab[e] = exp_tab_entry_c(e);
-  if constexpr (FT)
+  if constexpr (FT && DT == 0)
     for (int e = tid; e < 4 * NSF; e += kNarrowWG) ftab[e] = 8u * a.feat[2 * e] | (8u * a.feat[2 * e + 1]) << 16;
+  if constexpr (DT > 0)                        // the zero slots behind [z, 1] (slot Dz + 1 is rewritten with every step)
+    if (tid < 64) { Zall[(size_t)tid * ZS + DT + 2] = 0.0; Zall[(size_t)tid * ZS + DT + 3] = 0.0; }
   wg_sync();
 
   const int64_t nsteps = (N + 15) / 16;
@@ -232,16 +258,34 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
     double acc[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[c] = 0.0;
+    // one slot and many steps: its products would form ONE dependent chain of NSF matrix instructions — split in four (measured,
+    // N = 2e6, one / four chains: Dz=20 409 / 387 us, Dz=32 841 / 771 us; shorter chains and two slots: no difference or slower)
+    constexpr int NCHAIN = !FT ? 1 : MIMO_NARROW_CHAINS > 0 ? MIMO_NARROW_CHAINS : (V == 1 && NSF >= 64) ? 4 : 1;
+    double accx[V][NCHAIN > 1 ? NCHAIN - 1 : 1];
+    if constexpr (NCHAIN > 1) {
+#pragma unroll
+      for (int c = 0; c < V; ++c)
+#pragma unroll
+        for (int p = 0; p < NCHAIN - 1; ++p) accx[c][p] = 0.0;
+    }
     {
       double ring[kNarrowPF];
 #pragma unroll
       for (int e = 0; e < kNarrowPF; ++e) ring[e] = thl[e * 16];
       double aq = 0.0;
-      if constexpr (FT) aq = feat0(0);
+      if constexpr (FT && DT == 0) aq = feat0(0);
+      double zA[DT + 1], zS[DT + 1];                       // grouped: the lane's row and its copy shifted by hi
+      if constexpr (DT > 0) {
+        const double* r0h = row0 + hi;
+#pragma unroll
+        for (int i = 0; i <= DT; ++i) { zA[i] = row0[i]; zS[i] = r0h[i]; }
+      }
 #pragma unroll
       for (int s = 0; s < NSF; ++s) {
         double acur;
-        if constexpr (FT) {
+        if constexpr (DT > 0) {
+          acur = zA[GR.a[s]] * zS[GR.b0[s]];
+        } else if constexpr (FT) {
           acur = aq;
           if (s + 1 < NSF) aq = feat0(s + 1);        // (one step ahead: the LDS round trip hides under this step's products)
         } else {
@@ -252,8 +296,18 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
           const int e = s * V + c;
           const double tv = ring[e % kNarrowPF];
           if (!(MIMO_NARROW_WHATIF & 2)) ring[e % kNarrowPF] = thl[(e + kNarrowPF) * 16];     // (the last reads take the zero slices behind the image)
-          acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(acur, tv, acc[c], 0, 0, 0);
+          if (NCHAIN > 1 && s % NCHAIN != 0)
+            accx[c][s % NCHAIN - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(acur, tv, accx[c][s % NCHAIN - 1], 0, 0, 0);
+          else
+            acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(acur, tv, acc[c], 0, 0, 0);
         }
+      }
+    }
+    if constexpr (NCHAIN > 1) {
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        if constexpr (NCHAIN == 2) acc[c] += accx[c][0];
+        else if constexpr (NCHAIN == 4) acc[c] = (acc[c] + accx[c][0]) + (accx[c][1] + accx[c][2]);
       }
     }
 
@@ -312,11 +366,21 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       }
       // ---- S += R' . Phi ------------------------------------------------------------------------------------
       double bq = 0.0;
-      if constexpr (FT) bq = feat1(0) * inv;
+      if constexpr (FT && DT == 0) bq = feat1(0) * inv;
+      double zB[DT + 1], zT[DT + 1];                       // grouped: row 4 b + hi and its copy shifted by lo
+      if constexpr (DT > 0) {
+        const double* r1l = row1 + lo;
+#pragma unroll
+        for (int i = 0; i <= DT; ++i) { zB[i] = row1[i]; zT[i] = r1l[i]; }
+#pragma unroll
+        for (int c = 0; c < V; ++c) acc[c] *= inv;          // (V products instead of one per feature step)
+      }
 #pragma unroll
       for (int s = 0; s < NSF; ++s) {
         double bcur;
-        if constexpr (FT) {
+        if constexpr (DT > 0) {
+          bcur = zB[GR.a[s]] * zT[GR.b0[s]];
+        } else if constexpr (FT) {
           bcur = bq;
           if (s + 1 < NSF) bq = feat1(s + 1) * inv;
         } else {
@@ -418,7 +482,7 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
     // rows / columns of the block this kernel has no accumulator for
     for (int e = tid; e < Kpad * FT; e += kNarrowWG) {
       const int k = e / FT, f = e - k * FT;
-      if (k >= 4 * V || f >= 4 * NSF) P[e] = 0.0;
+      if (k >= 4 * V || f >= (DT ? (DT + 1) * (DT + 2) / 2 : 4 * NSF)) P[e] = 0.0;
     }
 #pragma unroll
     for (int g0 = 0; g0 < NACC; g0 += GB) {
@@ -436,7 +500,14 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
           for (int w = 0; w < 4; ++w)
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) tot += red[(i * 4 + w) * 64 + 16 * ci + 4 * bb + fj];
-          const int k = ci * V + c, f = 4 * s + fj;
+          const int k = ci * V + c;
+          int f = 4 * s + fj;
+          if constexpr (DT > 0) {            // step s of the grouped order = (row r, first column b0): feature (r, b0 + fj) or padding
+            int r = 0, s0 = 0;
+            while (s0 + (DT + 1 - r + 3) / 4 <= s) { s0 += (DT + 1 - r + 3) / 4; ++r; }
+            const int col = r + 4 * (s - s0) + fj;
+            f = col <= DT ? r * (DT + 1) - r * (r - 1) / 2 + (col - r) : FT;
+          }
           if (k < Kpad && f < FT) P[(size_t)k * FT + f] = k < K ? tot : 0.0;
         }
       }
@@ -515,6 +586,67 @@ static narrow_fn pick_narrow(int V, int nsf, int gibbs, int zi) {
 
 static int narrow_zi(int D) { return 16 * D <= 64 ? 1 : D <= 16 ? 4 : 8; }
 
+// ---- the grouped (Dz-templated) variant: full feature map, Dz = 5 .. 32 ------------------------------------------------
+// instantiated while the V x steps accumulators fit the unified register file of one wave per SIMD; the label pass for the
+// shapes whose labels have a label-statistics kernel behind them (Dz <= 16)
+constexpr int kNarrowGroupMaxAcc = 200;
+template <int D, int V>
+static narrow_fn pick_narrow_dt_mode(int gibbs) {
+  constexpr int NST = narrow_group_steps(D), ZI = D <= 16 ? 4 : 8;
+  if (gibbs) {
+    if constexpr (D <= 16) return narrow_kernel<V, NST, 1, ZI, D>;
+  } else {
+    if constexpr (V * NST <= kNarrowGroupMaxAcc) return narrow_kernel<V, NST, 0, ZI, D>;
+  }
+  return nullptr;
+}
+template <int D>
+static narrow_fn pick_narrow_dt_v(int V, int gibbs) {
+  switch (V) {
+    case 1: return pick_narrow_dt_mode<D, 1>(gibbs);
+    case 2: return pick_narrow_dt_mode<D, 2>(gibbs);
+    case 3: if constexpr (D <= 16) return pick_narrow_dt_mode<D, 3>(gibbs); else return nullptr;
+    case 4: if constexpr (D <= 16) return pick_narrow_dt_mode<D, 4>(gibbs); else return nullptr;
+    case 6: if constexpr (D <= 8) return pick_narrow_dt_mode<D, 6>(gibbs); else return nullptr;
+  }
+  return nullptr;
+}
+static narrow_fn pick_narrow_dt(int V, int D, int gibbs) {
+  switch (D) {
+#define MIMO_ND(d) case d: return pick_narrow_dt_v<d>(V, gibbs);
+    MIMO_ND(5) MIMO_ND(6) MIMO_ND(7) MIMO_ND(8) MIMO_ND(9) MIMO_ND(10) MIMO_ND(11) MIMO_ND(12) MIMO_ND(13) MIMO_ND(14) MIMO_ND(15) MIMO_ND(16)
+    MIMO_ND(17) MIMO_ND(18) MIMO_ND(19) MIMO_ND(20) MIMO_ND(21) MIMO_ND(22) MIMO_ND(23) MIMO_ND(24) MIMO_ND(25) MIMO_ND(26) MIMO_ND(27)
+    MIMO_ND(28) MIMO_ND(29) MIMO_ND(30) MIMO_ND(31) MIMO_ND(32)
+#undef MIMO_ND
+  }
+  return nullptr;
+}
+// Dz if the grouped variant serves (K, F, Dz), else 0 (MIMO_NARROW_GROUPED=0: off; MIMO_NARROW_GROUPED_MIN_D / _MAX_D: tuning knobs)
+int narrow_dt(int K, int F, int D, int gibbs) {
+  static const bool on = [] { const char* e = getenv("MIMO_NARROW_GROUPED"); return !e || atoi(e) != 0; }();
+  static const int dmin = [] { const char* e = getenv("MIMO_NARROW_GROUPED_MIN_D"); return e ? atoi(e) : 5; }();
+  static const int dmax = [] { const char* e = getenv("MIMO_NARROW_GROUPED_MAX_D"); return e ? atoi(e) : 32; }();
+  if (!on || D < 5 || D > 32 || D < dmin || D > dmax || F != (D + 1) * (D + 2) / 2) return 0;
+  const int V = narrow_v(K);
+  if (!V || !pick_narrow_dt(V, D, gibbs)) return 0;
+  // against the table-driven loops where both exist (profiles/r03_wide_sweep_grouped.txt, N = 2e6, us per pass, table / grouped):
+  // softmax pass Dz=8 K=4 95 / 86, K=12 155 / 162, K=24 249 / 302; Dz=12 K=4 159 / 133, K=8 235 / 201, K=12 279 / 316; Dz=16 K=4
+  // 258 / 205; Dz=24 K=8 1108 / 857; Dz=32 K=4 1552 / 840; Dz=5, 6: table-driven (a third more steps after the padding);
+  // label pass: Dz=16 K=4 297 / 256, Dz=12 K=4 217 / 202, below that no difference
+  static const bool always = [] { const char* e = getenv("MIMO_NARROW_GROUPED"); return e && atoi(e) == 2; }();
+  const bool prefer = gibbs ? D >= 12 : (D >= 13 || (V <= 2 && D >= 7));
+  if (!prefer && !always && pick_narrow(V, narrow_nsf(F), gibbs, narrow_zi(D))) return 0;
+  return D;
+}
+int narrow_steps(int K, int F, int D, int gibbs) { return narrow_dt(K, F, D, gibbs) ? narrow_group_steps(D) : narrow_nsf(F); }
+// position of feature (a, b), a <= b <= D, in the grouped order: step and index inside the step
+void narrow_group_pos(int D, int a, int b, int* step, int* j) {
+  int s0 = 0;
+  for (int r = 0; r < a; ++r) s0 += (D + 1 - r + 3) / 4;
+  *step = s0 + (b - a) / 4;
+  *j = (b - a) % 4;
+}
+
 // Which (K, feature count F, Dz) the narrow kernels take (full structure or a reduced map alike: they read the feature
 // table).  MIMO_NARROW=0 switches the route off, MIMO_NARROW_MIN_K / MIMO_NARROW_MAX_K move its K range (tuning knobs).
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
@@ -535,17 +667,21 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   } else if (K < kmin || K > kmax || K > 128 || D > 4) {
     return false;
   }
-  const int V = narrow_v(K), nsf = narrow_nsf(F);
-  if (!V || !pick_narrow(V, nsf, gibbs, narrow_zi(D))) return false;
+  const int V = narrow_v(K);
+  if (!V) return false;
+  if (narrow_dt(K, F, D, gibbs)) return narrow_lds_bytes(V, narrow_group_steps(D), narrow_group_zs(D)) <= 64 * 1024;
+  const int nsf = narrow_nsf(F);
+  if (!pick_narrow(V, nsf, gibbs, narrow_zi(D))) return false;
   return narrow_lds_bytes(V, nsf, ZS) <= 64 * 1024;
 }
 
 int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs) {
-  const int V = narrow_v(a.K), nsf = narrow_nsf(F);
+  const int dt = narrow_dt(a.K, F, a.D, gibbs);
+  const int V = narrow_v(a.K), nsf = dt ? narrow_group_steps(dt) : narrow_nsf(F);
   int per_cu = narrow_waves(V, nsf, gibbs ? 1 : 0);
-  if (narrow_fn fn = pick_narrow(V, nsf, gibbs, narrow_zi(a.D))) {
+  if (narrow_fn fn = dt ? pick_narrow_dt(V, dt, gibbs) : pick_narrow(V, nsf, gibbs, narrow_zi(a.D))) {
     int nb = 0;
-    const size_t lds = narrow_lds_bytes(V, nsf, a.ZS);
+    const size_t lds = narrow_lds_bytes(V, nsf, dt ? narrow_group_zs(dt) : a.ZS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), kNarrowWG, lds) == hipSuccess && nb > 0)
       per_cu = nb;
@@ -559,10 +695,11 @@ int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs) {
 }
 
 hipError_t launch_narrow(const KernelArgs& a, int F, int gibbs, int grid, hipStream_t stream) {
-  const int V = narrow_v(a.K), nsf = narrow_nsf(F);
-  narrow_fn fn = pick_narrow(V, nsf, gibbs, narrow_zi(a.D));
+  const int dt = narrow_dt(a.K, F, a.D, gibbs);
+  const int V = narrow_v(a.K), nsf = dt ? narrow_group_steps(dt) : narrow_nsf(F);
+  narrow_fn fn = dt ? pick_narrow_dt(V, dt, gibbs) : pick_narrow(V, nsf, gibbs, narrow_zi(a.D));
   if (!fn || 4 * V < a.K || 16 * a.D > 64 * narrow_zi(a.D)) return hipErrorInvalidValue;
-  const size_t lds = narrow_lds_bytes(V, nsf, a.ZS);
+  const size_t lds = narrow_lds_bytes(V, nsf, dt ? narrow_group_zs(dt) : a.ZS);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kNarrowWG), lds, stream, a);
