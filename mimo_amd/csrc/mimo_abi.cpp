@@ -83,7 +83,7 @@ struct mimo_ctx {
   int comm_world = 1;
   bool rowwave_vi_call = false; // set by mimo_estep for the call in progress: row-owner softmax + statistics kernel
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
-  int narrow_call = 0;          // set for the call in progress: Theta is in the narrow image (1: softmax + statistics pass, 2: label pass)
+  int narrow_call = 0;          // set for the call in progress: Theta is in the narrow image (1: softmax + statistics pass, 2: label pass, 3: label pass + statistics fused)
 
   // pending asynchronous call (MIMO_F_ASYNC)
   bool pending_async = false;
@@ -367,18 +367,29 @@ static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b,
 
 // Passes of the narrow shapes (mimo_narrow.hip: F <= 16 features, 32 < K <= 128 on the 4x4x4 matrix instruction): plain
 // requests only — nothing but statistics + scalars (softmax pass) or labels + their statistics (label pass).
-static bool use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain) {
-  if (!plain || use_small(ctx, K)) return false;
+// Returns the kernel mode + 1 (1: softmax + statistics, 2: label draw with the label-statistics kernel behind it, 3: label draw +
+// statistics in one pass — few components over many features, MIMO_NARROW_FUSED_LABELS=0: off) or 0.
+static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool stats = true) {
+  static const bool fused_labels = [] { const char* e = getenv("MIMO_NARROW_FUSED_LABELS"); return !e || atoi(e) != 0; }();
+  if (!plain || use_small(ctx, K)) return 0;
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
-  if (!narrow_covers(K, ctx->F, ctx->D, ZS, gibbs ? 1 : 0)) return false;
-  return gibbs ? label_stats_covers(K, ctx->D, ctx->structure) : ctx->n_bad == 0;
+  if (!gibbs) return narrow_covers(K, ctx->F, ctx->D, ZS, 0) && ctx->n_bad == 0 ? 1 : 0;
+  const bool two = narrow_covers(K, ctx->F, ctx->D, ZS, 1) && label_stats_covers(K, ctx->D, ctx->structure);
+  const bool one = fused_labels && ctx->n_bad == 0 && narrow_covers(K, ctx->F, ctx->D, ZS, 2);
+  if (one && !two) return 3;
+  // both exist: the fused pass wins while its second product is cheap next to a second pass over Z (profiles/r03_wide_sweep_fused_labels.txt,
+  // N = 2e6, us per sweep, label kernel + label statistics / fused: Dz=8 K=4 154 / 93, K=8 154 / 129, K=16 181 / 194; Dz=12 K=8 237 / 208,
+  // K=16 312 / 395; Dz=16 K=4 256 / 213, K=8 315 / 374, K=16 430 / 649)
+  const int V = narrow_v(K), D = ctx->D;
+  if (one && stats && (V == 1 || D <= 6 || (D <= 12 && V <= 3))) return 3;
+  return two ? 2 : 0;
 }
 
 // Theta image of the narrow kernels: [NSF][V][16]; slice s V + c, entry 4 kk + j = Theta[component j V + c][feature 4 s + kk]
 // (an output lane holds a contiguous quarter of the components: narrow_kernel)
 // Grouped variant (narrow_dt): the steps follow the rows of the upper triangle, feature (a, b) at narrow_group_pos.
-static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, bool gibbs) {
-  const int D = ctx->D, dt = narrow_dt(K, ctx->F, D, gibbs ? 1 : 0), NSF = narrow_steps(K, ctx->F, D, gibbs ? 1 : 0), V = narrow_v(K);
+static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, int mode) {
+  const int D = ctx->D, dt = narrow_dt(K, ctx->F, D, mode), NSF = narrow_steps(K, ctx->F, D, mode), V = narrow_v(K);
   std::vector<int> gpos;                // grouped: 4 step + index of every feature of the full map
   if (dt) {
     gpos.assign((size_t)ctx->F, 0);
@@ -533,11 +544,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
-  const bool narrow_vi = src == kSrcEstep && ctx->narrow_call == 1;                 // narrow softmax + statistics pass
+  const bool narrow_g1 = src == kSrcEstep && ctx->narrow_call == 3;                 // narrow label pass with the statistics of the labels in the same kernel
+  const bool narrow_vi = src == kSrcEstep && (ctx->narrow_call == 1 || narrow_g1);  // narrow softmax + statistics pass (or the above: same launch shape)
   const bool narrow_g = src == kSrcEstep && ctx->narrow_call == 2;                  // narrow label pass + label statistics
   const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave || narrow_g);
   int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
-             : rowvi ? rowwave_grid(a, ctx->num_cu) : narrow_vi ? narrow_grid(a, ctx->num_cu, ctx->F, 0)
+             : rowvi ? rowwave_grid(a, ctx->num_cu) : narrow_vi ? narrow_grid(a, ctx->num_cu, ctx->F, narrow_g1 ? 2 : 0)
              : fused_grid(a, ctx->num_cu, src);
   // two-stage pass on the pipelined E-step (mimo_wide.hip): that kernel is built for two workgroups per CU whatever K is
   // (fused_grid's fallback assumes one for K > 128); the statistics launches of the pass share the grid (partial blocks)
@@ -589,7 +601,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
     if (rc) return rc;
   } else if (narrow_vi) {
     rc = timed_launch(ctx, "narrow_kernel", [&]() -> int {
-      HIP_TRY(ctx, launch_narrow(a, ctx->F, 0, grid, ctx->stream));
+      HIP_TRY(ctx, launch_narrow(a, ctx->F, narrow_g1 ? 2 : 0, grid, ctx->stream));
       return MIMO_OK;
     });
     if (rc) return rc;
@@ -967,9 +979,9 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
   const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
-  const bool nv = use_narrow(ctx, K, false, plain);      // narrow shapes (Dz <= 4, 32 < K <= 128): mimo_narrow.hip
+  const bool nv = use_narrow(ctx, K, false, plain) != 0;      // narrow shapes (Dz <= 4, 32 < K <= 128; few components over many features): mimo_narrow.hip
   const bool rv = !nv && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
-  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, false) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
   ctx->narrow_call = nv ? 1 : 0;
@@ -1059,12 +1071,12 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
     }
   }
   const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
-  const bool nw = use_narrow(ctx, K, true, !wants_tables);
+  const int nw = use_narrow(ctx, K, true, !wants_tables, !no_stats);
   const bool rw = !nw && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
-  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, true) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, nw - 1) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_call = rw;
-  ctx->narrow_call = nw ? 2 : 0;
+  ctx->narrow_call = nw;
   rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr);
   ctx->rowwave_call = false;
   ctx->narrow_call = 0;
@@ -1472,10 +1484,10 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   if (use_small(ctx, K)) {
     out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
     out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
-  } else if (use_narrow(ctx, K, gibbs != 0, true)) {
-    out8[0] = MIMO_PLAN_NARROW; out8[1] = gibbs ? 2 : 1;
-    if (gibbs) { out8[4] = 2; out8[5] = 2; }
-    out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, gibbs ? 1 : 0);
+  } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true)) {
+    out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
+    if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
+    out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, nm - 1);
   } else if (!gibbs && ctx->n_bad == 0 && ctx->D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     out8[6] = rowwave_grid(a, ctx->num_cu);

@@ -46,6 +46,7 @@ hipError_t launch_vi_rowwave(const KernelArgs& a, int grid, hipStream_t stream);
 // [NSF V][16]: slice s V + c, entry 4 k + j = Theta[component j V + c][feature 4 s + k]
 int narrow_v(int K);                 // component slots per lane (4 V >= K), 0: not instantiated
 int narrow_nsf(int F);               // contraction steps: ceil(F / 4)
+// (gibbs: 0 softmax + statistics pass, 1 label draw, 2 label draw + statistics of the labels in the same pass)
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs);
 // the grouped variant (full feature map, Dz = 5 .. 32; rows of the upper triangle padded to whole steps): Dz if it serves the
 // shape, else 0; contraction steps of the image either way; position of feature (a, b) in the grouped order

@@ -104,8 +104,13 @@ struct NarrowGroup {
 constexpr int narrow_group_steps(int D) { int n = 0; for (int r = 0; r <= D; ++r) n += (D + 1 - r + 3) / 4; return n; }
 constexpr int narrow_group_zs(int D) { return (D + 4) | 1; }      // row stride of the grouped variant: z, 1, three zero slots
 
-template <int V, int NSF, int MODE, int ZI, int DT = 0>   // MODE 0: softmax + statistics (fast mean-field / EM pass), 1: label draw
+// MODE 0: softmax + statistics (fast mean-field / EM pass), 1: label draw, 2: label draw + the statistics of the labels in the same
+// pass (the one-hot row of the drawn label takes the place of the responsibilities in the second product: a sweep costs what a
+// softmax pass costs and reads Z once — for the table-driven / grouped loops, whose second product is cheap next to a second pass)
+template <int V, int NSF, int MODE, int ZI, int DT = 0>
 __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_kernel(const KernelArgs a) {
+  constexpr bool STATS = MODE != 1;
+  static_assert(MODE != 2 || NSF > 4, "label draw + statistics: table-driven and grouped loops only");
   static_assert(DT == 0 || (DT >= 5 && NSF == narrow_group_steps(DT)), "grouped variant: NSF = steps of the grouped order");
   constexpr NarrowGroup<DT> GR{};
   constexpr bool LEAN = narrow_lean(V, NSF, MODE);
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
   }
   const double* thl = Th + 4 * hi + lo;
 
-  double sacc[MODE == 0 ? V : 1][MODE == 0 ? NSF : 1];
-  if constexpr (MODE == 0) {
+  double sacc[STATS ? V : 1][STATS ? NSF : 1];
+  if constexpr (STATS) {
 #pragma unroll
     for (int c = 0; c < V; ++c)
 #pragma unroll
@@ -228,6 +233,39 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     read_factors();
   }
+
+  // ---- S += R' . Phi: rr = the lane's r values (the A operand as it is), inv = 1 / sum e (1 for one-hot rows) ----------------
+  auto stats_product = [&](double (&rr)[V], double (&bv)[MODE == 0 ? NP : 1], double inv) {
+    if constexpr (STATS) {
+      double bq = 0.0;
+      if constexpr (FT && DT == 0) bq = feat1(0) * inv;
+      double zB[DT + 1], zT[DT + 1];                       // grouped: row 4 b + hi and its copy shifted by lo
+      if constexpr (DT > 0) {
+        const double* r1l = row1 + lo;
+#pragma unroll
+        for (int i = 0; i <= DT; ++i) { zB[i] = row1[i]; zT[i] = r1l[i]; }
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int c = 0; c < V; ++c) rr[c] *= inv;          // (V products instead of one per feature step)
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NSF; ++s) {
+        double bcur;
+        if constexpr (DT > 0) {
+          bcur = zB[GR.a[s]] * zT[GR.b0[s]];
+        } else if constexpr (FT) {
+          bcur = bq;
+          if (s + 1 < NSF) bq = MODE == 0 ? feat1(s + 1) * inv : feat1(s + 1);
+        } else {
+          bcur = bv[s];
+        }
+#pragma unroll
+        for (int c = 0; c < V; ++c)
+          sacc[c][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(rr[c], bcur, sacc[c][s], 0, 0, 0);
+      }
+    }
+  };
 
   for (int64_t t = wv; t < nsteps; t += nwaves) {
     const int64_t n1 = t * 16 + 4 * b + hi;           // the row this lane normalises / draws for
@@ -364,32 +402,7 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         read_factors();
       }
-      // ---- S += R' . Phi ------------------------------------------------------------------------------------
-      double bq = 0.0;
-      if constexpr (FT && DT == 0) bq = feat1(0) * inv;
-      double zB[DT + 1], zT[DT + 1];                       // grouped: row 4 b + hi and its copy shifted by lo
-      if constexpr (DT > 0) {
-        const double* r1l = row1 + lo;
-#pragma unroll
-        for (int i = 0; i <= DT; ++i) { zB[i] = row1[i]; zT[i] = r1l[i]; }
-#pragma unroll
-        for (int c = 0; c < V; ++c) acc[c] *= inv;          // (V products instead of one per feature step)
-      }
-#pragma unroll
-      for (int s = 0; s < NSF; ++s) {
-        double bcur;
-        if constexpr (DT > 0) {
-          bcur = zB[GR.a[s]] * zT[GR.b0[s]];
-        } else if constexpr (FT) {
-          bcur = bq;
-          if (s + 1 < NSF) bq = feat1(s + 1) * inv;
-        } else {
-          bcur = bv[s];
-        }
-#pragma unroll
-        for (int c = 0; c < V; ++c)
-          sacc[c][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[c], bcur, sacc[c][s], 0, 0, 0);
-      }
+      stats_product(acc, bv, inv);
       if (++since_flush == 64) {          // (4 V)^64 <= 128^64 = 2^448 stays inside the float64 range
         sc_lse += log(sc_prod);
         sc_prod = 1.0;
@@ -469,10 +482,16 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       const int label = cnt < K ? cnt : K - 1;
       if (lo == 0 && valid) a.labels[n1] = label;
       __builtin_amdgcn_s_setprio(0);
+      if constexpr (MODE == 2) {             // the one-hot row of the label (rows past N: every feature is zero)
+#pragma unroll
+        for (int c = 0; c < V; ++c) acc[c] = (lo * V + c == label) ? 1.0 : 0.0;
+        double nobv[1] = {0.0};
+        stats_product(acc, nobv, 1.0);
+      }
     }
   }
 
-  if constexpr (MODE == 0) {
+  if constexpr (STATS) {
     // ---- per-workgroup partial block: the four blocks and the four waves added in a fixed order, GB accumulators at a time
     const int FT = a.F16_total, Kpad = a.K16 * 16;
     const size_t pstride = (size_t)Kpad * FT + 4;
@@ -551,11 +570,11 @@ static narrow_fn pick_narrow_mode(int gibbs, int zi) {
   if constexpr (NSF <= 4) {
     if (zi == 1) return gibbs ? narrow_kernel<V, NSF, 1, 1> : narrow_kernel<V, NSF, 0, 1>;
   } else if constexpr (NSF <= 39 && V <= kNarrowMaxVWide && V * NSF <= kNarrowMaxAcc) {
-    if (zi == 4) return gibbs ? narrow_kernel<V, NSF, 1, 4> : narrow_kernel<V, NSF, 0, 4>;
+    if (zi == 4) return gibbs == 2 ? narrow_kernel<V, NSF, 2, 4> : gibbs ? narrow_kernel<V, NSF, 1, 4> : narrow_kernel<V, NSF, 0, 4>;
   } else if constexpr (NSF > 39 && V <= 2 && V * NSF <= kNarrowMaxAccXWide) {
-    // Dz = 17 .. 32 (ZI = 8), softmax + statistics pass with K <= 8: one wave per SIMD, the accumulators take the second
-    // half of the unified register file (a label pass with so few components has no label-statistics kernel behind it)
-    if (zi == 8 && !gibbs) return narrow_kernel<V, NSF, 0, 8>;
+    // Dz = 17 .. 32 (ZI = 8), softmax + statistics pass or label draw + statistics with K <= 8: one wave per SIMD, the accumulators
+    // take the second half of the unified register file
+    if (zi == 8 && gibbs != 1) return gibbs == 2 ? narrow_kernel<V, NSF, 2, 8> : narrow_kernel<V, NSF, 0, 8>;
   }
   return nullptr;
 }
@@ -593,10 +612,10 @@ constexpr int kNarrowGroupMaxAcc = 200;
 template <int D, int V>
 static narrow_fn pick_narrow_dt_mode(int gibbs) {
   constexpr int NST = narrow_group_steps(D), ZI = D <= 16 ? 4 : 8;
-  if (gibbs) {
+  if (gibbs == 1) {
     if constexpr (D <= 16) return narrow_kernel<V, NST, 1, ZI, D>;
   } else {
-    if constexpr (V * NST <= kNarrowGroupMaxAcc) return narrow_kernel<V, NST, 0, ZI, D>;
+    if constexpr (V * NST <= kNarrowGroupMaxAcc) return gibbs == 2 ? narrow_kernel<V, NST, 2, ZI, D> : narrow_kernel<V, NST, 0, ZI, D>;
   }
   return nullptr;
 }
@@ -634,7 +653,7 @@ int narrow_dt(int K, int F, int D, int gibbs) {
   // 258 / 205; Dz=24 K=8 1108 / 857; Dz=32 K=4 1552 / 840; Dz=5, 6: table-driven (a third more steps after the padding);
   // label pass: Dz=16 K=4 297 / 256, Dz=12 K=4 217 / 202, below that no difference
   static const bool always = [] { const char* e = getenv("MIMO_NARROW_GROUPED"); return e && atoi(e) == 2; }();
-  const bool prefer = gibbs ? D >= 12 : (D >= 13 || (V <= 2 && D >= 7));
+  const bool prefer = gibbs == 1 ? D >= 12 : (D >= 13 || (V <= 2 && D >= 7));
   if (!prefer && !always && pick_narrow(V, narrow_nsf(F), gibbs, narrow_zi(D))) return 0;
   return D;
 }
@@ -663,8 +682,8 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
     // Dz = 17 .. 32 (profiles/r03_wide_sweep_dz17_32.txt, against the two-stage tile kernels that pay for 16 components): K <= 4
     // Dz=17 1514 -> 290 us, Dz=24 2253 -> 538, Dz=32 3095 -> 1525 (one wave per SIMD from Dz = 26); K = 8 Dz=20 1633 -> 632, Dz=26 2304 -> 1219
     const int kmax_w = wide_kmax > 0 ? wide_kmax : (D <= 8 ? 24 : D <= 16 ? 16 : 8);
-    if (!wide_on || K < 1 || K > kmax_w || D < 5 || D > 32 || (D > 16 && gibbs)) return false;
-  } else if (K < kmin || K > kmax || K > 128 || D > 4) {
+    if (!wide_on || K < 1 || K > kmax_w || D < 5 || D > 32 || (D > 16 && gibbs == 1)) return false;
+  } else if (K < kmin || K > kmax || K > 128 || D > 4 || gibbs == 2) {
     return false;
   }
   const int V = narrow_v(K);
@@ -678,7 +697,7 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
 int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs) {
   const int dt = narrow_dt(a.K, F, a.D, gibbs);
   const int V = narrow_v(a.K), nsf = dt ? narrow_group_steps(dt) : narrow_nsf(F);
-  int per_cu = narrow_waves(V, nsf, gibbs ? 1 : 0);
+  int per_cu = narrow_waves(V, nsf, gibbs == 1 ? 1 : 0);
   if (narrow_fn fn = dt ? pick_narrow_dt(V, dt, gibbs) : pick_narrow(V, nsf, gibbs, narrow_zi(a.D))) {
     int nb = 0;
     const size_t lds = narrow_lds_bytes(V, nsf, dt ? narrow_group_zs(dt) : a.ZS);
