@@ -38,6 +38,7 @@
 #ifndef MIMO_HIP_H
 #define MIMO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -322,6 +323,12 @@ int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const d
 int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, const double* psis,
                        const double* z, const double* g, const double* eps,
                        double* out_mu, double* out_lmbda, double* out_c, double* out_b);
+
+/* Checksum over every byte of a host buffer: out[0] = wrapping sum, out[1] = xor of its 64-bit words (the last nbytes % 8 bytes
+ * zero-extended) — memory-bandwidth bound, threaded above 8 MB.  What engine.bind() / the row-weight residency of the host mirror
+ * key on, so that an in-place edit of a caller's array between two calls is seen (the reference re-reads its arguments on every
+ * call: mimo/mixtures/gmm.py:62-75); any single-element edit changes it, a permutation of words does not. */
+int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]);
 
 /* digamma used by the two routines above (recurrence + asymptotic series), for tests. */
 double mimo_host_digamma(double x);

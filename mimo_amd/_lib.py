@@ -45,6 +45,7 @@ SIGNATURES = {
     "mimo_host_mnw_vi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_vp] * 15),
     "mimo_host_nw_gibbs": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "mimo_host_digamma": (C.c_double, [C.c_double]),
+    "mimo_host_checksum": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "mimo_predict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "mimo_predict_flags": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,

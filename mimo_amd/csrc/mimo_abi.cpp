@@ -574,7 +574,13 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const int ncb_total = a.F16 / 16;
   if (lstats) {
     if (rowwave) {
+      // the resident-Theta label kernel counts its labels for the slot table of the statistics kernel behind it
+      // (not with NaN rows: their labels are masked before the statistics; MIMO_FUSE_LABEL_HIST=0: off)
+      static const bool fuse_on = [] { const char* e = getenv("MIMO_FUSE_LABEL_HIST"); return !e || atoi(e) != 0; }();
+      a.fuse_hist = fuse_on && a.do_stats && ctx->n_bad == 0 && a.aux && label_stats_uses_slots(K, D, a.N) &&
+                    gibbs_rowwave_counts_labels(K, a.F16, a.ZS) ? 1 : 0;
       rc = timed_launch(ctx, "gibbs_rowwave_kernel", [&]() -> int {
+        if (a.fuse_hist) HIP_TRY(ctx, launch_label_hist_reset(a, ctx->stream));
         HIP_TRY(ctx, launch_gibbs_rowwave(a, rowwave_grid(a, ctx->num_cu), ctx->stream));
         return MIMO_OK;
       });

@@ -36,6 +36,8 @@ int label_stats_launches(int K, int D, int structure);
 // ... and the slot-table variant for skewed label vectors (K >= 17, Dz <= 9, N >= 2^17): needs KernelArgs::aux
 bool label_stats_uses_slots(int K, int D, int64_t N);
 size_t label_stats_aux_words();
+hipError_t launch_label_hist_reset(const KernelArgs& a, hipStream_t stream);
+bool gibbs_rowwave_counts_labels(int K, int F16, int ZS);
 
 // row-owner softmax + statistics pass, K <= 64, Dz <= 9 (mimo_rowwave.hip); theta in the row-owner image
 struct KernelArgs;

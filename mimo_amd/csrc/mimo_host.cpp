@@ -388,6 +388,53 @@ int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, co
   });
 }
 
+int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]) {
+  return guarded_host([&]() -> int {
+  if ((!data && nbytes) || !out) return MIMO_E_INVALID;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  const size_t nw = nbytes / 8;
+  // slices of whole words; a thread per ~4 MB, at most 8 (a thread costs ~15 us to start: 1 MB of streaming)
+  int nt = (int)std::min<size_t>(8, nbytes / ((size_t)4 << 20));
+  {
+    const unsigned hc = std::thread::hardware_concurrency();
+    nt = std::max(1, std::min<int>(nt, hc ? (int)hc : 1));
+  }
+  std::vector<uint64_t> part((size_t)2 * nt, 0);
+  auto run = [&](int t) noexcept {
+    const size_t w0 = nw * (size_t)t / nt, w1 = nw * (size_t)(t + 1) / nt;
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    size_t w = w0;
+    for (; w + 4 <= w1; w += 4) {
+      uint64_t v[4];
+      memcpy(v, p + 8 * w, 32);                  // (unaligned-safe; compiles to vector loads)
+      s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+      x0 ^= v[0]; x1 ^= v[1]; x2 ^= v[2]; x3 ^= v[3];
+    }
+    for (; w < w1; ++w) { uint64_t v; memcpy(&v, p + 8 * w, 8); s0 += v; x0 ^= v; }
+    part[2 * t] = s0 + s1 + s2 + s3;
+    part[2 * t + 1] = x0 ^ x1 ^ x2 ^ x3;
+  };
+  std::vector<std::thread> th;
+  int started = 1;
+  try {
+    th.reserve((size_t)(nt - 1));
+    for (int t = 1; t < nt; ++t) { th.emplace_back(run, t); ++started; }
+  } catch (...) {
+    // fewer helpers than planned: the calling thread does their slices below
+  }
+  run(0);
+  for (int t = started; t < nt; ++t) run(t);
+  for (auto& x : th) x.join();
+  uint64_t sum = 0, xr = 0;
+  for (int t = 0; t < nt; ++t) { sum += part[2 * t]; xr ^= part[2 * t + 1]; }
+  uint64_t tail = 0;                              // the last nbytes % 8 bytes, zero-extended
+  memcpy(&tail, p + 8 * nw, nbytes - 8 * nw);
+  out[0] = sum + tail;
+  out[1] = xr ^ tail;
+  return MIMO_OK;
+  });
+}
+
 double mimo_host_digamma(double x) { return digamma(x); }
 
 int mimo_host_debug_fault(int kind) {

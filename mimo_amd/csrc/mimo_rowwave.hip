@@ -70,6 +70,10 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
   for (int e = tid; e < NS * KB * 64; e += kRowWaveWG) Th[e] = a.theta[e];
   for (int e = tid; e < 4 * 64; e += kRowWaveWG) Th[NS * KB * 64 + e] = 0.0;
   for (int e = tid; e < kExpTab; e += kRowWaveWG) etab[e] = exp_tab_entry_c(e);
+  // a.fuse_hist: the histogram of the labels this launch draws, for the slot table of label_stats_slots_kernel — 16 LDS atomics per
+  // wave step here instead of a pass of its own over the labels (label_hist_kernel: 36 us at N = 1e7, same-address atomics of skewed labels)
+  __shared__ uint32_t hloc[256];
+  if (tid < 256) hloc[tid] = 0u;
   wg_sync();
 
   // z rows of a 16-row step: element e = lane + 64 i of the (16, D) block, i < ZI (16 D <= 144 up to Dz = 9, <= 256 up to 16)
@@ -218,8 +222,15 @@ __global__ __launch_bounds__(kRowWaveWG, 1) void gibbs_rowwave_kernel(const Kern
     cnt += __shfl_xor(cnt, 16);
     cnt += __shfl_xor(cnt, 32);
     const int label = cnt < K ? cnt : K - 1;
-    if (q == 0 && valid) a.labels[n] = label;
+    if (q == 0 && valid) {
+      a.labels[n] = label;
+      if (a.fuse_hist) atomicAdd(&hloc[label], 1u);
+    }
     __builtin_amdgcn_s_setprio(0);
+  }
+  if (a.fuse_hist) {                       // (wave-uniform)
+    wg_sync();
+    if (tid < 256 && hloc[tid]) atomicAdd(&a.aux[tid], hloc[tid]);
   }
 }
 
@@ -467,7 +478,7 @@ static bool rowwave_resident(int K, int F16, int ZS) {
   if (K < rowwave_min_k() || K > 256 || F16 > 160) return false;
   const int kb = rowwave_kb(K);
   if (F16 > 64 && !(kb <= 4 || (kb <= 8 && F16 <= 96))) return false;
-  return rowwave_lds_bytes(kb, F16 / 4, ZS) <= 160 * 1024;
+  return rowwave_lds_bytes(kb, F16 / 4, ZS) + 1024 <= 160 * 1024;      // (+ the kernel's static 1 KB label histogram)
 }
 // ... and beyond that, up to Dz = 32 (F16 <= 576), with Theta streamed through LDS (MIMO_ROWWAVE_STREAM=0: off, tuning knob)
 static bool rowwave_streams(int K, int F16, int ZS) {
@@ -1758,6 +1769,13 @@ static hipError_t launch_xwide(const KernelArgs& a, int grid, hipStream_t stream
   return hipSuccess;
 }
 
+// zero the histogram in front of a label kernel that counts its own labels (KernelArgs::fuse_hist)
+hipError_t launch_label_hist_reset(const KernelArgs& a, hipStream_t stream) {
+  return a.aux ? hipMemsetAsync(a.aux, 0, 256 * sizeof(uint32_t), stream) : hipErrorInvalidValue;
+}
+// the label pass of (K, F16) runs on gibbs_rowwave_kernel (Theta resident), the kernel that can count its labels
+bool gibbs_rowwave_counts_labels(int K, int F16, int ZS) { return rowwave_resident(K, F16, ZS); }
+
 // structure: 0 full, 1 diagonal, 2 linear (MIMO_STRUCT_*)
 hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipStream_t stream) {
   typedef void (*fn_t)(const KernelArgs);
@@ -1767,11 +1785,13 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
     if (!a.aux) return hipErrorInvalidValue;
     fn = structure == 1 ? pick_label_stats_slots<1>(a.D) : structure == 2 ? pick_label_stats_slots<2>(a.D) : pick_label_stats_slots<0>(a.D);
     if (!fn) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(a.aux, 0, 256 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    int hg = (int)((a.N + kWG * 16 - 1) / (kWG * 16));
-    if (hg > 1024) hg = 1024;
-    hipLaunchKernelGGL(label_hist_kernel, dim3(hg), dim3(kWG), 0, stream, a.labels, a.N, a.K, a.aux);
+    if (!a.fuse_hist) {       // (else: the label kernel of this pass counted them, launch_label_hist_reset ran in front of it)
+      hipError_t e = hipMemsetAsync(a.aux, 0, 256 * sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+      int hg = (int)((a.N + kWG * 16 - 1) / (kWG * 16));
+      if (hg > 1024) hg = 1024;
+      hipLaunchKernelGGL(label_hist_kernel, dim3(hg), dim3(kWG), 0, stream, a.labels, a.N, a.K, a.aux);
+    }
     hipLaunchKernelGGL(label_slots_kernel, dim3(1), dim3(kWG), 0, stream, a.aux, a.K);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);
     return hipGetLastError();

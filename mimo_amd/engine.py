@@ -145,9 +145,8 @@ class HipEngine:
         hierarchical drivers pass the same weights every iteration."""
         key = None
         if weights is not None:
-            wv = _f64(weights).reshape(-1)
-            key = (wv.__array_interface__['data'][0], wv.shape[0], content_fingerprint(wv, exact=True), id(self._keepalive), self.N,
-                   getattr(self, '_upload_count', 0))
+            wv, base = _weights_key(weights)
+            key = base + (id(self._keepalive), self.N, getattr(self, '_upload_count', 0))
             hit = getattr(self, '_xxw_cache', None)
             if hit is not None and hit[0] == key:
                 return hit[1]
@@ -303,11 +302,12 @@ class HipEngine:
         S = np.empty((K, 1 + self.D + self.D * self.D)) if stats else None
         sc = np.empty(3)
         if row_weights is not None and stats:
-            w = _f64(row_weights).reshape(-1)
+            w, base = _weights_key(row_weights)
             if w.shape[0] != self.N:
                 raise ValueError(f"row_weights has {w.shape[0]} entries, data has {self.N} rows")
             # the drivers pass the same weight vector every iteration: it stays on the device while its content does
-            wkey = (w.__array_interface__['data'][0], w.shape[0], content_fingerprint(w, exact=True), id(self._keepalive), self.N)
+            # (the drivers freeze it once per call — FrozenWeights —, a plain array is hashed here, every byte)
+            wkey = base + (id(self._keepalive), self.N)
             resident = getattr(self, '_w_key', None) == wkey
             rc = self._lib.mimo_estep_weighted(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(w),
                                                flags | (_lib.F_WEIGHTS_RESIDENT if resident else 0), _ptr(S), _ptr(sc))
@@ -570,10 +570,51 @@ def _word_checksum(Z):
     """Checksum over EVERY 8-byte word of a C-contiguous array: wrapping sum and xor of the words — two reductions at memory
     bandwidth, no temporary; any edit of a single element changes it (a permutation of elements would not)."""
     w = np.ascontiguousarray(Z).reshape(-1).view(np.uint8)
+    try:                     # one threaded pass in the library (host-only entry point: no GPU needed) — 32 MB of row weights in
+        lib = _lib.load()    # ~1 ms where the two NumPy reductions below take ~3 ms, as much as the pass they guard
+    except _lib.MimoHipError:
+        lib = None
+    if lib is not None:
+        out = (C.c_uint64 * 2)()
+        if lib.mimo_host_checksum(w.ctypes.data_as(C.c_void_p), w.size, out) == 0:
+            return (int(out[0]), int(out[1]))
     n8 = w.size // 8
     u = w[:8 * n8].view(np.uint64)
     import zlib
     return (int(np.add.reduce(u, dtype=np.uint64)), int(np.bitwise_xor.reduce(u)), zlib.crc32(w[8 * n8:]))
+
+
+class FrozenWeights:
+    """Row weights a driver passes unchanged to every iteration of ONE call (hgmm.py:199-207: the outer responsibilities of an
+    inner mixture): the content fingerprint — every byte — is taken once here instead of once per pass (32 MB of weights at
+    N = 4e6 hash in ~1.3 ms, twice per pass: more than the pass itself).  Behaves like the array (np.asarray works)."""
+    __slots__ = ('array', 'key')
+
+    def __init__(self, w):
+        self.array = np.ascontiguousarray(np.asarray(w, dtype=np.float64)).reshape(-1)
+        self.key = (self.array.__array_interface__['data'][0], self.array.shape[0], content_fingerprint(self.array, exact=True))
+
+    def __array__(self, dtype=None, copy=None):
+        return self.array if dtype is None else self.array.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.array.shape[0]
+
+    def __getitem__(self, idx):
+        return self.array[idx]
+
+
+def freeze_weights(w):
+    """None stays None, a FrozenWeights is returned as it is, anything else is wrapped (fingerprint taken now)."""
+    return w if w is None or isinstance(w, FrozenWeights) else FrozenWeights(w)
+
+
+def _weights_key(w):
+    """(array, identity of its content): FrozenWeights carry theirs, a plain array is hashed — every byte — now."""
+    if isinstance(w, FrozenWeights):
+        return w.array, w.key
+    wv = _f64(w).reshape(-1)
+    return wv, (wv.__array_interface__['data'][0], wv.shape[0], content_fingerprint(wv, exact=True))
 
 
 def content_fingerprint(Z, exact=None):

@@ -99,7 +99,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
         if randomize:
             resp = npr.rand(self.size, eng.N)
             resp /= np.sum(resp, axis=0)
-            return eng.weighted_stats(resp if weights is None else resp * weights)
+            return eng.weighted_stats(resp if weights is None else resp * np.asarray(weights))
         return eng.estep(*self.canonical_expected(), row_weights=weights)[0]
 
     def meanfield_coordinate_descent(self, obs, randomize=True, weights=None, maxiter=250, maxsubiter=5, tol=1e-8,
@@ -107,6 +107,7 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
         """One fused pass per iteration: the E-step under the new posterior yields the bound's data / label
         terms (unweighted responsibilities, hgmm.py:207) and the weighted statistics of the next update."""
         eng = self._bind(obs)
+        weights = _engine.freeze_weights(weights)          # the same vector in every iteration: fingerprinted once
         S = self._first_stats(eng, randomize, weights)
         vlb = []
         with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,

@@ -98,7 +98,7 @@ class BayesianMixtureOfLinearGaussiansWithTiedActivation:
         if randomize:
             resp = npr.rand(self.size, eng.N)
             resp /= np.sum(resp, axis=0)
-            return eng.weighted_stats(resp if weights is None else resp * weights)
+            return eng.weighted_stats(resp if weights is None else resp * np.asarray(weights))
         return eng.estep(*self.canonical_expected(), row_weights=weights)[0]
 
     def meanfield_coordinate_descent(self, x, y, randomize=True, weights=None, maxiter=250, maxsubiter=5, tol=1e-16,
@@ -106,6 +106,7 @@ class BayesianMixtureOfLinearGaussiansWithTiedActivation:
         """Returns [] like the reference (its append is commented out, hilr.py:198); `record_bound=True`
         returns the bound of every iteration instead — it comes with the pass at no extra cost."""
         eng = self._bind(x, y)
+        weights = _engine.freeze_weights(weights)          # the same vector in every iteration: fingerprinted once
         S = self._first_stats(eng, randomize, weights)
         vlb = []
         with tqdm(total=maxiter, desc=f'VI #{process_id + 1}', position=process_id,
