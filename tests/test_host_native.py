@@ -271,3 +271,41 @@ def test_batched_rvs_consumes_numpy_random_like_the_component_loop():
         aux = npr.normal(size=dy * dx).dot(ci.T)
         assert rel_err(lmbdas[k], lm) < 1e-12 and rel_err(As[k], mnw.Ms[k] + np.reshape(aux, (dy, dx), order='F')) < 1e-11
     assert npr.random() == after
+
+
+@pytest.mark.parametrize("nbytes", [0, 5, 8, 8 * 1000 + 3, 8 * 3_000_001 + 7])
+def test_host_checksum_is_sum_and_xor_of_the_words(nbytes):
+    """mimo_host_checksum (what bind() and the row-weight residency key on): wrapping sum and xor of every 64-bit word, the tail
+    zero-extended; threaded above 8 MB with the same result; any single-byte edit changes it."""
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(nbytes)
+    buf = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+    out = (C.c_uint64 * 2)()
+    assert lib.mimo_host_checksum(buf.ctypes.data_as(C.c_void_p), nbytes, out) == 0
+    padded = np.zeros((nbytes + 7) // 8 * 8, dtype=np.uint8); padded[:nbytes] = buf
+    words = padded.view(np.uint64)
+    assert int(out[0]) == int(np.add.reduce(words, dtype=np.uint64)) and int(out[1]) == int(np.bitwise_xor.reduce(words)) if nbytes else (out[0], out[1]) == (0, 0)
+    if nbytes:
+        first = (int(out[0]), int(out[1]))
+        buf[nbytes // 2] ^= 1
+        assert lib.mimo_host_checksum(buf.ctypes.data_as(C.c_void_p), nbytes, out) == 0
+        assert (int(out[0]), int(out[1])) != first
+    assert lib.mimo_host_checksum(None, 8, out) == _lib.E_INVALID
+
+
+def test_frozen_weights_are_fingerprinted_once_and_plain_arrays_on_every_call():
+    """engine.FrozenWeights (what the hierarchical drivers wrap their weight vector in for the length of one call): the key is the
+    one taken at construction; a plain array is hashed — every byte — whenever it is passed, so an in-place edit is seen."""
+    from mimo_amd import engine as E
+    w = np.random.default_rng(0).random(300_000)            # 2.4 MB: beyond the CRC range, inside the exact range
+    fw = E.freeze_weights(w)
+    assert E.freeze_weights(fw) is fw and E.freeze_weights(None) is None
+    arr, key = E._weights_key(fw)
+    assert arr is fw.array and key == fw.key and np.array_equal(np.asarray(fw), w) and len(fw) == w.shape[0]
+    _, k1 = E._weights_key(w)
+    assert k1 == key                                        # same content, same buffer: same identity
+    w[12345] += 1e-12
+    _, k2 = E._weights_key(w)
+    assert k2 != k1 and E._weights_key(fw)[1] == key        # the plain array is re-hashed, the frozen one is not
+    assert np.allclose(2.0 * np.asarray(fw), 2.0 * w)
