@@ -381,7 +381,7 @@ static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool s
   // N = 2e6, us per sweep, label kernel + label statistics / fused: Dz=8 K=4 154 / 93, K=8 154 / 129, K=16 181 / 194; Dz=12 K=8 237 / 208,
   // K=16 312 / 395; Dz=16 K=4 256 / 213, K=8 315 / 374, K=16 430 / 649)
   const int V = narrow_v(K), D = ctx->D;
-  if (one && stats && (V == 1 || D <= 6 || (D <= 12 && V <= 3))) return 3;
+  if (one && stats && (V == 1 || (D <= 6 && V <= 6) || (D <= 12 && V <= 3))) return 3;
   return two ? 2 : 0;
 }
 

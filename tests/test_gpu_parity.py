@@ -285,7 +285,8 @@ def test_row_weighted_estep(engine, D, K, N):
 
 @pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (32, 64, 20000), (8, 256, 33000), (32, 128, 9000),
                                    (5, 7, 0), (24, 200, 5000),
-                                   (16, 16, 30000), (32, 24, 20000), (24, 8, 9000), (31, 32, 33000)])   # K <= 32: split kernels
+                                   (16, 16, 30000), (32, 24, 20000), (24, 8, 9000), (31, 32, 33000),    # K <= 32: split kernels
+                                   (6, 40, 30011), (7, 64, 20005), (5, 33, 9001), (12, 8, 30000)])       # <= 16 / 17 .. features: narrow kernels
 def test_diagonal_structure(engine, D, K, N):
     """mimo_set_structure(MIMO_STRUCT_DIAG): the 2 Dz + 1 feature kernels against the oracle with W = diag —
     tables, statistics (zero off-diagonal second moments), bound, labels; full W is rejected; switching back."""
@@ -327,7 +328,8 @@ def test_diagonal_structure(engine, D, K, N):
 
 
 @pytest.mark.parametrize("D,K,N", [(2, 4, 1000), (16, 64, 40000), (15, 64, 20000), (8, 256, 33000), (32, 128, 9000),
-                                   (5, 7, 0)])
+                                   (5, 7, 0),
+                                   (8, 33, 30011), (12, 20, 20005), (6, 64, 25003), (16, 48, 9001), (11, 50, 70001)])   # narrow kernels on the linear map
 def test_linear_structure_for_tied_blocks(engine, D, K, N):
     """mimo_set_structure(MIMO_STRUCT_LINEAR): one W for all components — the Dz + 1 feature kernels plus the data
     constants of the shared quadratic term reproduce the full-structure results: n_k, sum r z, the POOLED second
@@ -698,7 +700,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(900 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "rowwave")
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
@@ -920,7 +922,7 @@ def test_row_owner_softmax_pass(engine, D, K, N):
     rng = np.random.default_rng(4000 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    narrow = (D, K) in ((2, 33), (1, 33)) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16))      # (few components at Dz >= 5: the table-driven narrow kernels)
+    narrow = (D, K) in ((2, 33), (1, 33)) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) or (D == 5 and K <= 64)   # (few components at Dz >= 5: the table-driven narrow kernels)
     assert engine.plan(K)["kind"] == ("narrow" if narrow else "rowwave-vi")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)
