@@ -10,7 +10,8 @@ STEPS = 7          # the PMC passes run bench.py --steps 5 --warmup 2
 
 def find(sub, suffix):
     hits = glob.glob(os.path.join(root, sub, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    # gpurun merges a call's files into gpurun_out/ without removing those of an earlier call: take the newest run
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def short(name):
