@@ -50,6 +50,7 @@ struct KernelArgs {
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
   double theta_inline[40];  // small-shape kernel with one lane per row (G = 1): Theta itself (kThetaInline doubles at most)
   uint32_t* aux;          // label_stats_slots_kernel: label histogram + slot table (label_stats_aux_words() words)
+  int k0;                 // label_stats_wide_kernel: first component of the launch's window (components k0 .. k0 + 127 of K > 128)
   int fuse_hist;          // gibbs_rowwave_kernel counts the labels it draws into aux[0 .. 255] (no label_hist_kernel behind it)
 };
 

@@ -1347,12 +1347,14 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
   __shared__ double red[kWG * 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = a.K;
+  // the launch takes the components k0 .. k0 + K - 1 of the a.K the labels run over (a window of at most 256 / FP: K > 128 at
+  // Dz = 10 .. 16 is two launches of 128 — each reads Z once — instead of four feature slices through label_stats_xwide_kernel)
+  const int k0 = a.k0;
+  const int K = a.K - k0 < kWG / FP ? a.K - k0 : kWG / FP;
   const int64_t N = a.N;
   const int64_t ntiles = (N + T - 1) / T;
   int Kp = 1;
   while (Kp < K) Kp <<= 1;
-  if (Kp * FP > kWG) Kp = kWG / FP;                           // (the host only routes K <= 256 / FP here)
   const int P = kWG / Kp, RP = P / FP;
   const int myk = tid & (Kp - 1), part = tid / Kp, fslice = part % FP, rpart = part / FP;
 
@@ -1370,8 +1372,8 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
       zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
     }
     const int64_t n = t * T + tid;
-    const int l = n < N ? a.labels[n] : -1;
-    lab = l < K ? l : -1;
+    const int l = (n < N ? a.labels[n] : -1) - k0;
+    lab = (l >= 0 && l < K) ? l : -1;       // outside the window (or outside [0, a.K): a caller's vector): skipped
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
 
@@ -1462,11 +1464,12 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
       }
     }
   }
-  // rows of the partial block without a component
-  for (int k = K + tid; k < a.K16 * 16; k += kWG)
-    for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
+  // rows of the partial block without a component (the first window's launch)
+  if (k0 == 0)
+    for (int k = a.K + tid; k < a.K16 * 16; k += kWG)
+      for (int f = 0; f < F; ++f) P_out[(size_t)k * FT + f] = 0.0;
   if (rpart == 0 && myk < K) {
-    double* Pk = P_out + (size_t)myk * FT;
+    double* Pk = P_out + (size_t)(k0 + myk) * FT;
     switch (fslice) {
       case 0: slice_store<DZ, FP, 0, MAXA>(acc, Pk); break;
       case 1: slice_store<DZ, FP, 1, MAXA>(acc, Pk); break;
@@ -1474,7 +1477,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
       default: if constexpr (FP == 4) slice_store<DZ, FP, 3, MAXA>(acc, Pk); break;
     }
   }
-  if (tid == 0 && a.write_scalars) {
+  if (tid == 0 && a.write_scalars && k0 == 0) {
     double* Ps = P_out + (size_t)a.K16 * 16 * FT;
     Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
   }
@@ -1675,7 +1678,12 @@ static bool xwide_on() {
   return on;
 }
 // wide kernel: 4 feature slices up to K = 64, 2 up to K = 128 (Dz <= 12); everything else of the full map: sliced launches
-static bool label_stats_wide_covers(int K, int D) { return D >= 10 && D <= 16 && (K <= 64 || (K <= 128 && D <= 12)); }
+// Dz = 10 .. 16: four feature slices per component up to K = 64, two beyond — in windows of 128 components per launch
+// (MIMO_LABEL_STATS_WIDE_ALL=0: the round-2 range — K <= 64, K <= 128 up to Dz = 12 —, the rest on the sliced kernel; tuning knob)
+static bool label_stats_wide_covers(int K, int D) {
+  static const bool all = [] { const char* e = getenv("MIMO_LABEL_STATS_WIDE_ALL"); return !e || atoi(e) != 0; }();
+  return D >= 10 && D <= 16 && (all || K <= 64 || (K <= 128 && D <= 12));
+}
 bool label_stats_covers(int K, int D, int structure) {
   if (K < rowwave_min_k() || K > 256 || D < 1) return false;
   if (structure != 0) return D <= 16;            // reduced maps (diagonal / linear): at most 2 Dz + 1 accumulators
@@ -1687,7 +1695,8 @@ bool label_stats_covers(int K, int D, int structure) {
 
 // launches of one statistics pass (each reads Z once): 1, or the slice groups of label_stats_xwide_kernel
 int label_stats_launches(int K, int D, int structure) {
-  if (structure != 0 || D <= 9 || label_stats_wide_covers(K, D)) return 1;
+  if (structure == 0 && D > 9 && label_stats_wide_covers(K, D)) return K <= 64 ? 1 : (K + 127) / 128;
+  if (structure != 0 || D <= 9) return 1;
   const int fpt = xwide_fpt(D, K);
   int Kp = 1;
   while (Kp < K) Kp <<= 1;
@@ -1803,8 +1812,18 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
     static const fn_t wide4[7] = {label_stats_wide_kernel<10, 4>, label_stats_wide_kernel<11, 4>, label_stats_wide_kernel<12, 4>,
                                   label_stats_wide_kernel<13, 4>, label_stats_wide_kernel<14, 4>, label_stats_wide_kernel<15, 4>,
                                   label_stats_wide_kernel<16, 4>};
-    static const fn_t wide2[3] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>};
+    static const fn_t wide2[7] = {label_stats_wide_kernel<10, 2>, label_stats_wide_kernel<11, 2>, label_stats_wide_kernel<12, 2>,
+                                  label_stats_wide_kernel<13, 2>, label_stats_wide_kernel<14, 2>, label_stats_wide_kernel<15, 2>,
+                                  label_stats_wide_kernel<16, 2>};
     fn = a.K <= 64 ? wide4[a.D - 10] : wide2[a.D - 10];
+    if (a.K > 128) {                  // windows of 128 components, one launch each into the same partial block
+      for (int k0 = 0; k0 < a.K; k0 += 128) {
+        KernelArgs w = a;
+        w.k0 = k0;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, w);
+      }
+      return hipGetLastError();
+    }
   } else {
     const bool s8 = xwide_fpt(a.D, a.K) == 8;
     switch (a.D) {
