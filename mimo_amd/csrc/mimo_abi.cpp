@@ -373,7 +373,7 @@ static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool s
   static const bool fused_labels = [] { const char* e = getenv("MIMO_NARROW_FUSED_LABELS"); return !e || atoi(e) != 0; }();
   if (!plain || use_small(ctx, K)) return 0;
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
-  if (!gibbs) return narrow_covers(K, ctx->F, ctx->D, ZS, 0) && ctx->n_bad == 0 ? 1 : 0;
+  if (!gibbs) return narrow_covers(K, ctx->F, ctx->D, ZS, 0) ? 1 : 0;     // (rows with NaN: their mask is the row-weight vector of the pass)
   const bool two = narrow_covers(K, ctx->F, ctx->D, ZS, 1) && label_stats_covers(K, ctx->D, ctx->structure);
   const bool one = fused_labels && ctx->n_bad == 0 && narrow_covers(K, ctx->F, ctx->D, ZS, 2);
   if (one && !two) return 3;
@@ -1009,7 +1009,9 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
   if (!S && !(flags & MIMO_F_ASYNC)) return fail(ctx, MIMO_E_INVALID, "mimo_estep_weighted: S is NULL");
   KernelArgs a;
   fill_args(ctx, K, &a);
-  if (!fused_covers(a.K16, a.F16 / 16, kSrcEstep))
+  // the narrow kernels take the weights on their normaliser (plain requests: statistics + scalars only)
+  const bool nv = use_narrow(ctx, K, false, (flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) == 0) != 0;
+  if (!nv && !fused_covers(a.K16, a.F16 / 16, kSrcEstep))
     return fail(ctx, MIMO_E_UNSUPPORTED, "mimo_estep_weighted: K=%d, Dz=%d runs on the two-stage path, which takes "
                 "its weights as a table (mimo_estep + mimo_weighted_stats)", K, ctx->D);
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
@@ -1027,9 +1029,12 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
     a.u = ctx->u_d;
     ctx->weights_resident = true;
   }
-  if ((rc = upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
-  return run_fused(ctx, a, kSrcEstep, flags, S, scalars);
+  ctx->narrow_call = nv ? 1 : 0;
+  rc = run_fused(ctx, a, kSrcEstep, flags, S, scalars);
+  ctx->narrow_call = 0;
+  return rc;
   });
 }
 

@@ -398,6 +398,9 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       inv = fma(fma(-ssum, inv, 1.0), inv, inv);
       inv = fma(fma(-ssum, inv, 1.0), inv, inv);
       if (lo == 0 && valid) { sc_lse += m; sc_prod *= ssum; }
+      // per-row weights of the statistics (mimo_estep_weighted: the outer responsibilities of a mixture of mixtures; the NaN-row
+      // mask): they ride on the normaliser — tables and scalars stay unweighted (hgmm.py:199-207)
+      if (a.u) inv *= valid ? a.u[n1] : 0.0;
       if constexpr (!FT) {
 #pragma unroll
         for (int s = 0; s < NP; ++s) bv[s] *= inv;      // r = e / sum e: the normaliser rides on the feature operand

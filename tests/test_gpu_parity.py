@@ -1000,6 +1000,12 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
     engine.estep_async(c, b, W)
     S2, sc2 = engine.estep_wait()
     assert np.array_equal(S2.sxx, S.sxx) and sc2[0] == sc[0]
+    # per-row weights of the statistics ride on the normaliser (mimo_estep_weighted on the same kernels): scalars unweighted
+    w = rng.uniform(0., 2., size=N)
+    wn, wsx, wsxx = O.packed_stats(Z, R * w[None, :])
+    Sw, scw = engine.estep(c, b, W, row_weights=w)
+    assert rel_err(Sw.n, wn) < 1e-11 and rel_err(Sw.sx, wsx) < 1e-11 and rel_err(Sw.sxx, wsxx) < 1e-11
+    assert abs(scw[0] - sc[0]) <= 1e-13 * max(1., abs(sc[0]))
     # label pass
     u = rng.random(N)
     lab, G = engine.gibbs_labels(c, b, W, u=u)

@@ -96,7 +96,7 @@ report("hierarchical (Normal-Wishart hyper-prior) GMM, mean-field VI, 5 sub-iter
 w = np.linspace(0.5, 1., N)
 t = per_iter(lambda it: hier.meanfield_coordinate_descent(X, randomize=False, weights=w, maxiter=it, maxsubiter=5, tol=0.,
                                                           progress_bar=False))
-report("hierarchical GMM, mean-field VI with per-row weights (mimo_estep_weighted, generic kernel, linear structure)", t, N * K,
+report("hierarchical GMM, mean-field VI with per-row weights (mimo_estep_weighted, linear structure)", t, N * K,
        N * K * (FEl + FSl), "flops of the linear form")
 
 t = per_iter(lambda it: full.meanfield_stochastic_descent(X, randomize=False, maxiter=it, batch_size=4096, progress_bar=False))
