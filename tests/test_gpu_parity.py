@@ -1058,3 +1058,15 @@ def test_streamed_label_kernel_many_steps(engine, D, K):
     assert np.array_equal(lab_p, ref_p)
     lab_q, Sq = engine.gibbs_labels(c, b, W, seed=3, sweep=7)
     assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx)
+
+
+@pytest.mark.parametrize("seed", [3])
+def test_random_shapes_structures_and_sizes_through_both_passes(engine, seed):
+    """tools/fuzz_parity.py in small: 50 random (Dz, K, structure, N) through the softmax pass (plain, weighted,
+    asynchronous, second launch) and the label pass (host uniforms, Philox, second launch) against the oracle — whatever
+    kernel family the router picks for the shape (a guard for the borders between the families)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    assert fuzz_parity.run(50, seed, eng=engine, max_rows=33000) == 0
