@@ -371,7 +371,7 @@ static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b,
 // statistics in one pass — few components over many features, MIMO_NARROW_FUSED_LABELS=0: off) or 0.
 static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool stats = true) {
   static const bool fused_labels = [] { const char* e = getenv("MIMO_NARROW_FUSED_LABELS"); return !e || atoi(e) != 0; }();
-  if (!plain || use_small(ctx, K)) return 0;
+  if (!plain) return 0;                 // (the small-shape kernel keeps the generic requests of its range and the shapes below narrow_covers' K)
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
   if (!gibbs) return narrow_covers(K, ctx->F, ctx->D, ZS, 0) ? 1 : 0;     // (rows with NaN: their mask is the row-weight vector of the pass)
   const bool two = narrow_covers(K, ctx->F, ctx->D, ZS, 1) && label_stats_covers(K, ctx->D, ctx->structure);
@@ -540,7 +540,7 @@ static int timed_launch(mimo_ctx* ctx, const char* name, L&& launch) {
 static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
   const int K = a.K, D = a.D;
   const int Kpad = a.K16 * 16;
-  const bool small = use_small(ctx, K);
+  const bool small = use_small(ctx, K) && ctx->narrow_call == 0;
   if (small) { a.F16_total = 16; a.F16 = 16; }
   const bool rowwave = src == kSrcEstep && ctx->rowwave_call;                       // label pass + label statistics
   const bool rowvi = src == kSrcEstep && ctx->rowwave_vi_call;                      // row-owner softmax + statistics pass
@@ -1492,13 +1492,13 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   memset(out8, 0, 8 * sizeof(int64_t));
   out8[4] = 1;                           // passes over Z
   out8[5] = gibbs ? 1 : 0;               // passes over the labels
-  if (use_small(ctx, K)) {
-    out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
-    out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
-  } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true)) {
+  if (const int nm = use_narrow(ctx, K, gibbs != 0, true)) {
     out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
     if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
     out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, nm - 1);
+  } else if (use_small(ctx, K)) {
+    out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
+    out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
   } else if (!gibbs && ctx->n_bad == 0 && ctx->D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     out8[6] = rowwave_grid(a, ctx->num_cu);

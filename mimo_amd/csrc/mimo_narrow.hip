@@ -80,7 +80,11 @@ void narrow_group_pos(int D, int a, int b, int* step, int* j) {
 // table).  MIMO_NARROW=0 switches the route off, MIMO_NARROW_MIN_K / MIMO_NARROW_MAX_K move its K range (tuning knobs).
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   static const bool on = [] { const char* e = getenv("MIMO_NARROW"); return !e || atoi(e) != 0; }();
-  static const int kmin = [] { const char* e = getenv("MIMO_NARROW_MIN_K"); return e ? atoi(e) : 33; }();
+  static const int kmin_env = [] { const char* e = getenv("MIMO_NARROW_MIN_K"); return e ? atoi(e) : 0; }();
+  // against the small-shape kernel (K <= 32 at Dz <= 2, K <= 16 at Dz = 3, 4) and the row-owner kernels behind it, N = 2e6, us per softmax
+  // pass / sweep (profiles/r03_small_vs_narrow.txt): Dz=2 K=16 57 / 79 against 59 / 88, K=20 112 / 156 against 77 / 112, K=32 113 / 159 against 95 / 124;
+  // Dz=3 K=12 86 / 146 against 61 / 88, K=24 171 / 166 against 87 / 130; Dz=4 K=8 55 / 81 against 59 / 91, K=16 110 / 163 against 83 / 105; Dz=1 K=32 83 / 126 against 73 / 110
+  const int kmin = kmin_env > 0 ? kmin_env : D <= 2 ? 17 : D == 3 ? 9 : 12;
   static const int kmax = [] { const char* e = getenv("MIMO_NARROW_MAX_K"); return e ? atoi(e) : 128; }();
   static const bool wide_on = [] { const char* e = getenv("MIMO_NARROW_WIDE"); return !e || atoi(e) != 0; }();
   static const int wide_kmax = [] { const char* e = getenv("MIMO_NARROW_WIDE_MAX_K"); return e ? atoi(e) : 0; }();
