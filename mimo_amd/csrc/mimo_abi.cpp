@@ -586,7 +586,10 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       });
       if (rc) return rc;
     } else if (narrow_g) {
+      static const bool fuse_on = [] { const char* e = getenv("MIMO_FUSE_LABEL_HIST"); return !e || atoi(e) != 0; }();
+      a.fuse_hist = fuse_on && a.do_stats && ctx->n_bad == 0 && a.aux && label_stats_uses_slots(K, D, a.N) ? 1 : 0;
       rc = timed_launch(ctx, "narrow_kernel", [&]() -> int {
+        if (a.fuse_hist) HIP_TRY(ctx, launch_label_hist_reset(a, ctx->stream));
         HIP_TRY(ctx, launch_narrow(a, ctx->F, 1, narrow_grid(a, ctx->num_cu, ctx->F, 1), ctx->stream));
         return MIMO_OK;
       });

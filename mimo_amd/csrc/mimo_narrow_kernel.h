@@ -146,6 +146,10 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
     for (int e = tid; e < 4 * NSF; e += kNarrowWG) ftab[e] = 8u * a.feat[2 * e] | (8u * a.feat[2 * e + 1]) << 16;
   if constexpr (DT > 0)                        // the zero slots behind [z, 1] (slot Dz + 1 is rewritten with every step)
     if (tid < 64) { Zall[(size_t)tid * ZS + DT + 2] = 0.0; Zall[(size_t)tid * ZS + DT + 3] = 0.0; }
+  // label pass with a.fuse_hist: the histogram of the labels drawn here, for the slot table of label_stats_slots_kernel behind it
+  // (as gibbs_rowwave_kernel: no label_hist_kernel pass over the labels)
+  __shared__ uint32_t hloc[MODE == 1 ? 256 : 1];
+  if constexpr (MODE == 1) hloc[tid] = 0u;
   wg_sync();
 
   const int64_t nsteps = (N + 15) / 16;
@@ -488,7 +492,11 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
       cnt += quad_i32<kQuadXor1>(cnt);
       cnt += quad_i32<kQuadXor2>(cnt);
       const int label = cnt < K ? cnt : K - 1;
-      if (lo == 0 && valid) a.labels[n1] = label;
+      if (lo == 0 && valid) {
+        a.labels[n1] = label;
+        if constexpr (MODE == 1)
+          if (a.fuse_hist) atomicAdd(&hloc[label], 1u);
+      }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (MODE == 2) {             // the one-hot row of the label (rows past N: every feature is zero)
 #pragma unroll
@@ -499,6 +507,12 @@ __global__ __launch_bounds__(kNarrowWG, narrow_waves(V, NSF, MODE)) void narrow_
     }
   }
 
+  if constexpr (MODE == 1) {
+    if (a.fuse_hist) {                       // (uniform)
+      wg_sync();
+      if (hloc[tid]) atomicAdd(&a.aux[tid], hloc[tid]);
+    }
+  }
   if constexpr (STATS) {
     // ---- per-workgroup partial block: the four blocks and the four waves added in a fixed order, GB accumulators at a time
     const int FT = a.F16_total, Kpad = a.K16 * 16;
