@@ -1071,3 +1071,36 @@ def test_random_shapes_structures_and_sizes_through_both_passes(engine, seed):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     assert fuzz_parity.run(50, seed, eng=engine, max_rows=33000) == 0
+
+
+@pytest.mark.parametrize("D,K", [(2, 50), (3, 12), (8, 4), (16, 8), (20, 4), (5, 40)])
+def test_rows_with_nan_on_the_narrow_kernels(engine, D, K):
+    """Rows that hold a NaN (section 4c of DESIGN.md: gaussian.py:493-494,512-520 of the reference) on the narrow kernels: the
+    softmax pass takes the row mask as its per-row weights (statistics without the rows, sum_n lse_n with them at z = 0), the
+    label pass draws every label and takes the statistics of the valid rows."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(8800 + 10 * D + K)
+    N = 20011
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    bad = rng.choice(N, size=37, replace=False)
+    Zn = Z.copy()
+    Zn[bad, rng.integers(0, D, size=bad.size)] = np.nan
+    mask = np.ones(N); mask[bad] = 0.
+    Zc = Z.copy(); Zc[bad] = 0.
+    engine.upload(Zn)
+    assert engine.n_bad == bad.size and engine.plan(K)["kind"] == "narrow"
+    L = O.canonical_eval(Zc, c, b, W)
+    lse = logsumexp(L, axis=0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Zc, R * mask[None, :])
+    S, sc = engine.estep(c, b, W)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    lab, G = engine.gibbs_labels(c, b, W, seed=4, sweep=2)
+    ref = O.sample_discrete_from_log(L, O.philox_uniforms(4, np.arange(N), 2))
+    assert np.array_equal(lab, ref)
+    gn, gsx, gsxx = O.packed_stats(Zc, O.one_hot(ref, K) * mask[None, :])
+    assert np.array_equal(G.n, gn) and rel_err(G.sx, gsx) < 1e-11 and rel_err(G.sxx, gsxx) < 1e-11
+    engine.upload(Z)
+    assert engine.n_bad == 0
