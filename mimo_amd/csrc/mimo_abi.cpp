@@ -76,6 +76,8 @@ struct mimo_ctx {
   unsigned long long* cnt_d = nullptr;                    // [1 + 256]: scan count, labels drawn on NaN rows per component
   int32_t* labels_tmp = nullptr; size_t labels_tmp_cap = 0;
   uint32_t* ls_aux = nullptr;                              // label histogram + slot table of label_stats_slots_kernel
+  uint16_t* sort_list = nullptr; size_t sort_list_cap = 0;   // tiles ranked once for a multi-launch label-statistics pass (label_tile_sort_kernel)
+  uint16_t* sort_start = nullptr; size_t sort_start_cap = 0;
   double* table_tmp = nullptr;  size_t table_tmp_cap = 0;
   int bad_counts_K = 0;         // > 0: cnt_d[1..K] holds the label counts of the NaN rows of the last label pass
 
@@ -535,6 +537,18 @@ static int timed_launch(mimo_ctx* ctx, const char* name, L&& launch) {
   return MIMO_OK;
 }
 
+// buffers of the presorted tiles for a label-statistics pass of several launches (Dz >= 10: windows / feature slices)
+static int prepare_label_presort(mimo_ctx* ctx, KernelArgs& a) {
+  a.sort_list = nullptr; a.sort_start = nullptr;
+  if (ctx->structure != 0 || a.D < 10 || label_stats_launches(a.K, a.D, ctx->structure) < 2 || a.N < 1) return MIMO_OK;
+  const size_t tiles128 = (size_t)((a.N + 127) / 128);
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->sort_list, &ctx->sort_list_cap, tiles128 * 128 + 256))) return rc;
+  if ((rc = ensure_dev(ctx, &ctx->sort_start, &ctx->sort_start_cap, tiles128 * 257 + 257))) return rc;
+  a.sort_list = ctx->sort_list; a.sort_start = ctx->sort_start;
+  return MIMO_OK;
+}
+
 // run the pass (one fused kernel, the two-stage sequence, or the small-shape kernel) -> reduce -> unpack;
 // deliver S / scalars to host or device pointers
 static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S, double* scalars) {
@@ -596,6 +610,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       if (rc) return rc;
     }
     if (a.do_stats) {
+      if ((rc = prepare_label_presort(ctx, a))) return rc;
       rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
         HIP_TRY(ctx, launch_label_stats(a, ctx->structure, grid, ctx->stream));
         return MIMO_OK;
@@ -673,6 +688,7 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       // label-indexed statistics of the labels just drawn: the HBM-bound pass instead of one-hot products per column group
       KernelArgs g = st;
       g.gibbs = 0; g.do_stats = 1; g.logp = nullptr; g.lse = nullptr;
+      if ((rc = prepare_label_presort(ctx, g))) return rc;
       rc = timed_launch(ctx, "label_stats_kernel", [&]() -> int {
         HIP_TRY(ctx, launch_label_stats(g, ctx->structure, grid, ctx->stream));
         return MIMO_OK;
@@ -841,7 +857,7 @@ int mimo_destroy(mimo_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   drain_profile(ctx);
   if (ctx->comm) { (void)mimo_comm::destroy(ctx->comm); ctx->comm = nullptr; }
-  void* bufs[] = {ctx->ls_aux, ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->row_mask, ctx->cnt_d, ctx->labels_tmp, ctx->table_tmp, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
+  void* bufs[] = {ctx->sort_list, ctx->sort_start, ctx->ls_aux, ctx->Z_owned, ctx->feat_d, ctx->feat_full_d, ctx->row_mask, ctx->cnt_d, ctx->labels_tmp, ctx->table_tmp, ctx->theta_d, ctx->partials, ctx->reduced, ctx->S_d, ctx->resp,
                   ctx->logp, ctx->lse, ctx->labels, ctx->u_d, ctx->win, ctx->lin};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (ctx->theta_h) (void)hipHostFree(ctx->theta_h);

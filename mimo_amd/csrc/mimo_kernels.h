@@ -50,6 +50,9 @@ struct KernelArgs {
   unsigned long long* stamps;  // diagnostic builds (-DMIMO_STAMPS) only: [grid][4 waves][8] phase cycle sums
   double theta_inline[40];  // small-shape kernel with one lane per row (G = 1): Theta itself (kThetaInline doubles at most)
   uint32_t* aux;          // label_stats_slots_kernel: label histogram + slot table (label_stats_aux_words() words)
+  uint16_t* sort_list;    // label_tile_sort_kernel -> label_stats_wide / _xwide_kernel: per tile the rows in component order, [ntiles][T]
+  uint16_t* sort_start;   // ... and the first list position of every component, [ntiles][257] (entry 256: rows in the list)
+  int presort;            // the statistics launch reads sort_list / sort_start instead of ranking the tile's labels itself
   int k0;                 // label_stats_wide_kernel: first component of the launch's window (components k0 .. k0 + 127 of K > 128)
   int fuse_hist;          // gibbs_rowwave_kernel counts the labels it draws into aux[0 .. 255] (no label_hist_kernel behind it)
 };

@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
   static_assert(FP == 2 || FP == 4, "feature slices per component");
   __shared__ __align__(16) double Zt[T * ZS];
   __shared__ __align__(16) uint32_t bitmap[kWG * NW];
-  __shared__ uint16_t list[T];
+  __shared__ __align__(16) uint16_t list[T];
   __shared__ int start[kWG + 1];
   __shared__ int cnts[kWG];
   __shared__ int wsum[4];
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
       zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
     }
     const int64_t n = t * T + tid;
-    const int l = (n < N ? a.labels[n] : -1) - k0;
+    const int l = ((n < N && !a.presort) ? a.labels[n] : -1) - k0;
     lab = (l >= 0 && l < K) ? l : -1;       // outside the window (or outside [0, a.K): a caller's vector): skipped
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -1384,48 +1384,59 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_wide_kernel(const KernelAr
       const int e = tid + kWG * i;
       if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
     }
-    {
-      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
-#pragma unroll
-      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
-    }
-    const int l0 = lab;
-    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
-    wg_sync();
-    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
-    wg_sync();
-    int cntk = 0;
-    {
-      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
-#pragma unroll
-      for (int w = 0; w < NW / 4; ++w) {
-        const uint4 v = bm[w];
-        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    int st, cmine;
+    if (a.presort) {                   // (uniform) the tile was ranked once for all the launches: label_tile_sort_kernel
+      const uint16_t* sg = a.sort_start + (size_t)t * 257 + (k0);
+      const bool mine = myk < K;
+      const int s0 = mine ? (int)sg[myk] : 0, s1 = mine ? (int)sg[myk + 1] : 0;
+      if (tid < T / 2) reinterpret_cast<uint32_t*>(list)[tid] = reinterpret_cast<const uint32_t*>(a.sort_list + (size_t)t * T)[tid];
+      if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+      st = s0; cmine = s1 - s0;
+      wg_sync();
+    } else {
+      {
+        uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+  #pragma unroll
+        for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
       }
+      const int l0 = lab;
+      if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+      wg_sync();
+      if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+      wg_sync();
+      int cntk = 0;
+      {
+        const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+  #pragma unroll
+        for (int w = 0; w < NW / 4; ++w) {
+          const uint4 v = bm[w];
+          cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+      }
+      int incl = cntk;
+  #pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const int v = __shfl_up(incl, s);
+        if (lane >= s) incl += v;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      wg_sync();
+      int off = 0;
+  #pragma unroll
+      for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+      start[tid] = off + incl - cntk;
+      cnts[tid] = cntk;
+      wg_sync();
+      if (l0 >= 0) {
+        const uint32_t* bm = bitmap + l0 * NW;
+        const int wq = tid >> 5;
+        int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
+        for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+        list[start[l0] + rank] = (uint16_t)tid;
+      }
+      wg_sync();
+      st = start[myk]; cmine = cnts[myk];
     }
-    int incl = cntk;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const int v = __shfl_up(incl, s);
-      if (lane >= s) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    wg_sync();
-    int off = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
-    start[tid] = off + incl - cntk;
-    cnts[tid] = cntk;
-    wg_sync();
-    if (l0 >= 0) {
-      const uint32_t* bm = bitmap + l0 * NW;
-      const int wq = tid >> 5;
-      int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
-      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
-      list[start[l0] + rank] = (uint16_t)tid;
-    }
-    wg_sync();
-    const int st = start[myk], cmine = cnts[myk];
     for (int p = rpart; p < cmine; p += RP) {
       const int row = list[st + p];
       const double* zp = Zt + row * ZS;
@@ -1551,7 +1562,7 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelA
       zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
     }
     const int64_t n = t * T + tid;
-    const int l = (tid < T && n < N) ? a.labels[n] : -1;
+    const int l = (tid < T && n < N && !a.presort) ? a.labels[n] : -1;
     lab = l < K ? l : -1;
   };
   if (blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -1563,48 +1574,59 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelA
       const int e = tid + kWG * i;
       if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
     }
-    {
-      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
-#pragma unroll
-      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
-    }
-    const int l0 = lab;
-    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
-    wg_sync();
-    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
-    wg_sync();
-    int cntk = 0;
-    {
-      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
-#pragma unroll
-      for (int w = 0; w < NW / 4; ++w) {
-        const uint4 v = bm[w];
-        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    int st, cmine;
+    if (a.presort) {                   // (uniform) the tile was ranked once for all the launches: label_tile_sort_kernel
+      const uint16_t* sg = a.sort_start + (size_t)t * 257;
+      const bool mine = myk < K;
+      const int s0 = mine ? (int)sg[myk] : 0, s1 = mine ? (int)sg[myk + 1] : 0;
+      if (tid < T / 2) reinterpret_cast<uint32_t*>(list)[tid] = reinterpret_cast<const uint32_t*>(a.sort_list + (size_t)t * T)[tid];
+      if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+      st = s0; cmine = s1 - s0;
+      wg_sync();
+    } else {
+      {
+        uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+  #pragma unroll
+        for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
       }
+      const int l0 = lab;
+      if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+      wg_sync();
+      if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+      wg_sync();
+      int cntk = 0;
+      {
+        const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+  #pragma unroll
+        for (int w = 0; w < NW / 4; ++w) {
+          const uint4 v = bm[w];
+          cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+      }
+      int incl = cntk;
+  #pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const int v = __shfl_up(incl, s);
+        if (lane >= s) incl += v;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      wg_sync();
+      int off = 0;
+  #pragma unroll
+      for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+      start[tid] = off + incl - cntk;
+      cnts[tid] = cntk;
+      wg_sync();
+      if (l0 >= 0) {
+        const uint32_t* bm = bitmap + l0 * NW;
+        const int wq = tid >> 5;
+        int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
+        for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+        list[start[l0] + rank] = (uint16_t)tid;
+      }
+      wg_sync();
+      st = start[myk]; cmine = cnts[myk];
     }
-    int incl = cntk;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const int v = __shfl_up(incl, s);
-      if (lane >= s) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    wg_sync();
-    int off = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
-    start[tid] = off + incl - cntk;
-    cnts[tid] = cntk;
-    wg_sync();
-    if (l0 >= 0) {
-      const uint32_t* bm = bitmap + l0 * NW;
-      const int wq = tid >> 5;
-      int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
-      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
-      list[start[l0] + rank] = (uint16_t)tid;
-    }
-    wg_sync();
-    const int st = start[myk], cmine = cnts[myk];
     if (myslice < FPT)
       for (int p = rpart; p < cmine; p += RP)
       {
@@ -1671,6 +1693,81 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_xwide_kernel(const KernelA
     double* Ps = P_out + (size_t)a.K16 * 16 * FT;
     Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// The ranking of a tile's labels — bitmap per component, popcount ranks, prefix over the components, the rows in component order —
+// is the same in every launch of the sliced / windowed label statistics (2 .. 8 launches at Dz >= 10): it runs ONCE here, and the
+// launches read the list (2 bytes per row) and the per-component starts (257 x 2 bytes per tile) instead — two workgroup barriers
+// per tile instead of six.  T = the consumer's tile (128 or 256 rows).
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kWG) void label_tile_sort_kernel(const int32_t* __restrict__ labels, int64_t N, int K,
+                                                              uint16_t* __restrict__ list_out, uint16_t* __restrict__ start_out) {
+  constexpr int NW = T / 32;
+  __shared__ __align__(16) uint32_t bitmap[kWG * NW];
+  __shared__ int start[kWG + 1];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ntiles = (N + T - 1) / T;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t n = t * T + tid;
+    int l0 = (tid < T && n < N) ? labels[n] : -1;
+    if (l0 >= K) l0 = -1;
+    {
+      uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) bm[w] = uint4{0u, 0u, 0u, 0u};
+    }
+    wg_sync();
+    if (l0 >= 0) atomicOr(&bitmap[l0 * NW + (tid >> 5)], 1u << (tid & 31));
+    wg_sync();
+    int cntk = 0;
+    {
+      const uint4* bm = reinterpret_cast<const uint4*>(bitmap + tid * NW);
+#pragma unroll
+      for (int w = 0; w < NW / 4; ++w) {
+        const uint4 v = bm[w];
+        cntk += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    start[tid] = off + incl - cntk;
+    if (tid == kWG - 1) start[kWG] = off + incl;
+    wg_sync();
+    uint16_t* so = start_out + (size_t)t * 257;
+    so[tid] = (uint16_t)start[tid];
+    if (tid == 0) so[256] = (uint16_t)start[kWG];
+    if (l0 >= 0) {
+      const uint32_t* bm = bitmap + l0 * NW;
+      const int wq = tid >> 5;
+      int rank = __popc(bm[wq] & ((1u << (tid & 31)) - 1u));
+      for (int w = 0; w < wq; ++w) rank += __popc(bm[w]);
+      list_out[(size_t)t * T + start[l0] + rank] = (uint16_t)tid;
+    }
+    wg_sync();                           // bitmap / start are rewritten by the next tile
+  }
+}
+// rank the tiles of a.labels once for the launches of a multi-launch label-statistics pass (tile = rows per tile of the consumer)
+static hipError_t launch_label_tile_sort(const KernelArgs& a, int tile, int grid, hipStream_t stream) {
+  if (!a.sort_list || !a.sort_start) return hipErrorInvalidValue;
+  if (tile == 128) hipLaunchKernelGGL(label_tile_sort_kernel<128>, dim3(grid), dim3(kWG), 0, stream, a.labels, a.N, a.K, a.sort_list, a.sort_start);
+  else hipLaunchKernelGGL(label_tile_sort_kernel<256>, dim3(grid), dim3(kWG), 0, stream, a.labels, a.N, a.K, a.sort_list, a.sort_start);
+  return hipGetLastError();
+}
+static bool label_presort_on() {
+  static const bool on = [] { const char* e = getenv("MIMO_LABEL_PRESORT"); return !e || atoi(e) != 0; }();   // tuning knob
+  return on;
 }
 
 static bool xwide_on() {
@@ -1767,8 +1864,17 @@ static hipError_t launch_xwide(const KernelArgs& a, int grid, hipStream_t stream
   int Kp = 1;
   while (Kp < a.K) Kp <<= 1;
   const int P = kWG / Kp, FPL = P < FPT ? P : FPT;
+  // rank the tiles once for all the launches — from four launches on (profiles/r03_label_presort.txt, N = 2e6, statistics stage in ms without /
+  // with: Dz=32 K=128 (8 launches) 2.33 / 1.96, K=256 (16) 4.31 / 3.64, Dz=20 K=96 (4) 0.76 / 0.71, Dz=24 K=128 (4) 0.89 / 0.85; two launches
+  // lose the extra pass: Dz=32 K=64 0.95 / 1.01): the ranking is a small part of a launch, the z tile and the member loop are the rest
+  const bool presort = FPT / FPL >= 4 && label_presort_on() && a.sort_list && a.sort_start;
+  if (presort) {
+    e = launch_label_tile_sort(a, T, grid, stream);
+    if (e != hipSuccess) return e;
+  }
   for (int s0 = 0; s0 < FPT; s0 += FPL) {          // FPT / FPL launches into the same partial block
     KernelArgs g = a;
+    g.presort = presort ? 1 : 0;
     g.cb0 = s0;
     if (s0 > 0) g.write_scalars = 0;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), lds, stream, g);
@@ -1817,8 +1923,14 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
                                   label_stats_wide_kernel<16, 2>};
     fn = a.K <= 64 ? wide4[a.D - 10] : wide2[a.D - 10];
     if (a.K > 128) {                  // windows of 128 components, one launch each into the same partial block
+      const bool presort = label_presort_on() && a.sort_list && a.sort_start;
+      if (presort) {
+        hipError_t e = launch_label_tile_sort(a, kLsWideTile, grid, stream);
+        if (e != hipSuccess) return e;
+      }
       for (int k0 = 0; k0 < a.K; k0 += 128) {
         KernelArgs w = a;
+        w.presort = presort ? 1 : 0;
         w.k0 = k0;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, w);
       }
