@@ -1104,3 +1104,30 @@ def test_rows_with_nan_on_the_narrow_kernels(engine, D, K):
     assert np.array_equal(G.n, gn) and rel_err(G.sx, gsx) < 1e-11 and rel_err(G.sxx, gsxx) < 1e-11
     engine.upload(Z)
     assert engine.n_bad == 0
+
+
+@pytest.mark.parametrize("D,K", [(8, 256), (2, 64), (9, 40), (4, 128), (6, 17)])
+def test_label_kernels_that_count_their_labels(engine, D, K):
+    """N >= 2^17 rows, K >= 17, Dz <= 9: the statistics of the drawn labels come from label_stats_slots_kernel, whose slot table
+    is built from a histogram the label kernel counted itself (KernelArgs::fuse_hist: gibbs_rowwave_kernel, narrow_kernel) —
+    labels bit-exact, counts exact, statistics against the oracle, a second sweep bit-identical; the statistics of a caller's
+    label vector (histogram by label_hist_kernel) agree bit for bit with those of the sweep that drew the same labels (where the
+    sweep uses the same statistics kernel)."""
+    from oracle import mimo_oracle as O
+    N = 140003
+    rng = np.random.default_rng(9900 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    c = c + 3. * rng.standard_normal(K)                    # uneven component weights: uneven slot table
+    engine.upload(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    lab, G = engine.gibbs_labels(c, b, W, seed=6, sweep=1)
+    ref = O.sample_discrete_from_log(L, O.philox_uniforms(6, np.arange(N), 1))
+    assert np.array_equal(lab, ref)
+    gn, gsx, gsxx = O.packed_stats(Z, O.one_hot(ref, K))
+    assert np.array_equal(G.n, gn) and rel_err(G.sx, gsx) < 1e-11 and rel_err(G.sxx, gsxx) < 1e-11
+    lab2, G2 = engine.gibbs_labels(c, b, W, seed=6, sweep=1)
+    assert np.array_equal(lab2, lab) and np.array_equal(G2.sxx, G.sxx) and np.array_equal(G2.sx, G.sx)
+    S = engine.label_stats(lab, K)
+    assert np.array_equal(S.n, G.n) and rel_err(S.sxx, G.sxx) < 1e-12
+    if (D, K) != (6, 17):              # (6, 17): the sweep takes its statistics inside the narrow label kernel — another summation order
+        assert np.array_equal(S.sxx, G.sxx)
