@@ -540,7 +540,8 @@ static int timed_launch(mimo_ctx* ctx, const char* name, L&& launch) {
 // buffers of the presorted tiles for a label-statistics pass of several launches (Dz >= 10: windows / feature slices)
 static int prepare_label_presort(mimo_ctx* ctx, KernelArgs& a) {
   a.sort_list = nullptr; a.sort_start = nullptr;
-  if (ctx->structure != 0 || a.D < 10 || label_stats_launches(a.K, a.D, ctx->structure) < 2 || a.N < 1) return MIMO_OK;
+  if (ctx->structure != 0 || a.D < 10 || a.N < 1 ||
+      (label_stats_launches(a.K, a.D, ctx->structure) < 2 && !label_stats_sorted(a.K, a.D, ctx->structure))) return MIMO_OK;
   const size_t tiles128 = (size_t)((a.N + 127) / 128);
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->sort_list, &ctx->sort_list_cap, tiles128 * 128 + 256))) return rc;

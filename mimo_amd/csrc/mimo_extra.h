@@ -33,6 +33,7 @@ hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 
 // label statistics (mimo_rowwave.hip): launches of one pass — 1, or the slice groups of the Dz > 16 / large-K kernel
 int label_stats_launches(int K, int D, int structure);
+bool label_stats_sorted(int K, int D, int structure);       // the one-pass kernel over the ranked tiles serves the shape (needs the presort buffers)
 // ... and the slot-table variant for skewed label vectors (K >= 17, Dz <= 9, N >= 2^17): needs KernelArgs::aux
 bool label_stats_uses_slots(int K, int D, int64_t N);
 size_t label_stats_aux_words();

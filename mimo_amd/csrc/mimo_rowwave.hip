@@ -1770,6 +1770,179 @@ static bool label_presort_on() {
   return on;
 }
 
+// ------------------------------------------------------------------------------------------
+// Label statistics from the ranked tiles in ONE pass over Z whatever Dz is (label_stats_sorted_kernel, Dz = 17 .. 32; the sliced
+// kernel above reads Z once per launch, 2 .. 16 launches).  The thread <-> accumulator assignment is turned around: the 256 threads of
+// a workgroup share the FEATURES (at most three each: F <= 561) and walk the components one after the other — for component k the
+// rows of the workgroup's tile range are looked up in the ranked tiles (label_tile_sort_kernel: list + starts), gathered 32 at a time
+// into LDS, and every thread adds its features of those rows; then its sums go into the partial block.  Rows are taken in ascending
+// order, ranges in ascending order per workgroup, the blocks are reduced in block order: run-to-run bit-identical.
+// Per row: F products, 2 LDS reads each — the LDS pipe bounds the pass (~100 cycles per row and CU at Dz = 32), not HBM.
+// ------------------------------------------------------------------------------------------
+constexpr int kSortedRange = 80;                 // tiles (of 256 rows) per range at most (ids: 40 KB; N = 1e7 on 512 workgroups: 77)
+constexpr int kSortedBatch = 64;                 // rows gathered per step
+template <int DZ>
+__global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const KernelArgs a, int R) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2, NF = (F + kWG - 1) / kWG;
+  constexpr int T = kLsWideTile, B = kSortedBatch, ZS = (DZ + 2) | 1;
+  constexpr int GPT = (B * DZ + kWG - 1) / kWG;                      // gathered elements per thread and batch
+  __shared__ __align__(16) double zbuf[B * ZS];
+  __shared__ uint16_t ids[kSortedRange * T];                          // (tile in range) << 8 | row in tile: by component, rows ascending
+  __shared__ int kbase[kWG + 1];                                      // first position of every component in ids
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T, nranges = (ntiles + R - 1) / R;
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride;
+
+  // this thread's features f = tid + 256 j: the two factors inside a z~ row ([z, 1, 0]); none: the zero slot twice
+  int oa[NF], ob[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int f = tid + kWG * j;
+    oa[j] = f < F ? a.feat[2 * f] : DZ + 1;
+    ob[j] = f < F ? a.feat[2 * f + 1] : DZ + 1;
+  }
+  // rows / columns of the block no accumulator of this kernel reaches, the scalar slots
+  for (int e = tid; e < a.K16 * 16 * FT; e += kWG) {
+    const int k = e / FT, f = e - k * FT;
+    if (k >= K || f >= F) P[e] = 0.0;
+  }
+  if (tid == 0 && a.write_scalars) { double* Ps = P + (size_t)a.K16 * 16 * FT; Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0; }
+  if (tid < B) zbuf[tid * ZS + DZ + 1] = 0.0;          // the zero slot (padding features): written once
+
+  bool first = true;
+  for (int64_t rg = blockIdx.x; rg < nranges; rg += gridDim.x) {
+    const int64_t t0 = rg * R;
+    const int nt = (int)(ntiles - t0 < R ? ntiles - t0 : R);
+    // ---- the rows of the range by component (thread k = component k): counts, prefix over the components, ids
+    wg_sync();                                           // the previous range's readers of ids / kbase are done
+    int cntk = 0;
+    if (tid < K)
+      for (int t = 0; t < nt; ++t) {
+        const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
+        cntk += (int)sg[1] - (int)sg[0];
+      }
+    int incl = cntk;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int v = __shfl_up(incl, sft);
+      if (lane >= sft) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    int o = off + incl - cntk;
+    kbase[tid] = o;
+    if (tid == kWG - 1) kbase[kWG] = off + incl;
+    if (tid < K)
+      for (int t = 0; t < nt; ++t) {
+        const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
+        const int s0 = sg[0], c = (int)sg[1] - s0;
+        const uint16_t* lg = a.sort_list + (size_t)(t0 + t) * T + s0;
+        for (int m = 0; m < c; ++m) ids[o++] = (uint16_t)((t << 8) | lg[m]);
+      }
+    wg_sync();
+    if (first) {                                         // components without a row in the workgroup's first range: zero rows
+      for (int e = tid; e < K * F; e += kWG) {
+        const int k = e / F, f = e - k * F;
+        if (kbase[k + 1] == kbase[k]) P[(size_t)k * FT + f] = 0.0;
+      }
+    }
+    // ---- stream the rows (component order) in full batches of B; the next batch is in flight (global -> registers) while the
+    //      current one is accumulated from LDS; a batch is walked in segments of one component each, whose sums go into the block
+    //      when its last row is done
+    const int nrows = kbase[kWG];
+    double gz[GPT];
+    auto fetch = [&](int pos) {
+      const int nb = nrows - pos < B ? nrows - pos : B;
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int e = tid + kWG * i, r = e / DZ, col = e - r * DZ;
+        double v = 0.0;
+        if (e < B * DZ && r < nb) {
+          const int id = ids[pos + r];
+          const int64_t n = (t0 + (id >> 8)) * T + (id & 255);
+          v = a.Z[n * DZ + col];
+        }
+        gz[i] = v;
+      }
+    };
+    if (nrows > 0) fetch(0);
+    double acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[j] = 0.0;
+    int k = 0;
+    for (int pos = 0; pos < nrows; pos += B) {
+      const int nb = nrows - pos < B ? nrows - pos : B;
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int e = tid + kWG * i, r = e / DZ, col = e - r * DZ;
+        if (e < B * DZ) zbuf[r * ZS + col] = gz[i];
+      }
+      if (tid < B) zbuf[tid * ZS + DZ] = 1.0;
+      wg_sync();
+      if (pos + B < nrows) fetch(pos + B);
+      int r = 0;
+      while (r < nb) {                                   // (uniform control flow: kbase is the same for every thread)
+        while (kbase[k + 1] <= pos + r) ++k;             // the component of row pos + r (empty ones are stepped over)
+        const int kend = kbase[k + 1] - pos;             // its rows end here (batch-relative)
+        const int rend = kend < nb ? kend : nb;
+        const double* zr = zbuf + r * ZS;
+        for (; r < rend; ++r, zr += ZS) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) acc[j] = fma(zr[oa[j]], zr[ob[j]], acc[j]);
+        }
+        if (kend <= nb) {                                // component k is complete: first range writes, later ranges add
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int f = tid + kWG * j;
+            if (f < F) {
+              double* q = P + (size_t)k * FT + f;
+              *q = first ? acc[j] : *q + acc[j];
+            }
+            acc[j] = 0.0;
+          }
+        }
+      }
+      wg_sync();
+    }
+    first = false;
+  }
+  if (first) {                                           // a workgroup without a range: an all-zero block
+    for (int e = tid; e < K * FT; e += kWG) {
+      const int k = e / FT, f = e - k * FT;
+      if (f < F) P[(size_t)k * FT + f] = 0.0;
+    }
+  }
+}
+static bool label_sorted_on() {
+  static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_SORTED"); return !e || atoi(e) != 0; }();   // tuning knob
+  return on;
+}
+static int label_sorted_min_d() {
+  static const int d = [] { const char* e = getenv("MIMO_LABEL_STATS_SORTED_MIN_D"); return e ? atoi(e) : 17; }();  // tuning knob
+  return d;
+}
+static bool label_stats_sorted_covers(int K, int D) { return label_sorted_on() && D >= label_sorted_min_d() && D >= 10 && D <= kMaxD && K >= 1 && K <= 256; }
+template <int DZ>
+static hipError_t launch_sorted(const KernelArgs& a, int grid, hipStream_t stream) {
+  hipError_t e = launch_label_tile_sort(a, kLsWideTile, grid, stream);
+  if (e != hipSuccess) return e;
+  const int64_t ntiles = (a.N + kLsWideTile - 1) / kLsWideTile;
+  int R = (int)((ntiles + grid - 1) / (grid > 0 ? grid : 1));            // one range per workgroup where the cap allows (no second round for a few)
+  R = R < 1 ? 1 : R > kSortedRange ? kSortedRange : R;
+  hipLaunchKernelGGL(label_stats_sorted_kernel<DZ>, dim3(grid), dim3(kWG), 0, stream, a, R);
+  return hipGetLastError();
+}
+
+bool label_stats_sorted(int K, int D, int structure) { return structure == 0 && label_stats_sorted_covers(K, D); }
+
 static bool xwide_on() {
   static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_XWIDE"); return !e || atoi(e) != 0; }();   // tuning knob
   return on;
@@ -1791,7 +1964,9 @@ bool label_stats_covers(int K, int D, int structure) {
 }
 
 // launches of one statistics pass (each reads Z once): 1, or the slice groups of label_stats_xwide_kernel
+bool label_stats_sorted(int K, int D, int structure);
 int label_stats_launches(int K, int D, int structure) {
+  if (label_stats_sorted(K, D, structure)) return 1;
   if (structure == 0 && D > 9 && label_stats_wide_covers(K, D)) return K <= 64 ? 1 : (K + 127) / 128;
   if (structure != 0 || D <= 9) return 1;
   const int fpt = xwide_fpt(D, K);
@@ -1910,6 +2085,14 @@ hipError_t launch_label_stats(const KernelArgs& a, int structure, int grid, hipS
     hipLaunchKernelGGL(label_slots_kernel, dim3(1), dim3(kWG), 0, stream, a.aux, a.K);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), 0, stream, a);
     return hipGetLastError();
+  }
+  if (structure == 0 && a.sort_list && a.sort_start && label_stats_sorted_covers(a.K, a.D)) {
+    switch (a.D) {
+#define MIMO_SD(d) case d: return launch_sorted<d>(a, grid, stream);
+      MIMO_SD(10) MIMO_SD(11) MIMO_SD(12) MIMO_SD(13) MIMO_SD(14) MIMO_SD(15) MIMO_SD(16) MIMO_SD(17) MIMO_SD(18) MIMO_SD(19) MIMO_SD(20)
+      MIMO_SD(21) MIMO_SD(22) MIMO_SD(23) MIMO_SD(24) MIMO_SD(25) MIMO_SD(26) MIMO_SD(27) MIMO_SD(28) MIMO_SD(29) MIMO_SD(30) MIMO_SD(31) MIMO_SD(32)
+#undef MIMO_SD
+    }
   }
   if (structure == 1) fn = pick_label_stats_struct<1>(a.D);
   else if (structure == 2) fn = pick_label_stats_struct<2>(a.D);
