@@ -1954,12 +1954,14 @@ static bool label_stats_wide_covers(int K, int D) {
   static const bool all = [] { const char* e = getenv("MIMO_LABEL_STATS_WIDE_ALL"); return !e || atoi(e) != 0; }();
   return D >= 10 && D <= 16 && (all || K <= 64 || (K <= 128 && D <= 12));
 }
+static bool label_stats_sorted_covers(int K, int D);
 bool label_stats_covers(int K, int D, int structure) {
   if (K < rowwave_min_k() || K > 256 || D < 1) return false;
   if (structure != 0) return D <= 16;            // reduced maps (diagonal / linear): at most 2 Dz + 1 accumulators
   if (D <= 9 || label_stats_wide_covers(K, D)) return true;
   // (K <= 16 at Dz > 16: one launch of 16-thread-per-component slices measured 0.71 against 0.61 ms of the one-hot products,
   //  Dz = 20, K = 16, N = 2e6; from K = 24 on the sliced kernel wins: Dz = 24, K = 24 0.80 / 1.20 ms, Dz = 32, K = 128 1.50 / 2.41 ms)
+  if (label_stats_sorted_covers(K, D)) return true;        // (the one-pass kernel takes any K; defined below)
   return xwide_on() && D <= kMaxD && K > 16;
 }
 
