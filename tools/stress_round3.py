@@ -16,7 +16,8 @@ for (N, D, K) in ((400003, 2, 50), (300007, 1, 100), (250013, 4, 128), (300011, 
                   (300007, 8, 4), (250007, 16, 4), (200003, 12, 13), (260003, 5, 24), (200003, 16, 16),   # table-driven / grouped loops
                   (150011, 24, 8), (120007, 32, 4), (130003, 20, 3), (140009, 28, 2),                      # Dz > 16: one wave per SIMD
                   (3 * 8 * 256 * 16 + 9, 8, 256), (600011, 9, 200), (500009, 6, 40),                        # slot-table label statistics
-                  (150011, 16, 128), (130003, 20, 64), (120007, 12, 256), (100003, 24, 96), (90001, 32, 128)):   # streamed label kernel
+                  (150011, 16, 128), (130003, 20, 64), (120007, 12, 256), (100003, 24, 96), (90001, 32, 128),    # streamed label kernel
+                  (700001, 20, 12), (650003, 32, 200), (1200007, 17, 40)):            # one-pass label statistics over several ranges per workgroup
     rng = np.random.default_rng(N % 1000 + D + K)
     Z = rng.standard_normal((N, D)) * 1.5; A = rng.standard_normal((K, D, D))
     W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D); mu = rng.standard_normal((K, D)) * 2
