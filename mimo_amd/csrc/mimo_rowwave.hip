@@ -1858,8 +1858,8 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
     //      current one is accumulated from LDS; a batch is walked in segments of one component each, whose sums go into the block
     //      when its last row is done
     const int nrows = kbase[kWG];
-    double gz[GPT];
-    auto fetch = [&](int pos) {
+    double gz[2][GPT];                                   // two batches in flight ahead of the one in LDS
+    auto fetch = [&](int pos, double (&g)[GPT]) {
       const int nb = nrows - pos < B ? nrows - pos : B;
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
@@ -1870,24 +1870,25 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
           const int64_t n = (t0 + (id >> 8)) * T + (id & 255);
           v = a.Z[n * DZ + col];
         }
-        gz[i] = v;
+        g[i] = v;
       }
     };
-    if (nrows > 0) fetch(0);
+    if (nrows > 0) fetch(0, gz[0]);
+    if (nrows > B) fetch(B, gz[1]);
     double acc[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[j] = 0.0;
     int k = 0;
-    for (int pos = 0; pos < nrows; pos += B) {
+    auto step = [&](int pos, double (&g)[GPT]) {         // batch at pos: its rows sit in g; g is refilled with the batch two ahead
       const int nb = nrows - pos < B ? nrows - pos : B;
 #pragma unroll
       for (int i = 0; i < GPT; ++i) {
         const int e = tid + kWG * i, r = e / DZ, col = e - r * DZ;
-        if (e < B * DZ) zbuf[r * ZS + col] = gz[i];
+        if (e < B * DZ) zbuf[r * ZS + col] = g[i];
       }
       if (tid < B) zbuf[tid * ZS + DZ] = 1.0;
       wg_sync();
-      if (pos + B < nrows) fetch(pos + B);
+      if (pos + 2 * B < nrows) fetch(pos + 2 * B, g);
       int r = 0;
       while (r < nb) {                                   // (uniform control flow: kbase is the same for every thread)
         while (kbase[k + 1] <= pos + r) ++k;             // the component of row pos + r (empty ones are stepped over)
@@ -1911,6 +1912,10 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
         }
       }
       wg_sync();
+    };
+    for (int pos = 0; pos < nrows; pos += 2 * B) {
+      step(pos, gz[0]);
+      if (pos + B < nrows) step(pos + B, gz[1]);
     }
     first = false;
   }
