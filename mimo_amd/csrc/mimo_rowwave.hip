@@ -1821,11 +1821,13 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
     // ---- the rows of the range by component (thread k = component k): counts, prefix over the components, ids
     wg_sync();                                           // the previous range's readers of ids / kbase are done
     int cntk = 0;
-    if (tid < K)
+    if (tid < K) {                                       // = start[last tile][..] differences summed: independent loads, eight tiles in flight
+#pragma unroll 8
       for (int t = 0; t < nt; ++t) {
         const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
         cntk += (int)sg[1] - (int)sg[0];
       }
+    }
     int incl = cntk;
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) {
@@ -1841,11 +1843,29 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
     kbase[tid] = o;
     if (tid == kWG - 1) kbase[kWG] = off + incl;
     if (tid < K)
-      for (int t = 0; t < nt; ++t) {
-        const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
-        const int s0 = sg[0], c = (int)sg[1] - s0;
-        const uint16_t* lg = a.sort_list + (size_t)(t0 + t) * T + s0;
-        for (int m = 0; m < c; ++m) ids[o++] = (uint16_t)((t << 8) | lg[m]);
+      for (int tb = 0; tb < nt; tb += 4) {               // four tiles' starts (and first list entries) in flight before they are used
+        int s0[4], c[4];
+        uint16_t l0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i < nt ? tb + i : nt - 1;
+          const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
+          s0[i] = sg[0]; c[i] = tb + i < nt ? (int)sg[1] - s0[i] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i < nt ? tb + i : nt - 1;
+          l0[i] = c[i] > 0 ? a.sort_list[(size_t)(t0 + t) * T + s0[i]] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i;
+          if (c[i] > 0) {
+            ids[o++] = (uint16_t)((t << 8) | l0[i]);
+            const uint16_t* lg = a.sort_list + (size_t)(t0 + t) * T + s0[i];
+            for (int m = 1; m < c[i]; ++m) ids[o++] = (uint16_t)((t << 8) | lg[m]);
+          }
+        }
       }
     wg_sync();
     if (first) {                                         // components without a row in the workgroup's first range: zero rows
