@@ -1073,7 +1073,7 @@ def test_random_shapes_structures_and_sizes_through_both_passes(engine, seed):
     assert fuzz_parity.run(50, seed, eng=engine, max_rows=33000) == 0
 
 
-@pytest.mark.parametrize("D,K", [(2, 50), (3, 12), (8, 4), (16, 8), (20, 4), (5, 40)])
+@pytest.mark.parametrize("D,K", [(2, 50), (3, 12), (8, 4), (16, 8), (20, 4), (5, 40), (20, 40), (32, 100), (24, 12)])
 def test_rows_with_nan_on_the_narrow_kernels(engine, D, K):
     """Rows that hold a NaN (section 4c of DESIGN.md: gaussian.py:493-494,512-520 of the reference) on the narrow kernels: the
     softmax pass takes the row mask as its per-row weights (statistics without the rows, sum_n lse_n with them at z = 0), the
@@ -1089,7 +1089,8 @@ def test_rows_with_nan_on_the_narrow_kernels(engine, D, K):
     mask = np.ones(N); mask[bad] = 0.
     Zc = Z.copy(); Zc[bad] = 0.
     engine.upload(Zn)
-    assert engine.n_bad == bad.size and engine.plan(K)["kind"] == "narrow"
+    # ((20, 40), (32, 100), (24, 12): streamed label kernel + one-pass label statistics over the masked labels, two-stage softmax pass)
+    assert engine.n_bad == bad.size and (engine.plan(K)["kind"] == "narrow" or (D > 16 and K > 8))
     L = O.canonical_eval(Zc, c, b, W)
     lse = logsumexp(L, axis=0)
     R = np.exp(L - lse)
