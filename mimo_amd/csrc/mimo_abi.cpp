@@ -324,8 +324,9 @@ static bool use_rowwave(const mimo_ctx* ctx, int K, bool wants_tables) {
 // Theta image of the row-owner label kernel: [NS][KB][64]; component k sits in A-row (k / V) + 4 (k % 4) of row block
 // (k % V) / 4, V = 4 KB, so that an output lane holds a contiguous quarter of the components (gibbs_rowwave_kernel)
 static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, KB = rowwave_kb(K), V = 4 * KB;
+  const int D = ctx->D;
   const int ZSk = (K + 15) / 16 > 12 ? D + 2 : ((D + 2) | 1);      // as fill_args
+  const int KB = rowwave_kb_shape(K, ctx->F16, ZSk), V = 4 * KB;
   const int NS = rowwave_image_ns(K, ctx->F16, ZSk);                // (whole chunks where the label kernel streams Theta)
   const size_t count = (size_t)NS * KB * 64;
   int rc;

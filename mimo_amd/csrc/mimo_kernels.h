@@ -109,6 +109,7 @@ hipError_t launch_small(const KernelArgs& a, int src, int grid, hipStream_t stre
 // the label-indexed statistics kernel.  theta: [NS][KB][64] with the component permutation of rowwave_component().
 size_t rowwave_lds_bytes(int KB, int NS, int ZS);
 int rowwave_kb(int K);
+int rowwave_kb_shape(int K, int F16, int ZS);     // ... for the shape (the streamed walk may take two more than rowwave_kb)
 bool rowwave_covers(int K, int F16, int ZS);
 int rowwave_image_ns(int K, int F16, int ZS);     // contraction steps of the operand image (padded to whole chunks where Theta streams)
 int rowwave_grid(const KernelArgs& a, int num_cu);

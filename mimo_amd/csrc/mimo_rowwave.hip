@@ -480,16 +480,23 @@ static bool rowwave_resident(int K, int F16, int ZS) {
   if (F16 > 64 && !(kb <= 4 || (kb <= 8 && F16 <= 96))) return false;
   return rowwave_lds_bytes(kb, F16 / 4, ZS) + 1024 <= 160 * 1024;      // (+ the kernel's static 1 KB label histogram)
 }
+// Row blocks for the shape: rowwave_kb(K), except that the streamed walk of 193 <= K <= 224 (14 row blocks: chunks of 8 steps = 57 KB,
+// two of them + the z rows of Dz >= 25 do not fit 160 KB) runs with 16 (chunks of 6 steps = 49 KB) — 14 % more matrix work, no table
+int rowwave_kb_shape(int K, int F16, int ZS) {
+  const int kb = rowwave_kb(K);
+  if (kb == 14 && !rowwave_resident(K, F16, ZS) && stream_lds_bytes(14, F16, ZS) > 160 * 1024) return 16;
+  return kb;
+}
 // ... and beyond that, up to Dz = 32 (F16 <= 576), with Theta streamed through LDS (MIMO_ROWWAVE_STREAM=0: off, tuning knob)
 static bool rowwave_streams(int K, int F16, int ZS) {
   static const bool on = [] { const char* e = getenv("MIMO_ROWWAVE_STREAM"); return !e || atoi(e) != 0; }();
   if (!on || K < rowwave_min_k() || K > 256 || F16 > 576 || rowwave_resident(K, F16, ZS)) return false;
-  return stream_lds_bytes(rowwave_kb(K), F16, ZS) <= 160 * 1024;
+  return stream_lds_bytes(rowwave_kb_shape(K, F16, ZS), F16, ZS) <= 160 * 1024;
 }
 bool rowwave_covers(int K, int F16, int ZS) { return rowwave_resident(K, F16, ZS) || rowwave_streams(K, F16, ZS); }
 // contraction steps the operand image must hold for (K, F16): F16 / 4, or whole chunks of the streamed walk
 int rowwave_image_ns(int K, int F16, int ZS) {
-  return rowwave_streams(K, F16, ZS) ? stream_ns_pad(rowwave_kb(K), F16) : F16 / 4;
+  return rowwave_streams(K, F16, ZS) ? stream_ns_pad(rowwave_kb_shape(K, F16, ZS), F16) : F16 / 4;
 }
 
 typedef void (*rowwave_fn)(const KernelArgs);
@@ -554,7 +561,7 @@ static stream_fn pick_stream(int kb) {
 
 hipError_t launch_gibbs_rowwave(const KernelArgs& a, int grid, hipStream_t stream) {
   if (rowwave_streams(a.K, a.F16, a.ZS)) {
-    const int kb = rowwave_kb(a.K);
+    const int kb = rowwave_kb_shape(a.K, a.F16, a.ZS);
     stream_fn fn = 16 * a.D <= 256 ? pick_stream<4>(kb) : pick_stream<8>(kb);
     if (!fn || a.D > 32) return hipErrorInvalidValue;
     const size_t lds = stream_lds_bytes(kb, a.F16, a.ZS);

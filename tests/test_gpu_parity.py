@@ -1035,7 +1035,8 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
         assert not np.any(lab_o == K // 2) and Go.n[K // 2] == 0 and Go.n.sum() == N
 
 
-@pytest.mark.parametrize("D,K", [(16, 128), (12, 200), (20, 72), (16, 256), (32, 40), (24, 128)])
+@pytest.mark.parametrize("D,K", [(16, 128), (12, 200), (20, 72), (16, 256), (32, 40), (24, 128),
+                                 (28, 200), (32, 210), (25, 224)])     # 14 row blocks do not fit next to the z rows: run with 16
 def test_streamed_label_kernel_many_steps(engine, D, K):
     """gibbs_stream_kernel (the row-owner label kernel with Theta streamed through a double buffer in LDS: shapes whose operand
     image does not fit) over several workgroup steps per workgroup — the cyclic walk of the chunks across step boundaries, both
