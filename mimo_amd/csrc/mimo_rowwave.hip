@@ -1976,7 +1976,12 @@ static int label_sorted_min_d() {
   static const int d = [] { const char* e = getenv("MIMO_LABEL_STATS_SORTED_MIN_D"); return e ? atoi(e) : 17; }();  // tuning knob
   return d;
 }
-static bool label_stats_sorted_covers(int K, int D) { return label_sorted_on() && D >= label_sorted_min_d() && D >= 10 && D <= kMaxD && K >= 1 && K <= 256; }
+// Dz >= 17; and K > 128 from Dz = 15 (against the two windows of label_stats_wide_kernel, N = 2e6, ms: Dz=16 K=256 0.36 -> 0.27, K=192 0.32 -> 0.25,
+// Dz=15 K=160 0.26 -> 0.24; Dz=14 K=200 0.23 -> 0.25 and Dz=13 K=256 0.25 -> 0.26 stay windowed)
+static bool label_stats_sorted_covers(int K, int D) {
+  if (!label_sorted_on() || D < 10 || D > kMaxD || K < 1 || K > 256) return false;
+  return D >= label_sorted_min_d() || (D >= 15 && K > 128);
+}
 template <int DZ>
 static hipError_t launch_sorted(const KernelArgs& a, int grid, hipStream_t stream) {
   hipError_t e = launch_label_tile_sort(a, kLsWideTile, grid, stream);
