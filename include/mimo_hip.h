@@ -278,6 +278,10 @@ int mimo_comm_destroy(mimo_ctx* ctx);
 
 /* ---- copy-outs of device-resident tables ----------------------------------------------- */
 int mimo_get_resp(mimo_ctx* ctx, double* resp_host /* K×N */);
+/* The columns `cols[0 .. ncols)` (row indices of the data) of the resident responsibility table: out (K, ncols) row-major.  What a
+ * host-side correction over a few rows needs (the share of the rows with NaN in the gating counts: categorical.py:35-46 counts
+ * them, gaussian.py:493-494 drops them) without copying the (K, N) table.  MIMO_E_STATE without a resident table. */
+int mimo_get_resp_columns(mimo_ctx* ctx, const int64_t* cols, int64_t ncols, double* out);
 int mimo_get_logp(mimo_ctx* ctx, double* logp_host /* K×N */);
 int mimo_get_lse(mimo_ctx* ctx, double* lse_host /* N */);
 int mimo_get_labels(mimo_ctx* ctx, int32_t* labels_host /* N */);
@@ -324,10 +328,12 @@ int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, co
                        const double* z, const double* g, const double* eps,
                        double* out_mu, double* out_lmbda, double* out_c, double* out_b);
 
-/* Checksum over every byte of a host buffer: out[0] = wrapping sum, out[1] = xor of its 64-bit words (the last nbytes % 8 bytes
- * zero-extended) — memory-bandwidth bound, threaded above 8 MB.  What engine.bind() / the row-weight residency of the host mirror
- * key on, so that an in-place edit of a caller's array between two calls is seen (the reference re-reads its arguments on every
- * call: mimo/mixtures/gmm.py:62-75); any single-element edit changes it, a permutation of words does not. */
+/* Position-dependent checksum over every byte of a host buffer.  With w_i the 8-byte little-endian words (the last nbytes % 8
+ * bytes zero-extended), m_i = w_i ^ (w_i >> 32) and nw their number:  out[0] = sum_i m_i,  out[1] = sum_i (nw - i) m_i  (mod 2^64).
+ * Memory-bandwidth bound, threaded above 8 MB.  What engine.bind() / the row-weight residency of the host mirror key on, so
+ * that an in-place edit of a caller's array between two calls is seen (the reference re-reads its arguments on every call:
+ * mimo/mixtures/gmm.py:62-75): any edit of one word changes both sums, a swap of two unequal words (a row shuffle) changes
+ * out[1].  mimo_data_checksum returns the same function of the rows mimo_upload copied, computed on the device. */
 int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]);
 
 /* digamma used by the two routines above (recurrence + asymptotic series), for tests. */
@@ -366,6 +372,22 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_ROWWAVE_VI 5   /* softmax pass at K <= 64, Dz <= 9: row-owner kernel for both matrix products     */
 #define MIMO_PLAN_NARROW     6   /* Dz <= 4 with 32 < K <= 128: 4x4x4 matrix-instruction kernels (+ label statistics) */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
+
+/* Checksum of the rows as mimo_upload received them (before rows with NaN are zeroed in the library's copy): the function
+ * mimo_host_checksum defines, computed on the device inside the NaN scan of the upload (one read of Z either way).  A caller that
+ * keeps the host array can compare the two to learn whether the array was edited since the upload (engine.bind() does, on a
+ * helper thread under the first kernel of a call).  MIMO_E_STATE after mimo_attach (borrowed device rows: nothing was copied)
+ * or without data.  Reference counterpart: none — it re-reads the caller's array on every call (mimo/mixtures/gmm.py:261). */
+int mimo_data_checksum(mimo_ctx* ctx, uint64_t out[2]);
+
+/* Test / tuning hook: overrides a launch-geometry value for later calls.  Keys:
+ *   "num_cu"       (per context) the compute-unit count every persistent grid is sized from; 0 restores the device's own.
+ *                  A small value makes every workgroup of every kernel family walk many tiles / steps / ranges at test sizes.
+ *   "sorted_range" (process-wide) cap on the 256-row tiles per range of label_stats_sorted_kernel (default and maximum 80;
+ *                  0 restores it): with a low cap a workgroup takes several ranges ("first range writes, later ranges add").
+ * Results do not depend on either value beyond the documented summation order of the partial blocks.  MIMO_E_INVALID for
+ * an unknown key or a value out of range.  The reference has no counterpart (launch geometry is ours). */
+int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value);
 
 /* Test hook for the no-exception contract: throws, INSIDE the guarded boundary, kind 1: std::bad_alloc,
  * 2: std::runtime_error, 3: a non-std exception; returns the code the guard maps it to (MIMO_E_NOMEM,

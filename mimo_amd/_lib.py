@@ -51,6 +51,7 @@ SIGNATURES = {
     "mimo_predict_flags": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                      _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mimo_get_resp": (C.c_int, [_vp, _vp]),
+    "mimo_get_resp_columns": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "mimo_get_logp": (C.c_int, [_vp, _vp]),
     "mimo_get_lse": (C.c_int, [_vp, _vp]),
     "mimo_get_labels": (C.c_int, [_vp, _vp]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "mimo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mimo_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "mimo_comm_destroy": (C.c_int, [_vp]),
+    "mimo_tune": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "mimo_data_checksum": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "mimo_debug_fault": (C.c_int, [_vp, C.c_int]),
     "mimo_host_debug_fault": (C.c_int, [C.c_int]),
     "mimo_version": (C.c_char_p, []),

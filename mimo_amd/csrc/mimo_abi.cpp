@@ -28,7 +28,8 @@ int allreduce_sum_f64(void* comm, double* buf, size_t count, hipStream_t stream,
 
 struct mimo_ctx {
   int device = 0;
-  int num_cu = 256;
+  int num_cu = 256;       // what the grids are sized from (mimo_tune "num_cu" overrides it for tests)
+  int hw_num_cu = 256;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   char err[512] = {0};   // fixed buffer: reporting an error never allocates
@@ -73,7 +74,9 @@ struct mimo_ctx {
   // rows with missing values (NaN): zeroed in the owned copy, excluded from every statistic through the mask
   double* row_mask = nullptr;   size_t mask_cap = 0;      // (N,) 1 = complete row
   int64_t n_bad = 0;
-  unsigned long long* cnt_d = nullptr;                    // [1 + 256]: scan count, labels drawn on NaN rows per component
+  unsigned long long* cnt_d = nullptr;                    // [1 + 256 + 2]: scan count, labels drawn on NaN rows per component, content checksum of the upload
+  uint64_t data_sum[2] = {0, 0};                          // mimo_data_checksum: the rows as mimo_upload received them
+  bool data_sum_valid = false;
   int32_t* labels_tmp = nullptr; size_t labels_tmp_cap = 0;
   uint32_t* ls_aux = nullptr;                              // label histogram + slot table of label_stats_slots_kernel
   uint16_t* sort_list = nullptr; size_t sort_list_cap = 0;   // tiles ranked once for a multi-launch label-statistics pass (label_tile_sort_kernel)
@@ -836,7 +839,7 @@ int mimo_create(mimo_ctx** out, int device) {
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete ctx; return fail(nullptr, MIMO_E_HIP, "hipSetDevice failed"); }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = ctx->hw_num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return fail(nullptr, MIMO_E_HIP, "hipStreamCreate failed");
@@ -893,17 +896,26 @@ static int set_data(mimo_ctx* ctx, int64_t N, int Dz) {
 
 // Find the rows that hold a NaN.  `owned`: Z is the library's copy — such rows are zeroed in place and the mask written;
 // otherwise (borrowed device buffer) they are only counted, and if there are any the data is copied first.
-static int scan_nan_rows(mimo_ctx* ctx) {
+static int scan_nan_rows(mimo_ctx* ctx, bool checksum) {
   ctx->n_bad = 0; ctx->bad_counts_K = 0;
-  if (ctx->N <= 0) return MIMO_OK;
+  ctx->data_sum_valid = false;
+  if (ctx->N <= 0) {
+    if (checksum) { ctx->data_sum[0] = ctx->data_sum[1] = 0; ctx->data_sum_valid = true; }
+    return MIMO_OK;
+  }
   int rc;
-  if (!ctx->cnt_d) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->cnt_d), 257 * sizeof(unsigned long long)));
-  // flat scan first (one coalesced read of Z): data without a NaN — the usual case — is done after it
+  if (!ctx->cnt_d) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->cnt_d), 259 * sizeof(unsigned long long)));
+  // flat scan first (one coalesced read of Z): data without a NaN — the usual case — is done after it; the same read
+  // yields the content checksum of an upload (before any row is zeroed)
   HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
-  HIP_TRY(ctx, launch_nan_any(ctx->Z, ctx->N * ctx->D, reinterpret_cast<unsigned int*>(ctx->cnt_d), ctx->num_cu, ctx->stream));
+  if (checksum) HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d + 257, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, launch_nan_any(ctx->Z, ctx->N * ctx->D, reinterpret_cast<unsigned int*>(ctx->cnt_d), ctx->hw_num_cu, ctx->stream,
+                              checksum ? ctx->cnt_d + 257 : nullptr));
   unsigned long long nb = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&nb, ctx->cnt_d, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
+  if (checksum) HIP_TRY(ctx, hipMemcpyAsync(ctx->data_sum, ctx->cnt_d + 257, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->data_sum_valid = checksum;
   if (nb == 0) return MIMO_OK;
   HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d, 0, sizeof(unsigned long long), ctx->stream));
   HIP_TRY(ctx, launch_nan_scan(const_cast<double*>(ctx->Z), ctx->N, ctx->D, nullptr, ctx->cnt_d, false, ctx->stream));
@@ -935,7 +947,16 @@ int mimo_upload(mimo_ctx* ctx, const double* Z_host, int64_t N, int Dz) {
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->Z_owned), bytes));
   if (N > 0) HIP_TRY(ctx, hipMemcpy(ctx->Z_owned, Z_host, (size_t)N * Dz * sizeof(double), hipMemcpyHostToDevice));
   ctx->Z = ctx->Z_owned;
-  return scan_nan_rows(ctx);
+  return scan_nan_rows(ctx, true);
+  });
+}
+
+int mimo_data_checksum(mimo_ctx* ctx, uint64_t out[2]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !out) return fail(ctx, MIMO_E_INVALID, "mimo_data_checksum: null argument");
+  if (!ctx->Z || !ctx->data_sum_valid) return fail(ctx, MIMO_E_STATE, "mimo_data_checksum: no uploaded rows (attached device rows are not summed)");
+  out[0] = ctx->data_sum[0]; out[1] = ctx->data_sum[1];
+  return MIMO_OK;
   });
 }
 
@@ -947,7 +968,7 @@ int mimo_attach(mimo_ctx* ctx, const double* Z_dev, int64_t N, int Dz) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->Z_owned) { HIP_TRY(ctx, hipFree(ctx->Z_owned)); ctx->Z_owned = nullptr; }
   ctx->Z = Z_dev;
-  return scan_nan_rows(ctx);
+  return scan_nan_rows(ctx, false);
   });
 }
 
@@ -1348,6 +1369,25 @@ int mimo_get_resp(mimo_ctx* ctx, double* out) {
   return copy_out(ctx, out, ctx->resp, (size_t)ctx->resp_K * ctx->N * sizeof(double), ctx->resp_valid, "mimo_get_resp");
   });
 }
+int mimo_get_resp_columns(mimo_ctx* ctx, const int64_t* cols, int64_t ncols, double* out) {
+  return guarded(ctx, [&]() -> int {
+  int rc = bind(ctx); if (rc) return rc;
+  if (ncols < 0 || (ncols > 0 && (!cols || !out))) return fail(ctx, MIMO_E_INVALID, "mimo_get_resp_columns: bad arguments");
+  if (!ctx->resp_valid || !ctx->resp) return fail(ctx, MIMO_E_STATE, "mimo_get_resp_columns: no responsibility table is resident");
+  if (ncols == 0) return MIMO_OK;
+  for (int64_t j = 0; j < ncols; ++j)
+    if (cols[j] < 0 || cols[j] >= ctx->N) return fail(ctx, MIMO_E_INVALID, "mimo_get_resp_columns: column %lld outside [0, N)", (long long)cols[j]);
+  const size_t K = (size_t)ctx->resp_K, words = (size_t)ncols + K * (size_t)ncols;      // indices | gathered block, in the staged-labels / weights workspace
+  if ((rc = ensure_dev(ctx, &ctx->table_tmp, &ctx->table_tmp_cap, words))) return rc;
+  int64_t* cols_d = reinterpret_cast<int64_t*>(ctx->table_tmp);
+  double* out_d = ctx->table_tmp + ncols;
+  HIP_TRY(ctx, hipMemcpyAsync(cols_d, cols, (size_t)ncols * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch_gather_columns(ctx->resp, (int)K, ctx->N, cols_d, ncols, out_d, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out, out_d, K * (size_t)ncols * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIMO_OK;
+  });
+}
 int mimo_get_logp(mimo_ctx* ctx, double* out) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return fail(nullptr, MIMO_E_INVALID, "null context");
@@ -1453,6 +1493,24 @@ int mimo_debug_fault(mimo_ctx* ctx, int kind) {
     if (kind == 2) throw std::runtime_error("mimo_debug_fault");
     if (kind == 3) throw 42;
     return kind == 0 ? MIMO_OK : fail(ctx, MIMO_E_INVALID, "mimo_debug_fault: unknown kind %d", kind);
+  });
+}
+
+int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value) {
+  return guarded(ctx, [&]() -> int {
+    if (!ctx || !key) return fail(ctx, MIMO_E_INVALID, "mimo_tune: null argument");
+    if (ctx->pending_async) return fail(ctx, MIMO_E_STATE, "an asynchronous call is pending: call mimo_wait first");
+    if (!strcmp(key, "num_cu")) {
+      if (value < 0 || value > 4096) return fail(ctx, MIMO_E_INVALID, "mimo_tune: num_cu = %lld outside [0, 4096]", (long long)value);
+      ctx->num_cu = value == 0 ? ctx->hw_num_cu : (int)value;
+      return MIMO_OK;
+    }
+    if (!strcmp(key, "sorted_range")) {
+      if (value < 0 || value > 80) return fail(ctx, MIMO_E_INVALID, "mimo_tune: sorted_range = %lld outside [0, 80]", (long long)value);
+      set_sorted_range_cap((int)value);
+      return MIMO_OK;
+    }
+    return fail(ctx, MIMO_E_INVALID, "mimo_tune: unknown key '%s'", key);
   });
 }
 

@@ -13,11 +13,14 @@ hipError_t launch_sample_table(const double* logp, int K, int64_t N, const doubl
 hipError_t launch_random_resp(double* resp, int K, int64_t N, uint64_t seed, int64_t row0, hipStream_t stream);
 
 // rows with missing values (mimo_small.hip): scan (+ zero the rows and write the mask when `write`), masked labels / tables
-hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream);   // flag |= 1 if any element is a NaN
+// flag |= 1 if any element is a NaN; sums (or null): += the content checksum of mimo_host_checksum (two 64-bit words, zeroed by the caller)
+hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream, unsigned long long* sums = nullptr);
 hipError_t launch_nan_scan(double* Z, int64_t N, int D, double* mask, unsigned long long* count, bool write, hipStream_t stream);
 hipError_t launch_mask_labels(const int32_t* labels, const double* mask, int32_t* out, int64_t N, int K,
                               unsigned long long* bad_counts, hipStream_t stream);
 hipError_t launch_mask_table(const double* table, const double* mask, double* out, int K, int64_t N, hipStream_t stream);
+
+hipError_t launch_gather_columns(const double* table, int K, int64_t N, const int64_t* cols, int64_t ncols, double* out, hipStream_t stream);
 
 // shader clock under float64 load (mimo_small.hip): out[2 g] = shader-clock ticks, out[2 g + 1] = 100 MHz ticks of workgroup g
 hipError_t launch_clock_probe(unsigned long long* out, int grid, int iters, hipStream_t stream);
@@ -34,6 +37,7 @@ hipError_t launch_wide_estep(const KernelArgs& a, int grid, hipStream_t stream);
 // label statistics (mimo_rowwave.hip): launches of one pass — 1, or the slice groups of the Dz > 16 / large-K kernel
 int label_stats_launches(int K, int D, int structure);
 bool label_stats_sorted(int K, int D, int structure);       // the one-pass kernel over the ranked tiles serves the shape (needs the presort buffers)
+void set_sorted_range_cap(int tiles);                        // tiles per range of the one-pass kernel at most (mimo_tune "sorted_range"; 0: default)
 // ... and the slot-table variant for skewed label vectors (K >= 17, Dz <= 9, N >= 2^17): needs KernelArgs::aux
 bool label_stats_uses_slots(int K, int D, int64_t N);
 size_t label_stats_aux_words();

@@ -388,11 +388,18 @@ int mimo_host_nw_gibbs(int K, int D, const double* mus, const double* kappas, co
   });
 }
 
+// Position-dependent content checksum of a byte range, the same function the device computes over the resident rows
+// (nan_any_kernel in mimo_small.hip: mimo_data_checksum).  Words w_i = the 8-byte little-endian words (the last one
+// zero-extended), m_i = w_i ^ (w_i >> 32) (a bijection that carries the high half — where "round" doubles such as 0.0, 1.0, 2.0
+// differ — into the low bits), nw = their number:
+//     out[0] = sum_i m_i              out[1] = sum_i (nw - i) m_i          (mod 2^64)
+// Any edit of one word changes both; a swap of two unequal words changes out[1] (their distance is below 2^32 words); sums
+// mod 2^64 do not depend on how the range is cut into slices or in which order the slices are added.
 int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]) {
   return guarded_host([&]() -> int {
   if ((!data && nbytes) || !out) return MIMO_E_INVALID;
   const unsigned char* p = static_cast<const unsigned char*>(data);
-  const size_t nw = nbytes / 8;
+  const size_t nfull = nbytes / 8, nw = (nbytes + 7) / 8;
   // slices of whole words; a thread per ~4 MB, at most 8 (a thread costs ~15 us to start: 1 MB of streaming)
   int nt = (int)std::min<size_t>(8, nbytes / ((size_t)4 << 20));
   {
@@ -401,18 +408,20 @@ int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]) {
   }
   std::vector<uint64_t> part((size_t)2 * nt, 0);
   auto run = [&](int t) noexcept {
-    const size_t w0 = nw * (size_t)t / nt, w1 = nw * (size_t)(t + 1) / nt;
-    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    const size_t w0 = nfull * (size_t)t / nt, w1 = nfull * (size_t)(t + 1) / nt;
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     size_t w = w0;
-    for (; w + 4 <= w1; w += 4) {
+    uint64_t wt = (uint64_t)(nw - w0);           // weight of word w
+    for (; w + 4 <= w1; w += 4, wt -= 4) {
       uint64_t v[4];
       memcpy(v, p + 8 * w, 32);                  // (unaligned-safe; compiles to vector loads)
-      s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
-      x0 ^= v[0]; x1 ^= v[1]; x2 ^= v[2]; x3 ^= v[3];
+      const uint64_t m0 = v[0] ^ (v[0] >> 32), m1 = v[1] ^ (v[1] >> 32), m2 = v[2] ^ (v[2] >> 32), m3 = v[3] ^ (v[3] >> 32);
+      a0 += m0; a1 += m1; a2 += m2; a3 += m3;
+      b0 += m0 * wt; b1 += m1 * (wt - 1); b2 += m2 * (wt - 2); b3 += m3 * (wt - 3);
     }
-    for (; w < w1; ++w) { uint64_t v; memcpy(&v, p + 8 * w, 8); s0 += v; x0 ^= v; }
-    part[2 * t] = s0 + s1 + s2 + s3;
-    part[2 * t + 1] = x0 ^ x1 ^ x2 ^ x3;
+    for (; w < w1; ++w, --wt) { uint64_t v; memcpy(&v, p + 8 * w, 8); const uint64_t m = v ^ (v >> 32); a0 += m; b0 += m * wt; }
+    part[2 * t] = a0 + a1 + a2 + a3;
+    part[2 * t + 1] = b0 + b1 + b2 + b3;
   };
   std::vector<std::thread> th;
   int started = 1;
@@ -425,12 +434,16 @@ int mimo_host_checksum(const void* data, size_t nbytes, uint64_t out[2]) {
   run(0);
   for (int t = started; t < nt; ++t) run(t);
   for (auto& x : th) x.join();
-  uint64_t sum = 0, xr = 0;
-  for (int t = 0; t < nt; ++t) { sum += part[2 * t]; xr ^= part[2 * t + 1]; }
-  uint64_t tail = 0;                              // the last nbytes % 8 bytes, zero-extended
-  memcpy(&tail, p + 8 * nw, nbytes - 8 * nw);
-  out[0] = sum + tail;
-  out[1] = xr ^ tail;
+  uint64_t A = 0, B = 0;
+  for (int t = 0; t < nt; ++t) { A += part[2 * t]; B += part[2 * t + 1]; }
+  if (nw > nfull) {                               // the last nbytes % 8 bytes, zero-extended: word nw - 1, weight 1
+    uint64_t tail = 0;
+    memcpy(&tail, p + 8 * nfull, nbytes - 8 * nfull);
+    const uint64_t m = tail ^ (tail >> 32);
+    A += m; B += m;
+  }
+  out[0] = A;
+  out[1] = B;
   return MIMO_OK;
   });
 }

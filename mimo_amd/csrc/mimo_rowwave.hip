@@ -1968,6 +1968,8 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
     }
   }
 }
+static int g_sorted_range_cap = kSortedRange;
+void set_sorted_range_cap(int tiles) { g_sorted_range_cap = tiles < 1 || tiles > kSortedRange ? kSortedRange : tiles; }
 static bool label_sorted_on() {
   static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_SORTED"); return !e || atoi(e) != 0; }();   // tuning knob
   return on;
@@ -1988,7 +1990,7 @@ static hipError_t launch_sorted(const KernelArgs& a, int grid, hipStream_t strea
   if (e != hipSuccess) return e;
   const int64_t ntiles = (a.N + kLsWideTile - 1) / kLsWideTile;
   int R = (int)((ntiles + grid - 1) / (grid > 0 ? grid : 1));            // one range per workgroup where the cap allows (no second round for a few)
-  R = R < 1 ? 1 : R > kSortedRange ? kSortedRange : R;
+  R = R < 1 ? 1 : R > g_sorted_range_cap ? g_sorted_range_cap : R;      // (mimo_tune "sorted_range" lowers the cap: several ranges per workgroup at test sizes)
   hipLaunchKernelGGL(label_stats_sorted_kernel<DZ>, dim3(grid), dim3(kWG), 0, stream, a, R);
   return hipGetLastError();
 }

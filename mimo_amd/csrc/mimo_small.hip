@@ -456,44 +456,56 @@ __global__ __launch_bounds__(kWG) void nan_scan_kernel(double* __restrict__ Z, i
 // Is there a NaN anywhere in the (N, D) block?  The common answer is no, and then this flat scan — 16-byte loads where the
 // buffer is aligned, eight per thread in flight, grid-stride — is all an upload pays (bound by the one read of Z; the row-wise
 // kernel above reads with a stride of D doubles per lane: 0.64 TB/s at D = 16).  Only data that does hold a NaN goes on to it.
-__global__ __launch_bounds__(kWG) void nan_any_kernel(const unsigned long long* __restrict__ Z, int64_t count, unsigned int* __restrict__ flag) {
+// With `sums` the kernel also accumulates the content checksum mimo_host_checksum defines (include/mimo_hip.h): m = w ^ (w >> 32),
+// sums[0] += m, sums[1] += (count - index) m, 64-bit integer atomics (order-free) — the same read of Z serves both.
+template <bool SUM>
+__global__ __launch_bounds__(kWG) void nan_any_kernel(const unsigned long long* __restrict__ Z, int64_t count, unsigned int* __restrict__ flag,
+                                                      unsigned long long* __restrict__ sums) {
   typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
   const int64_t tid = (int64_t)blockIdx.x * kWG + threadIdx.x, nthr = (int64_t)gridDim.x * kWG;
   unsigned long long worst = 0ull;        // max of the exponent + mantissa bits seen: > 0x7ff0.. <=> some element is a NaN
+  unsigned long long sa = 0ull, sb = 0ull;
   const bool aligned = (reinterpret_cast<uintptr_t>(Z) & 15u) == 0;
   const int64_t pairs = aligned ? count / 2 : 0;
   const u2* Z2 = reinterpret_cast<const u2*>(Z);
+  auto take = [&](unsigned long long w, int64_t e) {
+    const unsigned long long a0 = w & 0x7fffffffffffffffull;
+    worst = worst > a0 ? worst : a0;
+    if constexpr (SUM) {
+      const unsigned long long m = w ^ (w >> 32);
+      sa += m;
+      sb += m * (unsigned long long)(count - e);
+    }
+  };
   int64_t i = tid;
   for (; i + 7 * nthr < pairs; i += 8 * nthr) {
     u2 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = Z2[i + j * nthr];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned long long a0 = v[j].x & 0x7fffffffffffffffull, a1 = v[j].y & 0x7fffffffffffffffull;
-      worst = worst > a0 ? worst : a0;
-      worst = worst > a1 ? worst : a1;
-    }
+    for (int j = 0; j < 8; ++j) { take(v[j].x, 2 * (i + j * nthr)); take(v[j].y, 2 * (i + j * nthr) + 1); }
   }
   for (; i < pairs; i += nthr) {
     const u2 v = Z2[i];
-    const unsigned long long a0 = v.x & 0x7fffffffffffffffull, a1 = v.y & 0x7fffffffffffffffull;
-    worst = worst > a0 ? worst : a0;
-    worst = worst > a1 ? worst : a1;
+    take(v.x, 2 * i); take(v.y, 2 * i + 1);
   }
-  for (int64_t e = 2 * pairs + tid; e < count; e += nthr) {     // the odd element, or everything of an unaligned buffer
-    const unsigned long long a0 = Z[e] & 0x7fffffffffffffffull;
-    worst = worst > a0 ? worst : a0;
-  }
+  for (int64_t e = 2 * pairs + tid; e < count; e += nthr) take(Z[e], e);     // the odd element, or everything of an unaligned buffer
   if (worst > 0x7ff0000000000000ull) atomicOr(flag, 1u);
+  if constexpr (SUM) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { sa += __shfl_xor(sa, s); sb += __shfl_xor(sb, s); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], sa); atomicAdd(&sums[1], sb); }
+  }
 }
 
-hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream) {
+hipError_t launch_nan_any(const double* Z, int64_t count, unsigned int* flag, int num_cu, hipStream_t stream, unsigned long long* sums) {
   if (count <= 0) return hipSuccess;
   int64_t g = (int64_t)num_cu * 8, need = (count / 2 + kWG - 1) / kWG;
   if (g > need) g = need;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(nan_any_kernel, dim3((unsigned)g), dim3(kWG), 0, stream, reinterpret_cast<const unsigned long long*>(Z), count, flag);
+  const unsigned long long* Zw = reinterpret_cast<const unsigned long long*>(Z);
+  if (sums) hipLaunchKernelGGL(nan_any_kernel<true>, dim3((unsigned)g), dim3(kWG), 0, stream, Zw, count, flag, sums);
+  else hipLaunchKernelGGL(nan_any_kernel<false>, dim3((unsigned)g), dim3(kWG), 0, stream, Zw, count, flag, sums);
   return hipGetLastError();
 }
 
@@ -514,6 +526,20 @@ __global__ __launch_bounds__(kWG) void mask_table_kernel(const double* __restric
   if (n >= N) return;
   const double m = mask[n];
   for (int k = 0; k < K; ++k) out[(int64_t)k * N + n] = table[(int64_t)k * N + n] * m;
+}
+
+// out[k][j] = table[k][cols[j]]: the few columns of a (K, N) table a host-side correction needs (rows with NaN)
+__global__ __launch_bounds__(kWG) void gather_columns_kernel(const double* __restrict__ table, int K, int64_t N, const int64_t* __restrict__ cols,
+                                                             int64_t ncols, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (e >= (int64_t)K * ncols) return;
+  const int64_t k = e / ncols, j = e - k * ncols, n = cols[j];
+  out[e] = (n >= 0 && n < N) ? table[k * N + n] : 0.0;
+}
+hipError_t launch_gather_columns(const double* table, int K, int64_t N, const int64_t* cols, int64_t ncols, double* out, hipStream_t stream) {
+  if (ncols <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)(((int64_t)K * ncols + kWG - 1) / kWG)), dim3(kWG), 0, stream, table, K, N, cols, ncols, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_nan_scan(double* Z, int64_t N, int D, double* mask, unsigned long long* count, bool write, hipStream_t stream) {

@@ -51,7 +51,69 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-class HipEngine:
+class _HostSum:
+    """Content checksum (`_word_checksum`) of a host array on a helper thread (the library call releases the GIL)."""
+
+    def __init__(self, Z):
+        import threading
+        self.Z, self.out, self.err = Z, None, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            self.out = _word_checksum(self.Z)
+        except Exception as exc:           # pragma: no cover  (reported by result())
+            self.err = exc
+
+    def result(self):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        return self.out
+
+
+class BoundDataGuard:
+    """Exact staleness check of the resident rows without a hash on the critical path (bind()).  For arrays above 16 MB bind()
+    compares a SAMPLE of the bound host array with what it saw at upload time (a fast negative); when the sample matches it
+    starts `_HostSum` on a helper thread and returns.  The first data pass of the call runs meanwhile; before its results
+    leave the engine (`checked` methods) the host checksum is compared with the checksum of the rows as they were uploaded
+    (`data_checksum`: computed on the device inside the upload's NaN scan).  A mismatch — the caller edited a few elements of
+    the bound array in place, which the sample did not see — uploads the array again, warns, and repeats the pass: the caller
+    never receives numbers computed on stale rows (the reference re-reads its argument on every call, mimo/mixtures/gmm.py:261)."""
+    _verify = None
+
+    def _start_verify(self, Z):
+        self._verify = _HostSum(Z)
+
+    def _settle(self):
+        """True: the resident rows are the bound array's (or nothing is pending).  False: they were stale and have been replaced."""
+        v, self._verify = self._verify, None
+        if v is None or v.result() == tuple(self.data_checksum()):
+            return True
+        import warnings
+        warnings.warn("the array bound to the engine was edited in place since it was uploaded (a change the sampled fingerprint "
+                      "did not see): uploaded again and the pass repeated", RuntimeWarning, stacklevel=3)
+        key = getattr(self, "_bound_key", None)
+        self.upload(v.Z)
+        self._bound_key = key
+        return False
+
+
+def checked(fn):
+    """Method decorator: run, then settle a pending verification of the bound rows; if they were stale, run again on the fresh ones."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        out = fn(self, *args, **kwargs)
+        if self._verify is not None and not self._settle():
+            out = fn(self, *args, **kwargs)
+        return out
+    return wrapper
+
+
+class HipEngine(BoundDataGuard):
     def __init__(self, device=0):
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -177,6 +239,10 @@ class HipEngine:
         sc[1] += corr          # sum r l gains the same constant (sum_k r = 1); NaN stays NaN
         return sc
 
+    def tune(self, key, value):
+        """Launch-geometry override for tests and experiments (mimo_tune): 'num_cu' (0: the device's own), 'sorted_range'."""
+        self._check(self._lib.mimo_tune(self._ctx, key.encode(), int(value)))
+
     def profile(self, enable=True):
         self._check(self._lib.mimo_profile(self._ctx, 1 if enable else 0))
 
@@ -236,7 +302,14 @@ class HipEngine:
         self._after_upload()
 
     # -- rows with NaN (dropped from the statistics, normaliser-only log-density: mimo_nan_info) -------------
+    def data_checksum(self):
+        """Content checksum of the rows as upload() received them (mimo_data_checksum; `_word_checksum` of the host array)."""
+        out = (C.c_uint64 * 2)()
+        self._check(self._lib.mimo_data_checksum(self._ctx, out))
+        return (int(out[0]), int(out[1]))
+
     def _after_upload(self):
+        self._verify = None
         self._w_key = None
         self._xxw_cache = None
         self._upload_count = getattr(self, '_upload_count', 0) + 1
@@ -277,6 +350,7 @@ class HipEngine:
             raise ValueError(f"parameter shapes {c.shape}, {b.shape}, {W.shape} do not match K={K}, Dz={self.D}")
         return c, b, W, K
 
+    @checked
     def estep(self, c, b, W, stats=True, keep_resp=False, keep_logp=False, keep_lse=False, entropy_split=False,
               row_weights=None):
         """Fused E-step.  Returns (SuffStats | None, scalars[3]); scalars[1:] are NaN unless
@@ -328,6 +402,7 @@ class HipEngine:
         """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
         The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs."""
         c, b, W, K = self._params(c, b, W)
+        self._async_args = (c, b, W) if self._verify is not None else None
         self._async_W0 = None
         if self._linear():
             if not np.array_equal(W, np.broadcast_to(W[:1], W.shape)):
@@ -341,16 +416,25 @@ class HipEngine:
         self._async_c = np.array(c) if getattr(self, 'n_bad', 0) else None
 
     def estep_wait(self):
-        K = self._async_K
-        S = np.empty((K, 1 + self.D + self.D * self.D))
-        sc = np.empty(3)
-        self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
-        S = SuffStats.from_packed(S, K, self.D)
+        out = self._estep_wait()
+        if self._verify is not None and getattr(self, '_async_args', None) is not None and not self._settle():
+            self.estep_async(*self._async_args)          # stale rows: the pass again on the fresh upload
+            out = self._estep_wait()
+        return out
+
+    def _finish_async(self, S, sc):
         if getattr(self, '_async_c', None) is not None:
             self._nan_softmax_share(S, self._async_c)
         if getattr(self, '_async_W0', None) is not None:
             return self._linear_stats(S, self._xx_total()), self._linear_scalars(sc, self._async_W0)
         return S, sc
+
+    def _estep_wait(self):
+        K = self._async_K
+        S = np.empty((K, 1 + self.D + self.D * self.D))
+        sc = np.empty(3)
+        self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
+        return self._finish_async(SuffStats.from_packed(S, K, self.D), sc)
 
     def estep_device(self, c, b, W, S_dev_ptr, scalars_dev_ptr):
         """Asynchronous fused E-step writing packed S / scalars to device pointers."""
@@ -359,6 +443,7 @@ class HipEngine:
                                          C.c_void_p(S_dev_ptr), C.c_void_p(scalars_dev_ptr)))
         self._K = K
 
+    @checked
     def gibbs_labels(self, c, b, W, seed=0, sweep=0, u=None, stats=True, return_labels=True,
                      keep_logp=False):
         """Fused Gibbs label step.  Returns (labels int32 | None, SuffStats | None)."""
@@ -393,6 +478,7 @@ class HipEngine:
             _lib.F_DEVICE_OUT, None, C.c_void_p(S_dev_ptr)))
         self._K = K
 
+    @checked
     def weighted_stats(self, resp=None, K=None):
         """Statistics for arbitrary (K,N) weights; resp=None reuses the resident table."""
         if resp is None:
@@ -409,11 +495,12 @@ class HipEngine:
         S = SuffStats.from_packed(S, K, self.D)
         if getattr(self, 'n_bad', 0):
             bad = self.nan_rows()
-            S.n_rows = S.n + (np.sum(resp[:, bad], axis=1) if resp is not None else np.sum(self.get_resp(K)[:, bad], axis=1))
+            S.n_rows = S.n + (np.sum(resp[:, bad], axis=1) if resp is not None else np.sum(self.get_resp_columns(bad, K), axis=1))
         if self._linear():     # sum_k r_kn is the weight of row n in the pooled second moment (1 for responsibilities)
             S = self._linear_stats(S, self._xx_total() if resp is None else self._xx(np.sum(resp, axis=0)))
         return S
 
+    @checked
     def label_stats(self, labels, K):
         """Statistics of hard labels (no one-hot table); labels=None reuses the resident draw."""
         K = int(K)
@@ -433,6 +520,7 @@ class HipEngine:
             S.n_rows = S.n + self._nan_label_counts(K)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
+    @checked
     def random_resp_stats(self, K, seed=0):
         """Statistics of random initial responsibilities drawn on the device (mimo_random_resp_stats): the
         randomize=True start of the drivers without K N host uniforms; the table stays resident (get_resp)."""
@@ -442,7 +530,7 @@ class HipEngine:
         self._K = K
         S = SuffStats.from_packed(S, K, self.D)
         if getattr(self, 'n_bad', 0):        # the share of the rows with NaN: their random responsibilities (the table is resident)
-            S.n_rows = S.n + np.sum(self.get_resp(K)[:, self.nan_rows()], axis=1)
+            S.n_rows = S.n + np.sum(self.get_resp_columns(self.nan_rows(), K), axis=1)
         return self._linear_stats(S, self._xx_total()) if self._linear() else S
 
     def sample_from_log(self, logp=None, K=None, u=None, seed=0, sweep=0, return_lognorms=False):
@@ -478,6 +566,7 @@ class HipEngine:
             self._check(self._lib.mimo_table_entropy(self._ctx, _ptr(table), table.size, 0, C.byref(out)))
         return out.value
 
+    @checked
     def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
         """Posterior-predictive mixture moments of every resident row (mimo_predict).
         Returns (mu (N,dy), covar (N,dy,dy), nlpd (N) | None)."""
@@ -530,6 +619,13 @@ class HipEngine:
         self._check(self._lib.mimo_get_resp(self._ctx, _ptr(out)))
         return out
 
+    def get_resp_columns(self, rows, K=None):
+        """(K, len(rows)) block of the resident responsibility table (mimo_get_resp_columns): a few columns, not K N doubles."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty((int(K if K is not None else self._K), rows.shape[0]))
+        self._check(self._lib.mimo_get_resp_columns(self._ctx, _ptr(rows), rows.shape[0], _ptr(out)))
+        return out
+
     def get_logp(self, K=None):
         out = np.empty((int(K if K is not None else self._K), self.N))
         self._check(self._lib.mimo_get_logp(self._ctx, _ptr(out)))
@@ -566,22 +662,43 @@ def _exact_mode():
     return os.environ.get("MIMO_BIND_EXACT", "0") == "1"
 
 
+def _verify_mode():
+    """Background verification of large bound arrays (BoundDataGuard); MIMO_BIND_VERIFY=0 leaves the sampled fingerprint alone."""
+    import os
+    return os.environ.get("MIMO_BIND_VERIFY", "1") != "0"
+
+
 def _word_checksum(Z):
-    """Checksum over EVERY 8-byte word of a C-contiguous array: wrapping sum and xor of the words — two reductions at memory
-    bandwidth, no temporary; any edit of a single element changes it (a permutation of elements would not)."""
+    """Position-dependent checksum over EVERY byte of a C-contiguous array (mimo_host_checksum, include/mimo_hip.h): with w_i the
+    8-byte words (the tail zero-extended), m_i = w_i ^ (w_i >> 32) and nw their number, (sum_i m_i, sum_i (nw - i) m_i) mod 2^64
+    — at memory bandwidth, no temporary; any edit of one element changes it, and so does a swap of two unequal elements (an
+    in-place row shuffle).  The NumPy form below is the same function (used when the library cannot be loaded)."""
     w = np.ascontiguousarray(Z).reshape(-1).view(np.uint8)
     try:                     # one threaded pass in the library (host-only entry point: no GPU needed) — 32 MB of row weights in
-        lib = _lib.load()    # ~1 ms where the two NumPy reductions below take ~3 ms, as much as the pass they guard
+        lib = _lib.load()    # ~1 ms where NumPy reductions take ~3 ms, as much as the pass they guard
     except _lib.MimoHipError:
         lib = None
     if lib is not None:
         out = (C.c_uint64 * 2)()
         if lib.mimo_host_checksum(w.ctypes.data_as(C.c_void_p), w.size, out) == 0:
             return (int(out[0]), int(out[1]))
+    return _word_checksum_numpy(w)
+
+
+def _word_checksum_numpy(w):
     n8 = w.size // 8
     u = w[:8 * n8].view(np.uint64)
-    import zlib
-    return (int(np.add.reduce(u, dtype=np.uint64)), int(np.bitwise_xor.reduce(u)), zlib.crc32(w[8 * n8:]))
+    tail = w[8 * n8:]
+    nw = n8 + (1 if tail.size else 0)
+    m = u ^ (u >> np.uint64(32))
+    mask = (1 << 64) - 1
+    A = int(np.add.reduce(m, dtype=np.uint64)) if n8 else 0
+    B = int(np.add.reduce(m * (np.uint64(nw) - np.arange(n8, dtype=np.uint64)), dtype=np.uint64)) if n8 else 0
+    if tail.size:
+        t = int.from_bytes(tail.tobytes(), 'little')
+        mt = t ^ (t >> 32)
+        A, B = (A + mt) & mask, (B + mt) & mask
+    return (A, B)
 
 
 class FrozenWeights:
@@ -664,6 +781,10 @@ def bind(engine, Z, structure='full', exact=None):
         engine.upload(Z)                 # (also invalidates the cached pooled second moment)
         engine._bound_key = key
         engine._bound_ref = Z        # keeps the address from being recycled
+    elif _verify_mode() and isinstance(engine, BoundDataGuard) and Z.flags.c_contiguous and Z.dtype == np.float64 \
+            and Z.nbytes > _FULL_SUM_BYTES and not (_exact_mode() if exact is None else exact) and engine._verify is None:
+        # the sampled fingerprint matched: every byte is compared behind the first pass of this call (BoundDataGuard)
+        engine._start_verify(Z)
     return engine
 
 

@@ -51,7 +51,7 @@ class ShardedEngine:
         self._nccl = dist.get_backend(group) == "nccl"
         self._native = False
         self._rank_order = os.environ.get("MIMO_SHARDED_RANK_ORDER", "1") != "0"
-        self._checked = False
+        self._checks_left = 2
         if self._nccl and hasattr(inner, "comm_init") and os.environ.get("MIMO_SHARDED_NATIVE", "0") == "1":
             try:
                 self._attach_native(inner)
@@ -106,9 +106,11 @@ class ShardedEngine:
                 "all ranks, or pass the same seeded `param_rng` everywhere.")
 
     def check_replicated_once(self, *arrays, what="parameters"):
-        """`assert_replicated` on the first call only (the drivers call it every sweep)."""
-        if not self._checked:
-            self._checked = True
+        """`assert_replicated` on the first TWO calls after an upload (the drivers call it every sweep): a run that starts from
+        `init_labels='posterior'` makes its first label pass with the parameters it was given — identical on every rank — and
+        only the second one with blocks drawn from the ranks' host generators."""
+        if self._checks_left > 0:
+            self._checks_left -= 1
             self.assert_replicated(*arrays, what=what)
 
     def _any_nan(self):
@@ -125,13 +127,31 @@ class ShardedEngine:
     def D(self):
         return self.inner.D
 
+    @property
+    def n_bad(self):
+        """Rows of THIS rank's block that hold a NaN (the host-side fixes of the linear-Gaussian mixtures are row-local:
+        mixtures/ilr.py nan_rows_table, lingauss.log_likelihood)."""
+        return getattr(self.inner, 'n_bad', 0)
+
+    def nan_rows(self):
+        return self.inner.nan_rows()
+
+    def plan(self, K, gibbs=False):
+        return self.inner.plan(K, gibbs)
+
+    def tune(self, key, value):
+        return self.inner.tune(key, value)
+
+    def predict_device(self, *args, **kwargs):
+        return self.inner.predict_device(*args, **kwargs)      # row-local, like predict
+
     def upload(self, Z_local):
         """Bind this rank's row block."""
         self.inner.upload(Z_local)
         self.inner.set_row_offset(self._row0)
         self._xx_global = None
         self._any_nan_cache = None
-        self._checked = False
+        self._checks_left = 2
 
     def set_row_offset(self, row0):
         self._row0 = int(row0)

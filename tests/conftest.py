@@ -65,4 +65,6 @@ def engine(_session_engine):
     is engine state (a tied model leaves it at 'linear'): every test starts from the full feature map."""
     _session_engine.set_structure('full')
     _session_engine.set_row_offset(0)
+    _session_engine.tune("num_cu", 0)              # launch-geometry overrides of a previous test (mimo_tune) are undone
+    _session_engine.tune("sorted_range", 0)
     return _session_engine

@@ -125,6 +125,95 @@ def test_bind_sees_in_place_edits():
     assert z1 is not z0 and np.array_equal(z1[:, 2:], y)
 
 
+def test_bind_sees_row_swaps_and_single_elements():
+    """The content key is position dependent: an in-place swap of two rows of a 2 - 16 MB array — same bytes,
+    another order — uploads again, and so does one edited element; the native checksum and its NumPy form are one function."""
+    import numpy as np
+    from mimo_amd import engine as E
+
+    class Counting(OracleEngine):
+        uploads = 0
+
+        def upload(self, Z):
+            Counting.uploads += 1
+            super().upload(np.array(Z, copy=True))
+
+    rng = np.random.default_rng(1)
+    for n in (0, 5, 8, 13, 4096, 100_003):
+        w = rng.integers(0, 256, size=n, dtype=np.uint8)
+        assert E._word_checksum(w) == E._word_checksum_numpy(w) and len(E._word_checksum(w)) == 2
+    X = np.ones((3 * 4096, 16)); X[7] = 2.
+    a = E._word_checksum(X)
+    X[[7, 7 + 2048]] = X[[7 + 2048, 7]]                  # "round" doubles 2^11 rows apart: the weighted sum of the raw words would not move
+    assert E._word_checksum(X) != a
+    eng, X = Counting(), rng.standard_normal((400_000, 4))           # 12.8 MB: every word is summed
+    E.bind(eng, X); E.bind(eng, X)
+    assert Counting.uploads == 1
+    X[[11, 300_000]] = X[[300_000, 11]]
+    E.bind(eng, X)
+    assert Counting.uploads == 2 and np.array_equal(eng.Z, X)
+    rng.shuffle(X)
+    E.bind(eng, X)
+    assert Counting.uploads == 3 and np.array_equal(eng.Z, X)
+    X[123_456, 2] += 1e-9
+    E.bind(eng, X)
+    assert Counting.uploads == 4 and np.array_equal(eng.Z, X)
+
+
+def test_bound_rows_are_verified_behind_the_first_pass():
+    """Arrays above 16 MB: bind() compares a sample and, when it matches, checks EVERY byte on a helper thread while the first
+    pass runs (engine.BoundDataGuard); a single edited element that the sample misses is found before results leave the
+    engine: the array is uploaded again, a warning raised and the pass repeated — synchronous and asynchronous form."""
+    import numpy as np
+    from mimo_amd import engine as E
+
+    class Guarded(E.BoundDataGuard, OracleEngine):
+        uploads = 0
+
+        def upload(self, Z):
+            Guarded.uploads += 1
+            self._verify = None
+            self._uploaded_sum = E._word_checksum(np.ascontiguousarray(Z, dtype=float))
+            super().upload(np.array(Z, copy=True))
+
+        def data_checksum(self):
+            return self._uploaded_sum
+
+        estep = E.checked(OracleEngine.estep)
+
+    rng = np.random.default_rng(2)
+    N, D, K = 1_100_000, 2, 3                                         # 17.6 MB
+    X = rng.standard_normal((N, D))
+    c, b, W = rng.standard_normal(K), rng.standard_normal((K, D)), np.stack(K * [np.eye(D)])
+    eng = Guarded()
+    E.bind(eng, X)
+    S0, _ = eng.estep(c, b, W)
+    assert Guarded.uploads == 1 and eng._verify is None
+    E.bind(eng, X)                                                    # untouched: verified, no upload, no warning
+    assert eng._verify is not None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        S1, _ = eng.estep(c, b, W)
+    assert Guarded.uploads == 1 and eng._verify is None and np.array_equal(S1.sxx, S0.sxx)
+    X[777_777, 1] += 5.                                               # one element: the strided sample does not see it
+    assert E._bind_key(X) == eng._bound_key
+    E.bind(eng, X)
+    with pytest.warns(RuntimeWarning, match="edited in place"):
+        S2, _ = eng.estep(c, b, W)
+    assert Guarded.uploads == 2 and np.array_equal(eng.Z, X) and not np.array_equal(S2.sxx, S0.sxx)
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    L = O.canonical_eval(X, c, b, W)
+    n, sx, sxx = O.packed_stats(X, np.exp(L - logsumexp(L, axis=0)))
+    assert np.allclose(S2.sxx, sxx, rtol=1e-12)
+    E.bind(eng, X)                                                    # and now it is clean again
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng.estep(c, b, W)
+    assert Guarded.uploads == 2
+
+
 def test_sample_discrete_from_log_and_random_start_on_the_double():
     """Host logic of the two API additions with the oracle-backed double: axis handling / numpy.random call shape of
     sample_discrete_from_log, and the init_rng switch of the drivers."""
