@@ -88,6 +88,7 @@ struct mimo_ctx {
   int comm_world = 1;
   bool rowwave_vi_call = false; // set by mimo_estep for the call in progress: row-owner softmax + statistics kernel
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
+  bool mid_call = false;        // set for the call in progress: Theta is in the grouped image of the mid kernel (mimo_mid.hip)
   int narrow_call = 0;          // set for the call in progress: Theta is in the narrow image (1: softmax + statistics pass, 2: label pass, 3: label pass + statistics fused)
 
   // pending asynchronous call (MIMO_F_ASYNC)
@@ -375,7 +376,7 @@ static int upload_theta_rowwave(mimo_ctx* ctx, const double* c, const double* b,
 // requests only — nothing but statistics + scalars (softmax pass) or labels + their statistics (label pass).
 // Returns the kernel mode + 1 (1: softmax + statistics, 2: label draw with the label-statistics kernel behind it, 3: label draw +
 // statistics in one pass — few components over many features, MIMO_NARROW_FUSED_LABELS=0: off) or 0.
-static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool stats = true) {
+static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool stats) {
   static const bool fused_labels = [] { const char* e = getenv("MIMO_NARROW_FUSED_LABELS"); return !e || atoi(e) != 0; }();
   if (!plain) return 0;                 // (the small-shape kernel keeps the generic requests of its range and the shapes below narrow_covers' K)
   const int ZS = (K + 15) / 16 > 12 ? ctx->D + 2 : ((ctx->D + 2) | 1);      // as fill_args
@@ -442,6 +443,64 @@ static int upload_theta_narrow(mimo_ctx* ctx, const double* c, const double* b, 
   }
   if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
   for (int k = K; k < 4 * V; ++k) put(k, fidx(ctx, D, D), kPadLogDensity);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return MIMO_OK;
+}
+
+// Softmax + statistics pass of the mid shapes (mimo_mid.hip): plain requests (statistics + scalars, row weights / the NaN mask
+// allowed), full feature map, K <= 32 where neither the narrow kernels (few components) nor the single-pass tile kernels do
+// better — measured per shape (profiles/r04_mid_kernel_sweep.txt): from Dz = 17 everything the narrow kernels do not take;
+// MIMO_MID_MIN_D moves the lower end (tuning knob)
+static int g_mid_min_d = [] { const char* e = getenv("MIMO_MID_MIN_D"); return e ? atoi(e) : 0; }();       // (mimo_tune "mid_min_d"; 0: the measured rule)
+static int g_mid_narrow_k = [] { const char* e = getenv("MIMO_MID_NARROW_K"); return e ? atoi(e) : 0; }(); // (mimo_tune "mid_narrow_k")
+static int use_narrow(const mimo_ctx* ctx, int K, bool gibbs, bool plain, bool stats);
+static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
+  const int D = ctx->D;
+  if (!plain || !mid_covers(K, D, ctx->structure)) return false;
+  if (g_mid_min_d > 0 || g_mid_narrow_k > 0)       // forced by the caller (tests, sweeps)
+    return D >= (g_mid_min_d > 0 ? g_mid_min_d : 9) &&
+           (K >= (g_mid_narrow_k > 0 ? g_mid_narrow_k : 33) || !use_narrow(ctx, K, false, plain, true));
+  // measured (tools/mid_sweep.py, profiles/r04_mid_kernel_sweep.txt; fraction of the float64 rate, other route -> mid):
+  //   K = 17 .. 32: from Dz = 13 (Dz=13 K=32 0.55 -> 0.61, Dz=14 0.58 -> 0.66, Dz=16 0.61 -> 0.64, Dz=20 0.41 -> 0.69, Dz=32 0.48 -> 0.75;
+  //                 Dz=12 K=32 0.61 -> 0.57 and Dz=11 0.53 -> 0.50 stay on the tile / row-owner kernels)
+  //   K = 13 .. 16: from Dz = 12 against the narrow kernels (Dz=12 K=16 0.41 -> 0.49, Dz=14 0.44 -> 0.58, Dz=16 0.42 -> 0.57; Dz=11 0.45 -> 0.43)
+  //   K <= 12: the narrow kernels where they exist (Dz=16 K=12 0.44 = 0.44, Dz=15 0.42 -> 0.38, Dz=20 K=8 0.37 -> 0.30) up to Dz = 23
+  //            (Dz=24 K=8 0.31 -> 0.32, Dz=26 K=8 0.19 -> 0.34); beyond them the two-stage path was all there was (Dz=20 K=12 0.18 -> 0.47)
+  if (K >= 17) return D >= 13;
+  if (K >= 13) return D >= 12;
+  return D >= 24 || !use_narrow(ctx, K, false, plain, true);
+}
+
+// Theta image of the mid kernel: [steps][KB][64] in the grouped feature order + mid_pf() zero slices
+static int upload_theta_mid(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
+  const int D = ctx->D, KB = (K + 15) / 16, NS = mid_steps(D);
+  const size_t count = ((size_t)NS * KB + mid_pf()) * 64;
+  int rc;
+  if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
+  if ((rc = ensure_pinned(ctx, &ctx->theta_h, &ctx->theta_hcap, count))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  double* img = ctx->theta_h;
+  memset(img, 0, count * sizeof(double));
+  bool finite = true;
+  auto put = [&](int k, int aa, int bb, double v) {
+    int st, jj;
+    narrow_group_pos(D, aa, bb, &st, &jj);
+    finite = finite && std::fabs(v) <= 1.7976931348623157e308;
+    img[((size_t)st * KB + k / 16) * 64 + 16 * jj + k % 16] = v;
+  };
+  for (int k = 0; k < K; ++k) {
+    const double* bk = b + (size_t)k * D;
+    const double* Wk = W + (size_t)k * D * D;
+    if (c[k] != c[k] || c[k] > 1.7976931348623157e308) return fail(ctx, MIMO_E_INVALID, "c[%d] is NaN or +inf", k);
+    put(k, D, D, c[k] < kPadLogDensity ? kPadLogDensity : c[k]);
+    for (int a = 0; a < D; ++a) {
+      put(k, a, D, bk[a]);
+      put(k, a, a, -0.5 * Wk[a * D + a]);
+      for (int bb = a + 1; bb < D; ++bb) put(k, a, bb, -0.5 * (Wk[a * D + bb] + Wk[bb * D + a]));
+    }
+  }
+  if (!finite) return fail(ctx, MIMO_E_INVALID, "b or W holds a NaN or an infinity");
+  for (int k = K; k < 16 * KB; ++k) put(k, D, D, kPadLogDensity);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->theta_d, img, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MIMO_OK;
 }
@@ -567,12 +626,13 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const bool narrow_vi = src == kSrcEstep && (ctx->narrow_call == 1 || narrow_g1);  // narrow softmax + statistics pass (or the above: same launch shape)
   const bool narrow_g = src == kSrcEstep && ctx->narrow_call == 2;                  // narrow label pass + label statistics
   const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave || narrow_g);
+  const bool mid = src == kSrcEstep && ctx->mid_call;                               // mid shapes: row-owner E-step + column-owner statistics
   int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
              : rowvi ? rowwave_grid(a, ctx->num_cu) : narrow_vi ? narrow_grid(a, ctx->num_cu, ctx->F, narrow_g1 ? 2 : 0)
-             : fused_grid(a, ctx->num_cu, src);
+             : mid ? mid_grid(a, ctx->num_cu) : fused_grid(a, ctx->num_cu, src);
   // two-stage pass on the pipelined E-step (mimo_wide.hip): that kernel is built for two workgroups per CU whatever K is
   // (fused_grid's fallback assumes one for K > 128); the statistics launches of the pass share the grid (partial blocks)
-  if (!small && !lstats && !rowvi && !narrow_vi && src == kSrcEstep && !fused_covers(a.K16, a.F16 / 16, src) &&
+  if (!small && !lstats && !rowvi && !narrow_vi && !mid && src == kSrcEstep && !fused_covers(a.K16, a.F16 / 16, src) &&
       wide_estep_covers(a.K16, D, a.F16, a.gibbs)) {
     const int64_t g2 = 2 * (int64_t)ctx->num_cu;
     grid = (int)(g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1));
@@ -631,6 +691,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   } else if (narrow_vi) {
     rc = timed_launch(ctx, "narrow_kernel", [&]() -> int {
       HIP_TRY(ctx, launch_narrow(a, ctx->F, narrow_g1 ? 2 : 0, grid, ctx->stream));
+      return MIMO_OK;
+    });
+    if (rc) return rc;
+  } else if (mid) {
+    rc = timed_launch(ctx, "mid_kernel", [&]() -> int {
+      HIP_TRY(ctx, launch_mid(a, grid, ctx->stream));
       return MIMO_OK;
     });
     if (rc) return rc;
@@ -1027,15 +1093,19 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
   const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
-  const bool nv = use_narrow(ctx, K, false, plain) != 0;      // narrow shapes (Dz <= 4, 32 < K <= 128; few components over many features): mimo_narrow.hip
-  const bool rv = !nv && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
-  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  const bool md = use_mid(ctx, K, plain);                     // mid shapes (K <= 32 over wide rows): mimo_mid.hip
+  const bool nv = !md && use_narrow(ctx, K, false, plain, true) != 0;      // narrow shapes (Dz <= 4, 32 < K <= 128; few components over many features): mimo_narrow.hip
+  const bool rv = !nv && !md && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : md ? upload_theta_mid(ctx, c, b, W, K)
+            : rv ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_vi_call = rv;
   ctx->narrow_call = nv ? 1 : 0;
+  ctx->mid_call = md;
   rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, scalars);
   ctx->rowwave_vi_call = false;
   ctx->narrow_call = 0;
+  ctx->mid_call = false;
   return rc;
   });
 }
@@ -1052,8 +1122,10 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
   KernelArgs a;
   fill_args(ctx, K, &a);
   // the narrow kernels take the weights on their normaliser (plain requests: statistics + scalars only)
-  const bool nv = use_narrow(ctx, K, false, (flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) == 0) != 0;
-  if (!nv && !fused_covers(a.K16, a.F16 / 16, kSrcEstep))
+  const bool plain_w = (flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) == 0;
+  const bool md = use_mid(ctx, K, plain_w);              // mid shapes (K <= 32 over wide rows)
+  const bool nv = !md && use_narrow(ctx, K, false, plain_w, true) != 0;
+  if (!nv && !md && !fused_covers(a.K16, a.F16 / 16, kSrcEstep))
     return fail(ctx, MIMO_E_UNSUPPORTED, "mimo_estep_weighted: K=%d, Dz=%d runs on the two-stage path, which takes "
                 "its weights as a table (mimo_estep + mimo_weighted_stats)", K, ctx->D);
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
@@ -1071,11 +1143,13 @@ int mimo_estep_weighted(mimo_ctx* ctx, const double* c, const double* b, const d
     a.u = ctx->u_d;
     ctx->weights_resident = true;
   }
-  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  if ((rc = nv ? upload_theta_narrow(ctx, c, b, W, K, 0) : md ? upload_theta_mid(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->narrow_call = nv ? 1 : 0;
+  ctx->mid_call = md;
   rc = run_fused(ctx, a, kSrcEstep, flags, S, scalars);
   ctx->narrow_call = 0;
+  ctx->mid_call = false;
   return rc;
   });
 }
@@ -1510,6 +1584,16 @@ int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value) {
       set_sorted_range_cap((int)value);
       return MIMO_OK;
     }
+    if (!strcmp(key, "mid_narrow_k")) {
+      if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_narrow_k = %lld outside [0, 64]", (long long)value);
+      g_mid_narrow_k = (int)value;
+      return MIMO_OK;
+    }
+    if (!strcmp(key, "mid_min_d")) {
+      if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_min_d = %lld outside [0, 64]", (long long)value);
+      g_mid_min_d = (int)value;
+      return MIMO_OK;
+    }
     return fail(ctx, MIMO_E_INVALID, "mimo_tune: unknown key '%s'", key);
   });
 }
@@ -1571,7 +1655,10 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   memset(out8, 0, 8 * sizeof(int64_t));
   out8[4] = 1;                           // passes over Z
   out8[5] = gibbs ? 1 : 0;               // passes over the labels
-  if (const int nm = use_narrow(ctx, K, gibbs != 0, true)) {
+  if (!gibbs && use_mid(ctx, K, true)) {
+    out8[0] = MIMO_PLAN_MID; out8[1] = 1;
+    out8[6] = mid_grid(a, ctx->num_cu);
+  } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true, true)) {
     out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
     if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
     out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, nm - 1);

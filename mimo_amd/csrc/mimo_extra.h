@@ -63,4 +63,14 @@ void narrow_group_pos(int D, int a, int b, int* step, int* j);
 int narrow_grid(const KernelArgs& a, int num_cu, int F, int gibbs);
 hipError_t launch_narrow(const KernelArgs& a, int F, int gibbs, int grid, hipStream_t stream);
 
+// mid shapes (K <= 32 over Dz = 9 .. 32, full map) on row-owner E-step waves + column-owner statistics waves (mimo_mid.hip);
+// theta in the grouped image [steps][KB][64] (+ mid_pf() zero slices): slice (s, rb), entry 16 k + i = Theta[16 rb + i][feature
+// (a_s, b0_s + k)] of the grouped order (narrow_group_pos)
+bool mid_covers(int K, int D, int structure);
+int mid_steps(int D);
+int mid_pf();
+int mid_rows_per_step(int K, int D);
+int mid_grid(const KernelArgs& a, int num_cu);
+hipError_t launch_mid(const KernelArgs& a, int grid, hipStream_t stream);
+
 }  // namespace mimo

@@ -271,11 +271,12 @@ class HipEngine(BoundDataGuard):
         """How a pass with K components runs on the resident data (mimo_plan): kind, kernels, HBM passes."""
         o = (C.c_int64 * 8)()
         self._check(self._lib.mimo_plan(self._ctx, int(K), 1 if gibbs else 0, o))
-        kind = {1: "fused", 2: "two-stage", 3: "small", 4: "rowwave", 5: "rowwave-vi", 6: "narrow"}.get(o[0], "?")
+        kind = {1: "fused", 2: "two-stage", 3: "small", 4: "rowwave", 5: "rowwave-vi", 6: "narrow", 7: "mid"}.get(o[0], "?")
         kernel = {1: "mimo::fused_kernel", 2: "E-step (mimo::wide_estep_kernel / estep_chunked_kernel) + statistics per column group (mimo::wide_stats_kernel / fused_kernel)",
                   3: "mimo::small_kernel", 4: "mimo::gibbs_rowwave_kernel + mimo::label_stats_kernel",
                   5: "mimo::vi_rowwave_kernel",
-                  6: "mimo::narrow_kernel (+ mimo::label_stats_kernel for a label pass)"}.get(o[0], "?")
+                  6: "mimo::narrow_kernel (+ mimo::label_stats_kernel for a label pass)",
+                  7: "mimo::mid_kernel"}.get(o[0], "?")
         return {"kind": kind, "kernel": kernel, "kernels_per_pass": int(o[1]), "table_in_hbm": bool(o[2]),
                 "table_reads": int(o[3]), "data_passes": int(o[4]), "label_passes": int(o[5]),
                 "workgroups": int(o[6]), "compute_units": int(o[7])}

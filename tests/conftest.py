@@ -67,4 +67,6 @@ def engine(_session_engine):
     _session_engine.set_row_offset(0)
     _session_engine.tune("num_cu", 0)              # launch-geometry overrides of a previous test (mimo_tune) are undone
     _session_engine.tune("sorted_range", 0)
+    _session_engine.tune("mid_min_d", 0)
+    _session_engine.tune("mid_narrow_k", 0)
     return _session_engine

@@ -1,0 +1,120 @@
+"""GPU (-m gpu): the mid kernels (mimo_mid.hip: softmax + statistics pass of K <= 32 components over Dz = 9 .. 32, row-owner
+E-step waves + column-owner statistics waves) against the oracle: every Dz, both row-block counts, four- and eight-wave
+workgroups, ragged / tiny / many-super-step row counts, row weights, rows with NaN, the asynchronous form, repeated launches."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(rng, N, D, K):
+    Z = rng.standard_normal((N, D)) * 2.0 + rng.standard_normal(D)
+    A = rng.standard_normal((K, D, D))
+    W = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+    mu = rng.standard_normal((K, D)) * 2
+    b = np.einsum('kde,ke->kd', W, mu)
+    c = -0.5 * np.einsum('kd,kd->k', mu, b) + rng.standard_normal(K) * 0.1
+    return Z, c, b, W
+
+
+def _check(engine, Z, c, b, W, weights=None):
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    N = len(Z)
+    L = O.canonical_eval(Z, c, b, W)
+    lse = logsumexp(L, axis=0) if N else np.zeros(0)
+    R = np.exp(L - lse)
+    n, sx, sxx = O.packed_stats(Z, R if weights is None else R * weights[None, :])
+    S, sc = engine.estep(c, b, W, row_weights=weights)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    if N:
+        assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    return S, sc
+
+
+MID_SHAPES = [(D, K) for D in range(17, 33) for K in ((9, 32) if D % 2 else (16, 17))] + \
+             [(27, 8), (32, 7), (30, 5), (24, 24), (32, 31), (20, 12), (28, 20),
+              (13, 33), (16, 48), (19, 48), (20, 40), (21, 35), (24, 48), (25, 41), (26, 48), (14, 16), (12, 13)]     # three row blocks: K <= 48 up to Dz = 26
+
+
+@pytest.mark.parametrize("D,K", MID_SHAPES)
+def test_mid_kernels_vs_oracle(engine, D, K):
+    rng = np.random.default_rng(7700 + 40 * D + K)
+    engine.tune("mid_narrow_k", 1)          # (few components: the narrow kernels by default where they exist)
+    for N in (1, 17, 5003):
+        Z, c, b, W = _random_problem(rng, N, D, K)
+        engine.upload(Z)
+        assert engine.plan(K)["kind"] == "mid"
+        _check(engine, Z, c, b, W)
+    # many super-steps per workgroup (three CUs' worth of workgroups), weights, second launch, asynchronous form
+    N = 20011
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    engine.tune("num_cu", 3)
+    try:
+        S, sc = _check(engine, Z, c, b, W)
+        S2, sc2 = engine.estep(c, b, W)
+        assert np.array_equal(S2.sxx, S.sxx) and np.array_equal(S2.sx, S.sx) and sc2[0] == sc[0]
+        engine.estep_async(c, b, W)
+        S3, sc3 = engine.estep_wait()
+        assert np.array_equal(S3.sxx, S.sxx) and sc3[0] == sc[0]
+        _check(engine, Z, c, b, W, weights=rng.random(N))
+    finally:
+        engine.tune("num_cu", 0)
+    # a component switched off by its weight (log 0) enters like a padding component
+    c2 = c.copy(); c2[K // 2] = -np.inf
+    if K > 1:
+        from oracle import mimo_oracle as O
+        from scipy.special import logsumexp
+        L2 = O.canonical_eval(Z, np.where(np.isinf(c2), -1e300, c2), b, W)
+        lse2 = logsumexp(L2, axis=0)
+        n2, _, sxx2 = O.packed_stats(Z, np.exp(L2 - lse2))
+        So, sco = engine.estep(c2, b, W)
+        assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * abs(lse2.sum())
+
+
+@pytest.mark.parametrize("D,K", [(9, 9), (12, 16), (13, 32), (16, 17), (16, 32), (10, 24), (15, 12), (11, 30), (14, 16)])
+def test_mid_kernels_below_their_default_range(engine, D, K):
+    """Dz = 9 .. 16: the kernels exist there too (mimo_tune "mid_min_d" routes them); the router's default prefers the narrow /
+    tile / row-owner kernels where they measured faster."""
+    rng = np.random.default_rng(7900 + 40 * D + K)
+    N = 20011
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    engine.tune("mid_min_d", 9)
+    engine.tune("mid_narrow_k", 1)
+    try:
+        assert engine.plan(K)["kind"] == "mid"
+        S, sc = _check(engine, Z, c, b, W)
+        S2, sc2 = engine.estep(c, b, W)
+        assert np.array_equal(S2.sxx, S.sxx) and sc2[0] == sc[0]
+    finally:
+        engine.tune("mid_min_d", 0)
+        engine.tune("mid_narrow_k", 0)
+
+
+@pytest.mark.parametrize("D,K", [(20, 16), (32, 32), (27, 8)])
+def test_rows_with_nan_on_the_mid_kernels(engine, D, K):
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(8100 + 10 * D + K)
+    N = 20011
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    bad = rng.choice(N, size=29, replace=False)
+    Zn = Z.copy()
+    Zn[bad, rng.integers(0, D, size=bad.size)] = np.nan
+    mask = np.ones(N); mask[bad] = 0.
+    Zc = Z.copy(); Zc[bad] = 0.
+    engine.upload(Zn)
+    engine.tune("mid_narrow_k", 1)
+    assert engine.n_bad == bad.size and engine.plan(K)["kind"] == "mid"
+    L = O.canonical_eval(Zc, c, b, W)
+    lse = logsumexp(L, axis=0)
+    n, sx, sxx = O.packed_stats(Zc, np.exp(L - lse) * mask[None, :])
+    S, sc = engine.estep(c, b, W)
+    assert rel_err(S.n, n) < 1e-11 and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+    assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
+    assert abs(S.gating_counts.sum() - N) < 1e-9 * N
+    engine.upload(Z)
