@@ -371,7 +371,7 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_ROWWAVE    4   /* label pass: row-owner label kernel + label-indexed statistics kernel            */
 #define MIMO_PLAN_ROWWAVE_VI 5   /* softmax pass at K <= 64, Dz <= 9: row-owner kernel for both matrix products     */
 #define MIMO_PLAN_NARROW     6   /* Dz <= 4 with 32 < K <= 128: 4x4x4 matrix-instruction kernels (+ label statistics) */
-#define MIMO_PLAN_MID        7   /* softmax pass, K <= 48 over wide rows (Dz >= 12): row-owner E-step + column-owner statistics waves */
+#define MIMO_PLAN_MID        7   /* softmax pass of the mid shapes (K <= 96; mimo_mid.hip): row-owner E-step + column-owner statistics waves */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
 
 /* Checksum of the rows as mimo_upload received them (before rows with NaN are zeroed in the library's copy): the function
@@ -387,7 +387,7 @@ int mimo_data_checksum(mimo_ctx* ctx, uint64_t out[2]);
  *   "sorted_range" (process-wide) cap on the 256-row tiles per range of label_stats_sorted_kernel (default and maximum 80;
  *                  0 restores it): with a low cap a workgroup takes several ranges ("first range writes, later ranges add").
  *   "mid_min_d", "mid_narrow_k" (process-wide) 0 / 0: the mid kernels (mimo_mid.hip) run where they measured fastest.  Otherwise
- *                  they take every shape they exist for with Dz >= mid_min_d (default 9; > 32: the route is off), and the narrow
+ *                  they take every shape they exist for with Dz >= mid_min_d (default 5; > 32: the route is off), and the narrow
  *                  kernels keep the shapes both cover with K < mid_narrow_k (default 33).
  * Results do not depend on either value beyond the documented summation order of the partial blocks.  MIMO_E_INVALID for
  * an unknown key or a value out of range.  The reference has no counterpart (launch geometry is ours). */

@@ -458,7 +458,7 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
   const int D = ctx->D;
   if (!plain || !mid_covers(K, D, ctx->structure)) return false;
   if (g_mid_min_d > 0 || g_mid_narrow_k > 0)       // forced by the caller (tests, sweeps)
-    return D >= (g_mid_min_d > 0 ? g_mid_min_d : 9) &&
+    return D >= (g_mid_min_d > 0 ? g_mid_min_d : 5) &&
            (K >= (g_mid_narrow_k > 0 ? g_mid_narrow_k : 33) || !use_narrow(ctx, K, false, plain, true));
   // measured (tools/mid_sweep.py, profiles/r04_mid_kernel_sweep.txt; fraction of the float64 rate, other route -> mid):
   //   K = 17 .. 32: from Dz = 13 (Dz=13 K=32 0.55 -> 0.61, Dz=14 0.58 -> 0.66, Dz=16 0.61 -> 0.64, Dz=20 0.41 -> 0.69, Dz=32 0.48 -> 0.75;
@@ -466,8 +466,17 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
   //   K = 13 .. 16: from Dz = 12 against the narrow kernels (Dz=12 K=16 0.41 -> 0.49, Dz=14 0.44 -> 0.58, Dz=16 0.42 -> 0.57; Dz=11 0.45 -> 0.43)
   //   K <= 12: the narrow kernels where they exist (Dz=16 K=12 0.44 = 0.44, Dz=15 0.42 -> 0.38, Dz=20 K=8 0.37 -> 0.30) up to Dz = 23
   //            (Dz=24 K=8 0.31 -> 0.32, Dz=26 K=8 0.19 -> 0.34); beyond them the two-stage path was all there was (Dz=20 K=12 0.18 -> 0.47)
+  //   K = 33 .. 48: from Dz = 9 (Dz=9 K=48 0.48 -> 0.55, Dz=12 0.56 -> 0.60, Dz=16 0.57 -> 0.67, Dz=20 0.46 -> 0.71, Dz=26 0.52 -> 0.80; Dz=10, 11: level)
+  //   K = 49 .. 64: from Dz = 18 (Dz=18 K=64 0.64 -> 0.68, Dz=20 0.61 -> 0.76, Dz=21 0.66 -> 0.79; below, ten column blocks do not divide over eight
+  //                 waves and the tile kernels keep K = 64: Dz=16 0.78 against 0.57)
+  //   K = 65 .. 96: wherever the kernels exist from Dz = 6 (five / six row blocks instead of the eight the tile and two-stage kernels pay for:
+  //                 Dz=8 K=96 0.43 -> 0.56, Dz=9 K=72 0.35 -> 0.56, Dz=12 K=96 0.46 -> 0.62, Dz=14 K=80 0.35 -> 0.71, Dz=16 K=80 0.42 -> 0.60)
+  if (K >= 65) return D >= 6;
+  if (K >= 49) return D >= 18;
+  if (K >= 33) return D >= 9;
   if (K >= 17) return D >= 13;
   if (K >= 13) return D >= 12;
+  if (K <= 4) return !use_narrow(ctx, K, false, plain, true);        // (one slot of the narrow kernels: Dz=28 K=4 0.30 against 0.17 on 16-padded tiles)
   return D >= 24 || !use_narrow(ctx, K, false, plain, true);
 }
 

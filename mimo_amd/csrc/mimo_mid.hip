@@ -1,5 +1,6 @@
-// gfx950 kernel for the MID shapes of the softmax + statistics pass: a handful to a few dozen components (K <= 32) over WIDE rows
-// (Dz = 9 .. 32, F = (Dz+1)(Dz+2)/2 up to 561 features).  The reference's hierarchical / tied examples with few components over wide
+// gfx950 kernel for the MID shapes of the softmax + statistics pass: a handful to a few dozen components over WIDE rows (K <= 32 up to
+// Dz = 32, F = (Dz+1)(Dz+2)/2 up to 561 features; K <= 48 up to Dz = 26, K <= 64 up to Dz = 21, K <= 96 up to Dz = 14 — while the
+// accumulators fit), and the component counts between the tile kernels' sizes (65 .. 96: five or six row blocks instead of eight).  The reference's hierarchical / tied examples with few components over wide
 // inputs land here as D grows (examples/hgmm/*.py, examples/tgmm/vi_tgmm.py; mimo/mixtures/gmm.py:244-259 E-step,
 // gaussian.py:491-502 statistics).  Until round 4 they ran the round-1 two-stage pair (estep_chunked_kernel, which pays for 64
 // component slots whatever K is, + fused_kernel statistics per column group through the (K, N) table in HBM): 0.13 - 0.50 of the
@@ -26,11 +27,14 @@ namespace mimo {
 constexpr int kMidPF = 8;                                        // Theta slices in flight per wave
 constexpr int mid_zs(int D) { return (D + 4) | 1; }              // row stride: z, 1, three zero slots; odd
 constexpr int mid_ncb(int D) { return ((D + 1) * (D + 2) / 2 + 15) / 16; }
-// waves per workgroup: 4 (two workgroups per CU) while a wave's share of the accumulators — KB x its column blocks x 8 registers —
-// leaves room for the E-step's registers (the lane's row shifted by q: 2 (Dz + 1)), else 8 (one workgroup per CU)
-constexpr int mid_nw(int D, int KB) { return KB * ((mid_ncb(D) + 3) / 4) > (D <= 18 ? 12 : D <= 20 ? 11 : 9) ? 8 : 4; }
-// KB = 3 (K <= 48) while eight waves can hold the block
-constexpr bool mid_exists(int D, int KB) { return KB <= 2 || (KB == 3 && D >= 13 && 3 * ((mid_ncb(D) + 7) / 8) <= 9); }
+// Registers of an instantiation (calibrated on the compiler's reports: D=24 KB=1 NW=4 216, D=20 KB=2 NW=4 236, D=16 KB=3 NW=4 240):
+// the wave's accumulators — KB x its column blocks x 8 —, the E-step's L tile (8 KB), the lane's row shifted by q (2 (Dz + 1)),
+// ~110 besides (Theta ring, prefetched rows, operand addresses and factors, the softmax).
+constexpr int mid_regs(int D, int KB, int NW) { return 8 * KB * ((mid_ncb(D) + NW - 1) / NW) + 8 * KB + 2 * (D + 1) + 110; }
+// waves per workgroup: 4 (two workgroups per CU) while that fits 256 registers, else 8 (one workgroup per CU); up to ~50 bytes of
+// scratch outside the loops cost nothing measurable (Dz=26 K=48: 0.80 of the float64 rate with 52 bytes)
+constexpr int mid_nw(int D, int KB) { return mid_regs(D, KB, 4) <= 250 ? 4 : 8; }
+constexpr bool mid_exists(int D, int KB) { return KB >= 1 && KB <= 6 && D >= 5 && D <= 32 && mid_regs(D, KB, mid_nw(D, KB)) <= (KB <= 2 ? 275 : 264); }
 // the z and R tiles are double-buffered (one barrier per super-step) where two copies fit, else single (two barriers)
 constexpr size_t mid_tile_bytes(int D, int KB) { return sizeof(double) * (size_t)16 * mid_nw(D, KB) * (mid_zs(D) + 16 * KB + 1); }
 constexpr int mid_nbuf(int D, int KB) { return 2 * mid_tile_bytes(D, KB) * (mid_nw(D, KB) == 4 ? 2 : 1) + 2048 <= 160 * 1024 ? 2 : 1; }
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mid_kernel(const Ker
       }
     }
     if constexpr (NBUF == 1) wg_sync();                 // single tiles: the next super-step's rows overwrite what the slowest wave still reads
-    if (++since_flush == 32) {           // 48^32 < 2^179 stays inside the float64 range
+    if (++since_flush == 32) {           // 96^32 < 2^211 stays inside the float64 range
       sc_lse += log(sc_prod);
       sc_prod = 1.0;
       since_flush = 0;
@@ -250,15 +254,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mid_kernel(const Ker
 typedef void (*mid_fn)(const KernelArgs);
 template <int D>
 static mid_fn pick_mid_d(int kb) {
-  if (kb == 1) return mid_kernel<D, 1, mid_nw(D, 1)>;
-  if (kb == 2) return mid_kernel<D, 2, mid_nw(D, 2)>;
+  if constexpr (mid_exists(D, 1)) { if (kb == 1) return mid_kernel<D, 1, mid_nw(D, 1)>; }
+  if constexpr (mid_exists(D, 2)) { if (kb == 2) return mid_kernel<D, 2, mid_nw(D, 2)>; }
   if constexpr (mid_exists(D, 3)) { if (kb == 3) return mid_kernel<D, 3, mid_nw(D, 3)>; }
+  if constexpr (mid_exists(D, 4)) { if (kb == 4) return mid_kernel<D, 4, mid_nw(D, 4)>; }
+  if constexpr (mid_exists(D, 5)) { if (kb == 5) return mid_kernel<D, 5, mid_nw(D, 5)>; }
+  if constexpr (mid_exists(D, 6)) { if (kb == 6) return mid_kernel<D, 6, mid_nw(D, 6)>; }
   return nullptr;
 }
 static mid_fn pick_mid(int D, int kb) {
   switch (D) {
 #define MIMO_MD(d) case d: return pick_mid_d<d>(kb);
-    MIMO_MD(9) MIMO_MD(10) MIMO_MD(11) MIMO_MD(12) MIMO_MD(13) MIMO_MD(14) MIMO_MD(15) MIMO_MD(16)
+    MIMO_MD(5) MIMO_MD(6) MIMO_MD(7) MIMO_MD(8) MIMO_MD(9) MIMO_MD(10) MIMO_MD(11) MIMO_MD(12) MIMO_MD(13) MIMO_MD(14) MIMO_MD(15) MIMO_MD(16)
     MIMO_MD(17) MIMO_MD(18) MIMO_MD(19) MIMO_MD(20) MIMO_MD(21) MIMO_MD(22) MIMO_MD(23) MIMO_MD(24) MIMO_MD(25) MIMO_MD(26) MIMO_MD(27)
     MIMO_MD(28) MIMO_MD(29) MIMO_MD(30) MIMO_MD(31) MIMO_MD(32)
 #undef MIMO_MD
@@ -270,7 +277,7 @@ static mid_fn pick_mid(int D, int kb) {
 // mimo_abi.cpp decides where it is preferred over the narrow / tile / row-owner kernels)
 bool mid_covers(int K, int D, int structure) {
   static const bool on = [] { const char* e = getenv("MIMO_MID"); return !e || atoi(e) != 0; }();       // tuning knob
-  return on && structure == 0 && K >= 1 && K <= 48 && D >= 9 && D <= 32 && pick_mid(D, (K + 15) / 16) != nullptr;
+  return on && structure == 0 && K >= 1 && K <= 96 && D >= 5 && D <= 32 && pick_mid(D, (K + 15) / 16) != nullptr;
 }
 int mid_steps(int D) { return narrow_group_steps(D); }
 int mid_pf() { return kMidPF; }
@@ -289,7 +296,7 @@ int mid_grid(const KernelArgs& a, int num_cu) {
 hipError_t launch_mid(const KernelArgs& a, int grid, hipStream_t stream) {
   const int kb = (a.K + 15) / 16;
   mid_fn fn = pick_mid(a.D, kb);
-  if (!fn || a.K > 48 || a.K16 != kb) return hipErrorInvalidValue;
+  if (!fn || a.K > 96 || a.K16 != kb) return hipErrorInvalidValue;
   const size_t lds = mid_lds_bytes(a.D, kb);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -36,7 +36,8 @@ def _check(engine, Z, c, b, W, weights=None):
 
 MID_SHAPES = [(D, K) for D in range(17, 33) for K in ((9, 32) if D % 2 else (16, 17))] + \
              [(27, 8), (32, 7), (30, 5), (24, 24), (32, 31), (20, 12), (28, 20),
-              (13, 33), (16, 48), (19, 48), (20, 40), (21, 35), (24, 48), (25, 41), (26, 48), (14, 16), (12, 13)]     # three row blocks: K <= 48 up to Dz = 26
+              (13, 33), (16, 48), (19, 48), (20, 40), (21, 35), (24, 48), (25, 41), (26, 48), (14, 16), (12, 13),
+              (8, 96), (6, 80), (9, 72), (12, 96), (14, 90), (16, 80), (10, 65), (18, 64), (21, 50), (20, 60), (9, 33), (11, 48)]     # three to six row blocks
 
 
 @pytest.mark.parametrize("D,K", MID_SHAPES)
@@ -75,7 +76,7 @@ def test_mid_kernels_vs_oracle(engine, D, K):
         assert So.n[K // 2] < 1e-290 and rel_err(So.sxx, sxx2) < 1e-11 and abs(sco[0] - lse2.sum()) < 1e-12 * abs(lse2.sum())
 
 
-@pytest.mark.parametrize("D,K", [(9, 9), (12, 16), (13, 32), (16, 17), (16, 32), (10, 24), (15, 12), (11, 30), (14, 16)])
+@pytest.mark.parametrize("D,K", [(9, 9), (12, 16), (13, 32), (16, 17), (16, 32), (10, 24), (15, 12), (11, 30), (14, 16), (5, 96), (7, 40), (16, 64), (5, 17)])
 def test_mid_kernels_below_their_default_range(engine, D, K):
     """Dz = 9 .. 16: the kernels exist there too (mimo_tune "mid_min_d" routes them); the router's default prefers the narrow /
     tile / row-owner kernels where they measured faster."""
@@ -83,7 +84,7 @@ def test_mid_kernels_below_their_default_range(engine, D, K):
     N = 20011
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    engine.tune("mid_min_d", 9)
+    engine.tune("mid_min_d", 5)
     engine.tune("mid_narrow_k", 1)
     try:
         assert engine.plan(K)["kind"] == "mid"

@@ -20,7 +20,7 @@ for D, K in shapes:
     FE, FS = D * (D + 1) + 3 * D + 8, (D + 1) * (D + 2) + 1
     flops = N * K * (FE + FS)
     out = []
-    for mind, nk in ((64, 33), (9, 33), (9, 1), (0, 0)):
+    for mind, nk in ((64, 33), (int(os.environ.get("MID_SWEEP_MIN_D", "9")), 33), (int(os.environ.get("MID_SWEEP_MIN_D", "9")), 1), (0, 0)):
         eng.tune("mid_min_d", mind); eng.tune("mid_narrow_k", nk)
         kind = eng.plan(K)["kind"]
         for it in range(2): eng.estep(c, b, W)
