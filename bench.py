@@ -125,25 +125,7 @@ def build_model(cfg, engine):
     return BayesianMixtureOfGaussians(gating, comps, engine=engine)
 
 
-def cpu_baseline(cfg, X_host):
-    """The reference algorithm's VI sweep (E-step table in 1024-row chunks as the reference's
-    (K,N,D,D) replication forces, softmax, weighted statistics) timed on the host cores."""
-    from oracle import mimo_oracle as O
-    _, _, D, K, mode = cfg
-    rng = np.random.default_rng(0)
-    A = rng.standard_normal((K, D, D))
-    post = (rng.standard_normal((K, D)) * 3, np.full(K, 100.0), np.linalg.inv(A @ A.transpose(0, 2, 1) / D + np.eye(D)) / 50.,
-            np.full(K, 60.0))
-    gpost = np.full(K, 50.0)
-
-    def sweep(x):
-        ll = O.gmm_expected_log_complete_likelihood(x, post, 'dirichlet', gpost, chunk=1024)
-        r = O.responsibilities(ll)
-        return O.gauss_weighted_statistics(x, r)
-    sweep(X_host[:2048])                                   # warm the BLAS threads / caches
-    t0 = time.time(); sweep(X_host[:8192]); dt = time.time() - t0
-    rows = int(min(len(X_host), max(8192, 1024 * round(15.0 / max(dt / 8.0, 1e-4)))))   # ~15 s of CPU work
-    t0 = time.time(); sweep(X_host[:rows]); dt = time.time() - t0
+def _blas_threads():
     threads = os.cpu_count()
     try:
         from threadpoolctl import threadpool_info
@@ -152,22 +134,91 @@ def cpu_baseline(cfg, X_host):
             threads = blas[0]["num_threads"]
     except Exception:
         pass
-    out = {"value": rows * K / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
-           "sample": f"first {rows} rows of the same synthetic data, one VI sweep of the NumPy restatement of the "
-                     f"reference (E-step in 1024-row chunks + softmax + weighted_statistics), {dt:.1f} s"}
+    return int(threads)
+
+
+def _timed_rows(sweep, X_host, probe_rows, budget_s, max_rows):
+    """Rows that take about `budget_s` seconds of `sweep` (linear in the rows: no cross-datum coupling), and their time."""
+    sweep(X_host[:min(len(X_host), probe_rows // 4)])                      # warm the BLAS threads / caches
+    t0 = time.time(); sweep(X_host[:probe_rows]); dt = time.time() - t0
+    rows = int(min(len(X_host), max_rows, max(probe_rows, 1024 * round(probe_rows * budget_s / max(dt, 1e-4) / 1024))))
+    t0 = time.time(); sweep(X_host[:rows]); dt = time.time() - t0
+    return rows, dt
+
+
+def cpu_baseline(cfg, X_host):
+    """The NumPy restatement of the reference's sweep for this configuration (oracle/, verified equal to the reference on
+    the golden vectors), timed on the host cores on a bounded prefix of the same data:
+      vi    — E-step table in 1024-row chunks (the reference's (K,N,D,D) replication forces them: gaussian.py:481-485), softmax,
+              weighted_statistics;
+      gibbs — the label step un-chunked (gaussian.py:510-521 table + mimo/utils/stats.py:8-21 draw) + one_hot +
+              weighted_statistics of the drawn labels (gaussian.py:491-502), rows bounded by the (K,N,D) temporaries (2 GB);
+      ilr   — the VI sweep of the linear-Gaussian experts (bayesian.py:933-947 + 287-301 tables in chunks, softmax,
+              lingauss.py:306-322 + gaussian.py:491-502 statistics)."""
+    from oracle import mimo_oracle as O
+    _, _, D, K, mode = cfg
+    rng = np.random.default_rng(0)
+    if mode == "gibbs":
+        A = rng.standard_normal((K, D, D))
+        mus, lmbdas = rng.standard_normal((K, D)) * 3, A @ A.transpose(0, 2, 1) / D + np.eye(D)
+        probs = rng.dirichlet(np.ones(K))
+
+        def sweep(x):
+            lp = O.gmm_log_complete_likelihood(x, mus, lmbdas, probs)
+            labels = O.sample_discrete_from_log(lp, rng.random((1, len(x))))
+            return O.gauss_weighted_statistics(x, O.one_hot(labels, K))
+        what = "one Gibbs label step + weighted_statistics of the drawn labels, un-chunked"
+        probe, max_rows = 8192, int(2e9 / (8 * K * D))
+    elif mode == "ilr":
+        dx, dy = (8, 4) if D == 12 else (D // 2, D - D // 2)
+        A = rng.standard_normal((K, dx, dx))
+        bpost = (rng.standard_normal((K, dx)) * 3, np.full(K, 100.0), np.linalg.inv(A @ A.transpose(0, 2, 1) / dx + np.eye(dx)) / 50.,
+                 np.full(K, 60.0))
+        B = rng.standard_normal((K, dy, dy))
+        mpost = (rng.standard_normal((K, dy, dx + 1)), np.stack(K * [np.eye(dx + 1)]) * 50.,
+                 np.linalg.inv(B @ B.transpose(0, 2, 1) / dy + np.eye(dy)) / 50., np.full(K, 60.0))
+        gpost = np.full(K, 50.0)
+
+        def sweep(z):
+            x, y = z[:, :dx], z[:, dx:]
+            r = O.responsibilities(O.ilr_expected_log_complete_likelihood(x, y, bpost, mpost, 'dirichlet', gpost))
+            return O.gauss_weighted_statistics(x, r), O.lingauss_weighted_statistics(x, y, r)
+        what = "one VI sweep of the linear-Gaussian experts (E-step tables in chunks + softmax + both weighted_statistics)"
+        probe, max_rows = 4096, len(X_host)
+    else:
+        A = rng.standard_normal((K, D, D))
+        post = (rng.standard_normal((K, D)) * 3, np.full(K, 100.0), np.linalg.inv(A @ A.transpose(0, 2, 1) / D + np.eye(D)) / 50.,
+                np.full(K, 60.0))
+        gpost = np.full(K, 50.0)
+
+        def sweep(x):
+            ll = O.gmm_expected_log_complete_likelihood(x, post, 'dirichlet', gpost, chunk=1024)
+            r = O.responsibilities(ll)
+            return O.gauss_weighted_statistics(x, r)
+        what = "one VI sweep (E-step in 1024-row chunks + softmax + weighted_statistics)"
+        probe, max_rows = 8192, len(X_host)
+    rows, dt = _timed_rows(sweep, X_host, probe, 15.0, max_rows)           # ~15 s of CPU work
+    out = {"value": rows * K / dt, "unit": "evals/s", "cores": _blas_threads(), "kind": "port",
+           "sample": f"first {rows} rows of the same synthetic data, {what} of the NumPy restatement of the reference, {dt:.1f} s"}
     try:      # per-core figure (SURVEY.md section 8(d)): the same sweep with the BLAS pool limited to one thread, ~5 s
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1, user_api="blas"):
-            t0 = time.time(); sweep(X_host[:4096]); probe = time.time() - t0
-            r1 = int(min(len(X_host), max(4096, 1024 * round(4096 * 5.0 / max(probe, 1e-4) / 1024))))
-            t0 = time.time(); sweep(X_host[:r1]); d1 = time.time() - t0
+            r1, d1 = _timed_rows(sweep, X_host, probe // 2, 5.0, max_rows)
         out["one_core"] = {"value": r1 * K / d1, "unit": "evals/s", "cores": 1, "sample": f"first {r1} rows, {d1:.1f} s"}
     except Exception:
         pass
     return out
 
 
-def self_launch(args, argv):
+def _rank_ordered(engine):
+    """Which association the sum over the ranks has: the torch route follows ShardedEngine (MIMO_SHARDED_RANK_ORDER), the native
+    route the library's own switch (mimo_comm.cpp: MIMO_COMM_RANK_ORDER, default on)."""
+    if getattr(engine, "_native", False):
+        return os.environ.get("MIMO_COMM_RANK_ORDER", "1") != "0"
+    return bool(getattr(engine, "_rank_order", False))
+
+
+def self_launch(args, argv, launcher=None):
     """`python bench.py --gpus N` (N > 1) outside a distributed launcher: start the N ranks as children of a fresh
     torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has touched the GPU (torch is not
     even imported yet) and nothing is exec'ed: the launcher is a child process, its return code is ours."""
@@ -176,7 +227,7 @@ def self_launch(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+           "--master-addr", "127.0.0.1", "--master-port", str(port), launcher or os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
@@ -193,7 +244,10 @@ def self_launch(args, argv):
     raise SystemExit(0)
 
 
-def main():
+def main(argv=None, engine_factory=None, launcher=None):
+    """`engine_factory` / `launcher` are for callers that import this module (tests/bench_dry_run.py runs the step loop on the CPU
+    with an engine double: the ranks then sit on gloo and the line is marked dry_run and carries no measurement); the script
+    itself never sets them and imports nothing outside the product package (+ oracle/ for the cpu_baseline leg)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -206,15 +260,11 @@ def main():
                     help="drop the reference's per-iteration likelihood.params = posterior.rvs() (sample_likelihood=False)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0,
                     help="length of the sustained leg after the timed steps (>= 10 s: a 5-second utilisation sampler must see it)")
-    args = ap.parse_args()
-    # TEST HOOK, deliberately not a command-line argument of the measurement script: tests/test_bench_launch.py sets
-    # MIMO_BENCH_DRY_RUN_ENGINE='module:Class' (an engine double under tests/); the ranks then run on the CPU over gloo and the
-    # JSON line is marked dry_run and carries no measurement
-    args.dry_run_engine = os.environ.get("MIMO_BENCH_DRY_RUN_ENGINE", "")
+    args = ap.parse_args(argv)
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None and "RANK" not in os.environ:
-        self_launch(args, sys.argv[1:])
+        self_launch(args, sys.argv[1:] if argv is None else list(argv), launcher)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
@@ -222,7 +272,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    dry = bool(args.dry_run_engine)
+    dry = engine_factory is not None
     if not dry:
         torch.cuda.set_device(local_rank)
     device = "cpu" if dry else f"cuda:{local_rank}"
@@ -245,10 +295,7 @@ def main():
         N = args.rows
     X = make_data(N, D, K, seed=1337 + rank, device=device, ilr=(mode == "ilr"))
     if dry:
-        import importlib
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        mod, cls = args.dry_run_engine.split(":")
-        hip = getattr(importlib.import_module(mod), cls)()
+        hip = engine_factory()
         hip.upload(X.numpy())
     else:
         from mimo_amd.engine import HipEngine
@@ -356,7 +403,7 @@ def main():
             "allreduce_bytes_per_step": (8 * (K * (1 + D + D * D) + 4)) if dist is not None else 0,
             "allreduce_route": (("libmimo_hip RCCL communicator" if getattr(engine, "_native", False) else
                                  "torch.distributed (" + dist.get_backend() + ")")
-                                + (", all-gather + sum in rank order" if getattr(engine, "_rank_order", False) else ", all_reduce(sum)")
+                                + (", all-gather + sum in rank order" if _rank_ordered(engine) else ", all_reduce(sum)")
                                 if dist is not None else None),
             "config": {"workload": desc, "rows_per_gpu": N, "Dz": D, "K": K,
                        "step": "one iteration of the public driver loop ("
@@ -402,7 +449,7 @@ def main():
             out["elbo_first_last"] = [float(vlb[0]), float(vlb[-1])]
         if sustained:
             out["sustained"] = sustained
-        if world == 1 and not args.no_cpu_baseline and mode == "vi" and not dry:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(cfg, X[:600_000].cpu().numpy())
         else:
             out["cpu_baseline"] = None
