@@ -374,6 +374,13 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_MID        7   /* softmax pass of the mid shapes (K <= 96; mimo_mid.hip): row-owner E-step + column-owner statistics waves */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
 
+/* The same routing decision for a SHAPE — rows of Dz columns, N of them, K components, structure MIMO_STRUCT_*, softmax pass
+ * (gibbs = 0) or label pass — without a context, data or a device: out8[0 .. 5] as mimo_plan (out8[6], the grid, stays 0:
+ * it depends on the device's occupancy), and, if desc is not NULL, a one-line description of the kernels of the pass.  Host-only
+ * (runs on a machine without a GPU): what ROUTING.md is generated from and what tests/test_routing.py checks it against, so the
+ * routing constants are tested, not narrated.  No reference counterpart. */
+int mimo_plan_shape(int Dz, int K, int structure, int64_t N, int gibbs, int64_t* out8, char* desc, int desc_len);
+
 /* Checksum of the rows as mimo_upload received them (before rows with NaN are zeroed in the library's copy): the function
  * mimo_host_checksum defines, computed on the device inside the NaN scan of the upload (one read of Z either way).  A caller that
  * keeps the host array can compare the two to learn whether the array was edited since the upload (engine.bind() does, on a

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mimo_profile_kernels": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mimo_shader_clock_mhz": (C.c_int, [_vp, _dp]),
     "mimo_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "mimo_plan_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]),
     "mimo_nan_info": (C.c_int, [_vp, C.POINTER(C.c_int64), _vp, C.c_int, _vp]),
     "mimo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mimo_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),

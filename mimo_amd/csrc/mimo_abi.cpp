@@ -1651,6 +1651,69 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len) {
   });
 }
 
+// The routing decision of mimo_plan without anything that needs a device: kind, launches, passes (out8[6] — the grid — stays 0),
+// and a one-line description of the kernels (desc, may be null).
+static void plan_route(const mimo_ctx* ctx, const KernelArgs& a, int K, int gibbs, int64_t* out8, char* desc, size_t dlen) {
+  const int ncb = a.F16 / 16, D = ctx->D;
+  char lst[160] = "";           // the label-statistics stage of a label pass
+  auto label_stage = [&]() {
+    const int ll = label_stats_launches(K, D, ctx->structure);
+    if (label_stats_uses_slots(K, D, a.N)) snprintf(lst, sizeof lst, "label_slots_kernel + label_stats_slots_kernel");
+    else if (ctx->structure == 0 && D >= 10 && label_stats_sorted(K, D, ctx->structure)) snprintf(lst, sizeof lst, "label_tile_sort_kernel + label_stats_sorted_kernel");
+    else if (ctx->structure != 0 || D <= 9) snprintf(lst, sizeof lst, "label_stats_kernel");
+    else if (D <= 16 && ll * 128 >= K && (K <= 64 || ll == (K + 127) / 128)) snprintf(lst, sizeof lst, "label_stats_wide_kernel x %d", ll);
+    else snprintf(lst, sizeof lst, "label_stats_xwide_kernel x %d", ll);
+    return ll;
+  };
+  memset(out8, 0, 8 * sizeof(int64_t));
+  out8[4] = 1;                           // passes over Z
+  out8[5] = gibbs ? 1 : 0;               // passes over the labels
+  if (!gibbs && use_mid(ctx, K, true)) {
+    out8[0] = MIMO_PLAN_MID; out8[1] = 1;
+    if (desc) snprintf(desc, dlen, "mid_kernel<Dz=%d, row blocks %d, %d waves>", D, (K + 15) / 16, mid_rows_per_step(K, D) / 16);
+  } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true, true)) {
+    out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
+    if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
+    if (nm == 2) label_stage();
+    if (desc) snprintf(desc, dlen, "narrow_kernel<%d slots, %d steps%s, %s>%s%s", narrow_v(K), narrow_steps(K, ctx->F, D, nm - 1),
+                       narrow_dt(K, ctx->F, D, nm - 1) ? ", grouped" : "", nm == 1 ? "softmax + statistics" : nm == 2 ? "label draw" : "label draw + statistics",
+                       nm == 2 ? " + " : "", nm == 2 ? lst : "");
+  } else if (use_small(ctx, K)) {
+    out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
+    if (desc) snprintf(desc, dlen, "small_kernel<%d components per lane, %d lanes per row>", small_kl(D, K), small_g(D, K));
+  } else if (!gibbs && ctx->n_bad == 0 && D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
+    out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
+    if (desc) snprintf(desc, dlen, "vi_rowwave_kernel<%d row blocks>", K <= 32 ? 2 : 4);
+  } else if (gibbs && use_rowwave(ctx, K, false)) {
+    const int ll = label_stage();     // (> 1: the sliced statistics of the large shapes)
+    out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 1 + ll;
+    out8[4] = 1 + ll;                    // Z: label kernel + every statistics launch
+    out8[5] = 1 + ll;                    // labels written once, read once per statistics launch
+    if (desc) snprintf(desc, dlen, "%s<%d row blocks> + %s", gibbs_rowwave_counts_labels(K, ctx->F16, a.ZS) ? "gibbs_rowwave_kernel" : "gibbs_stream_kernel",
+                       rowwave_kb_shape(K, ctx->F16, a.ZS), lst);
+  } else if (fused_covers(a.K16, ncb, kSrcEstep)) {
+    out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;
+    if (desc) snprintf(desc, dlen, "fused_kernel<%d column blocks, %d row block%s per wave%s>", ncb, a.K16 <= 4 ? 1 : a.K16 <= 8 ? 2 : a.K16 <= 12 ? 3 : 4,
+                       a.K16 <= 4 ? "" : "s", K <= 32 && D >= 7 ? ", work split over the waves" : "");
+  } else {
+    const bool wide = !gibbs && wide_stats_covers(a.K16, D);       // as run_pass
+    const int gmax = wide ? wide_stats_group_ncb(a.K16, ncb) : stats_group_ncb(a.K16), groups = (ncb + gmax - 1) / gmax;
+    out8[0] = MIMO_PLAN_TWO_STAGE; out8[1] = 1 + groups;
+    out8[2] = gibbs ? 0 : 1;             // the (K, N) responsibility table goes through HBM
+    out8[3] = gibbs ? 0 : groups;        // and is read once per statistics launch
+    out8[4] = 1 + groups;                // Z: the E-step + every statistics launch
+    out8[5] = gibbs ? 1 + groups : 0;
+    const char* est = wide_estep_covers(a.K16, D, a.F16, gibbs) ? "wide_estep_kernel" : "estep_chunked_kernel";
+    if (gibbs && label_stats_covers(K, D, ctx->structure)) {      // label-indexed statistics (as run_pass)
+      const int ll = label_stage();
+      out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
+      if (desc) snprintf(desc, dlen, "%s (label draw) + %s", est, lst);
+    } else if (desc) {
+      snprintf(desc, dlen, "%s (%s) + %s x %d", est, gibbs ? "label draw" : "softmax -> (K, N) table", wide ? "wide_stats_kernel" : "fused_kernel (statistics)", groups);
+    }
+  }
+}
+
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   return guarded(ctx, [&]() -> int {
   int rc = bind(ctx); if (rc) return rc;
@@ -1660,51 +1723,40 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   KernelArgs a;
   fill_args(ctx, K, &a);
   a.gibbs = gibbs ? 1 : 0;
-  const int ncb = a.F16 / 16;
-  memset(out8, 0, 8 * sizeof(int64_t));
-  out8[4] = 1;                           // passes over Z
-  out8[5] = gibbs ? 1 : 0;               // passes over the labels
-  if (!gibbs && use_mid(ctx, K, true)) {
-    out8[0] = MIMO_PLAN_MID; out8[1] = 1;
-    out8[6] = mid_grid(a, ctx->num_cu);
-  } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true, true)) {
-    out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
-    if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
-    out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, nm - 1);
-  } else if (use_small(ctx, K)) {
-    out8[0] = MIMO_PLAN_SMALL; out8[1] = 1;
-    out8[6] = small_grid(a, ctx->num_cu, kSrcEstep);
-  } else if (!gibbs && ctx->n_bad == 0 && ctx->D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
-    out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
-    out8[6] = rowwave_grid(a, ctx->num_cu);
-  } else if (gibbs && use_rowwave(ctx, K, false)) {
-    const int ll = label_stats_launches(K, ctx->D, ctx->structure);     // (> 1: the sliced statistics of the large shapes)
-    out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 1 + ll;
-    out8[4] = 1 + ll;                    // Z: label kernel + every statistics launch
-    out8[5] = 1 + ll;                    // labels written once, read once per statistics launch
-    out8[6] = rowwave_grid(a, ctx->num_cu);
-  } else if (fused_covers(a.K16, ncb, kSrcEstep)) {
-    out8[0] = MIMO_PLAN_FUSED; out8[1] = 1;
-    out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
-  } else {
-    const bool wide = !gibbs && wide_stats_covers(a.K16, ctx->D);       // as run_pass
-    const int gmax = wide ? wide_stats_group_ncb(a.K16, ncb) : stats_group_ncb(a.K16), groups = (ncb + gmax - 1) / gmax;
-    out8[0] = MIMO_PLAN_TWO_STAGE; out8[1] = 1 + groups;
-    out8[2] = gibbs ? 0 : 1;             // the (K, N) responsibility table goes through HBM
-    out8[3] = gibbs ? 0 : groups;        // and is read once per statistics launch
-    out8[4] = 1 + groups;                // Z: the E-step + every statistics launch
-    out8[5] = gibbs ? 1 + groups : 0;
-    if (gibbs && label_stats_covers(K, ctx->D, ctx->structure)) {      // label-indexed statistics (as run_pass)
-      const int ll = label_stats_launches(K, ctx->D, ctx->structure);
-      out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
-    }
-    out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
-    if (wide_estep_covers(a.K16, ctx->D, a.F16, gibbs)) {                // as run_pass: two workgroups per CU
-      const int64_t g2 = 2 * (int64_t)ctx->num_cu;
-      out8[6] = g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1);
-    }
+  plan_route(ctx, a, K, gibbs, out8, nullptr, 0);
+  switch (out8[0]) {
+    case MIMO_PLAN_MID: out8[6] = mid_grid(a, ctx->num_cu); break;
+    case MIMO_PLAN_NARROW: out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, use_narrow(ctx, K, gibbs != 0, true, true) - 1); break;
+    case MIMO_PLAN_SMALL: out8[6] = small_grid(a, ctx->num_cu, kSrcEstep); break;
+    case MIMO_PLAN_ROWWAVE_VI: case MIMO_PLAN_ROWWAVE: out8[6] = rowwave_grid(a, ctx->num_cu); break;
+    case MIMO_PLAN_FUSED: out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep); break;
+    default:
+      out8[6] = fused_grid(a, ctx->num_cu, kSrcEstep);
+      if (wide_estep_covers(a.K16, ctx->D, a.F16, gibbs)) {                // as run_pass: two workgroups per CU
+        const int64_t g2 = 2 * (int64_t)ctx->num_cu;
+        out8[6] = g2 < a.ntiles ? g2 : (a.ntiles > 0 ? a.ntiles : 1);
+      }
   }
   out8[7] = ctx->num_cu;
+  return MIMO_OK;
+  });
+}
+
+int mimo_plan_shape(int Dz, int K, int structure, int64_t N, int gibbs, int64_t* out8, char* desc, int desc_len) {
+  return guarded(nullptr, [&]() -> int {
+  if (!out8) return fail(nullptr, MIMO_E_INVALID, "mimo_plan_shape: out is NULL");
+  if (Dz < 1 || Dz > kMaxD || K < 1 || K > 256 || N < 0 || structure < 0 || structure > 2)
+    return fail(nullptr, MIMO_E_UNSUPPORTED, "mimo_plan_shape: Dz = %d, K = %d, structure = %d outside the library's range", Dz, K, structure);
+  mimo_ctx ctx;                        // a description of the data, never a device context: no HIP call below
+  alignas(16) static const double aligned_rows[2] = {0.0, 0.0};
+  ctx.Z = aligned_rows; ctx.N = N; ctx.D = Dz; ctx.structure = structure;
+  ctx.F = structure == MIMO_STRUCT_DIAG ? diag_feat_count(Dz) : structure == MIMO_STRUCT_LINEAR ? lin_feat_count(Dz) : feat_count(Dz);
+  ctx.F16 = (ctx.F + 15) / 16 * 16;
+  KernelArgs a;
+  fill_args(&ctx, K, &a);
+  a.gibbs = gibbs ? 1 : 0;
+  if (desc && desc_len > 0) desc[0] = 0;
+  plan_route(&ctx, a, K, gibbs, out8, desc, desc && desc_len > 0 ? (size_t)desc_len : 0);
   return MIMO_OK;
   });
 }

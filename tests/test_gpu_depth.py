@@ -261,3 +261,20 @@ def test_bind_finds_one_edited_element_of_a_64_mb_array(engine):
     lab5, _ = engine.gibbs_labels(c, b, W, seed=1, sweep=1, stats=False)
     assert np.array_equal(S4.sxx, S5.sxx) and np.array_equal(lab, lab5)
     E.unbind(engine)
+
+
+def test_plan_with_data_agrees_with_the_shape_router(engine):
+    """mimo_plan (context + resident data) and mimo_plan_shape (host-only, what ROUTING.md is generated from) take the same decision."""
+    import ctypes as C
+    from mimo_amd import _lib
+    lib = _lib.load()
+    kinds = {1: "fused", 2: "two-stage", 3: "small", 4: "rowwave", 5: "rowwave-vi", 6: "narrow", 7: "mid"}
+    N = 140_000
+    for D in (1, 2, 3, 4, 5, 8, 9, 10, 12, 13, 16, 17, 20, 24, 27, 32):
+        engine.upload(np.zeros((N, D)))
+        for K in (1, 4, 8, 12, 16, 17, 32, 33, 48, 64, 65, 96, 97, 128, 129, 200, 256):
+            for gibbs in (False, True):
+                out = (C.c_int64 * 8)()
+                assert lib.mimo_plan_shape(D, K, 0, N, 1 if gibbs else 0, out, None, 0) == 0
+                p = engine.plan(K, gibbs=gibbs)
+                assert p["kind"] == kinds[out[0]] and p["kernels_per_pass"] == out[1] and p["data_passes"] == out[4], (D, K, gibbs, p, list(out))
