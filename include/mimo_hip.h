@@ -66,6 +66,7 @@ typedef struct mimo_ctx mimo_ctx;
 #define MIMO_F_DEVICE_IN      0x20  /* `resp` / `labels` / `u` inputs are device pointers          */
 #define MIMO_F_ENTROPY_SPLIT  0x40  /* also produce scalars[1], scalars[2] (see above)             */
 #define MIMO_F_ASYNC          0x80  /* enqueue only; fetch the host results with mimo_wait()       */
+#define MIMO_F_DIAG_VAR       0x200 /* mimo_predict_flags: the second output is (N, dy) variances followed by (N, dy) standard deviations */
 #define MIMO_F_WEIGHTS_RESIDENT 0x100 /* mimo_estep_weighted: reuse the row weights the previous weighted call uploaded
                                          (the hierarchical drivers pass the same vector every iteration: N doubles less
                                          over PCIe per call); `row_weights` is ignored                                */
@@ -228,7 +229,8 @@ int mimo_predict(mimo_ctx* ctx, const double* c, const double* b, const double* 
                  const double* M, const double* Q, const double* Cc, int dy, int affine, int mode,
                  const double* y, const double* P, const double* ld,
                  double* mu, double* covar, double* nlpd);
-/* The same with flags: MIMO_F_DEVICE_IN — y is a device pointer; MIMO_F_DEVICE_OUT — mu, covar (and nlpd) are device
+/* The same with flags: MIMO_F_DIAG_VAR — `covar` receives 2 N dy doubles: the variances (N, dy) (the diagonal of the covariance:
+ * what the reference's callers read, ilr.py:411-417) followed by the standard deviations (N, dy); MIMO_F_DEVICE_IN — y is a device pointer; MIMO_F_DEVICE_OUT — mu, covar (and nlpd) are device
  * pointers the kernel writes directly, and the call returns without waiting (the results are ordered on the context's
  * stream like every other launch: mimo_set_stream / the caller's next stream operation).  With both flags nothing but
  * the K parameter blocks crosses PCIe: at N = 4e6, dx = dy = 1 the host-array form spends 120 of its 125 ms there. */

@@ -16,6 +16,7 @@ OK = 0
 E_INVALID, E_HIP, E_NODATA, E_UNSUPPORTED, E_STATE, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 F_KEEP_RESP, F_KEEP_LOGP, F_KEEP_LSE, F_NO_STATS, F_DEVICE_OUT, F_DEVICE_IN, F_ENTROPY_SPLIT, F_ASYNC = 1, 2, 4, 8, 0x10, 0x20, 0x40, 0x80
 F_WEIGHTS_RESIDENT = 0x100
+F_DIAG_VAR = 0x200
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -1370,7 +1370,8 @@ int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const do
                        const double* y, const double* P, const double* ld,
                        double* mu, double* covar, double* nlpd, int flags) {
   return guarded(ctx, [&]() -> int {
-  const bool dev_in = (flags & MIMO_F_DEVICE_IN) != 0, dev_out = (flags & MIMO_F_DEVICE_OUT) != 0;
+  const bool dev_in = (flags & MIMO_F_DEVICE_IN) != 0, dev_out = (flags & MIMO_F_DEVICE_OUT) != 0, diag = (flags & MIMO_F_DIAG_VAR) != 0;
+  const size_t ncov = diag ? 2 * (size_t)dy : (size_t)dy * dy;        // doubles of the second output per row
   int rc = bind(ctx); if (rc) return rc;
   if (!ctx->Z) return fail(ctx, MIMO_E_NODATA, "mimo_predict: no data resident (call mimo_upload)");
   if (!c || !b || !W || !M || !Q || !Cc || !mu || !covar || K < 1 || (mode != 0 && mode != 1))
@@ -1382,7 +1383,7 @@ int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const do
   const size_t ng = (size_t)K * (1 + dx + (size_t)dx * dx), nM = (size_t)K * dy * dc, nQ = (size_t)K * dc * dc,
                nC = (size_t)K * dy * dy;
   const size_t nparam = ng + nM + nQ + 2 * nC + K;
-  const size_t nout = dev_out ? 0 : (size_t)N * (dy + (size_t)dy * dy + 1), nin = (want_nlpd && !dev_in) ? (size_t)N * dy : 0;
+  const size_t nout = dev_out ? 0 : (size_t)N * (dy + ncov + 1), nin = (want_nlpd && !dev_in) ? (size_t)N * dy : 0;
   // parameters | outputs | y, all in the staged-weights workspace
   if ((rc = ensure_dev(ctx, &ctx->win, &ctx->win_cap, nparam + nout + nin + 1))) return rc;
   std::vector<double> h(nparam);
@@ -1400,13 +1401,13 @@ int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const do
   double* d = ctx->win;
   HIP_TRY(ctx, hipMemcpyAsync(d, h.data(), nparam * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   PredictArgs a{};
-  a.Z = ctx->Z; a.N = N; a.dx = dx; a.dc = dc; a.dy = dy; a.K = K; a.mode = mode;
+  a.Z = ctx->Z; a.N = N; a.dx = dx; a.dc = dc; a.dy = dy; a.K = K; a.mode = mode; a.diag = diag ? 1 : 0;
   a.gate = d; a.M = d + ng; a.Q = a.M + nM; a.Cc = a.Q + nQ; a.P = a.Cc + nC; a.ld = a.P + nC;
   double* out = d + nparam;
   if (dev_out) {
     a.mu = mu; a.covar = covar; a.nlpd = want_nlpd ? nlpd : nullptr;
   } else {
-    a.mu = out; a.covar = out + (size_t)N * dy; a.nlpd = want_nlpd ? a.covar + (size_t)N * dy * dy : nullptr;
+    a.mu = out; a.covar = out + (size_t)N * dy; a.nlpd = want_nlpd ? a.covar + (size_t)N * ncov : nullptr;
   }
   if (want_nlpd) {
     if (dev_in) {
@@ -1429,7 +1430,7 @@ int mimo_predict_flags(mimo_ctx* ctx, const double* c, const double* b, const do
   if (dev_out) return MIMO_OK;
   if (N > 0) {
     HIP_TRY(ctx, hipMemcpyAsync(mu, a.mu, (size_t)N * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(covar, a.covar, (size_t)N * dy * dy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(covar, a.covar, (size_t)N * ncov * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (want_nlpd) HIP_TRY(ctx, hipMemcpyAsync(nlpd, a.nlpd, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -135,10 +135,12 @@ struct PredictArgs {
   const double* P;      // [K][dy][dy]   precision at cs = 1 (for the predictive log-density), or null
   const double* ld;     // [K]           logdet P
   double* mu; double* covar; double* nlpd;
+  int diag;             // 1: covar receives the variances [N][dy] followed by the standard deviations [N][dy] (MIMO_F_DIAG_VAR)
 };
 constexpr int kMaxPredictDy = 8;
 constexpr double kPadLogDensity = -1e300;   // c_k of the padding components k in [K, 16*K16)
 constexpr double kOffLogDensity = -1e299;   // l below this: a padding or switched-off component (its l is -1e300 to the last bit)
 hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupported);
+bool launch_predict_reg(const PredictArgs& a, hipStream_t stream, hipError_t* err);      // mimo_predict.hip: dx <= 8 with the affine column
 
 }  // namespace mimo

@@ -941,8 +941,14 @@ __global__ __launch_bounds__(256) void predict_kernel(const PredictArgs a) {
 #pragma unroll
       for (int d = 0; d < DY; ++d) {
         a.mu[n * DY + d] = m[d];
+        if (a.diag) {
+          const double v = cs * Ck[d * DY + d];
+          a.covar[n * DY + d] = v;
+          a.covar[(a.N + n) * DY + d] = sqrt(v);
+        } else {
 #pragma unroll
-        for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = cs * Ck[d * DY + e];
+          for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = cs * Ck[d * DY + e];
+        }
       }
     }
     if (a.nlpd) {               // the log-normaliser is still needed for the weights inside nlpd
@@ -956,8 +962,14 @@ __global__ __launch_bounds__(256) void predict_kernel(const PredictArgs a) {
 #pragma unroll
     for (int d = 0; d < DY; ++d) {
       a.mu[n * DY + d] = amu[d];
+      if (a.diag) {
+        const double v = aS[d][d] * inv - amu[d] * amu[d];
+        a.covar[n * DY + d] = v;
+        a.covar[(a.N + n) * DY + d] = sqrt(v);
+      } else {
 #pragma unroll
-      for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = aS[d][e] * inv - amu[d] * amu[e];
+        for (int e = 0; e < DY; ++e) a.covar[(n * DY + d) * DY + e] = aS[d][e] * inv - amu[d] * amu[e];
+      }
     }
   }
   if (a.nlpd) {
@@ -1331,6 +1343,8 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t stream, bool* unsupp
   *unsupported = a.dy < 1 || a.dy > kMaxPredictDy || a.dc > kMaxD + 1;
   if (*unsupported) return hipSuccess;
   if (a.N <= 0) return hipSuccess;
+  hipError_t reg_err = hipSuccess;
+  if (launch_predict_reg(a, stream, &reg_err)) return reg_err;      // narrow inputs (dx <= 8, affine): x~ in registers (mimo_predict.hip)
   fn_t fn = table[a.dy - 1];
   const size_t lds = (size_t)a.dc * 256 * sizeof(double);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),

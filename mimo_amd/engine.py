@@ -567,10 +567,25 @@ class HipEngine(BoundDataGuard):
             self._check(self._lib.mimo_table_entropy(self._ctx, _ptr(table), table.size, 0, C.byref(out)))
         return out.value
 
+    @staticmethod
+    def _host_out(shape):
+        """Output array for a large copy-out: page-locked (through PyTorch's caching host allocator) when it is big enough for the
+        transfer rate to matter — a device-to-host copy into pageable memory runs at a third of the PCIe rate."""
+        n = int(np.prod(shape))
+        if n >= (1 << 20):
+            try:
+                import torch
+                return torch.empty(shape, dtype=torch.float64, pin_memory=True).numpy()     # (the array keeps the tensor alive)
+            except Exception:
+                pass
+        return np.empty(shape)
+
     @checked
-    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
+    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None, variance='full'):
         """Posterior-predictive mixture moments of every resident row (mimo_predict).
-        Returns (mu (N,dy), covar (N,dy,dy), nlpd (N) | None)."""
+        Returns (mu (N,dy), covar (N,dy,dy), nlpd (N) | None); with variance='diagonal' the second entry is the pair
+        (var (N,dy), std (N,dy)) computed on the device — what the reference's callers read (ilr.py:411-417) — and a quarter
+        (dy = 4) of the bytes cross PCIe."""
         c, b, W, K = self._params(c, b, W)
         M, Q, Cc = _f64(M), _f64(Q), _f64(Cc)
         dy, dc = M.shape[1], self.D + (1 if affine else 0)
@@ -578,18 +593,23 @@ class HipEngine(BoundDataGuard):
             raise ValueError(f"predictive blocks {M.shape}, {Q.shape}, {Cc.shape} do not match K={K}, dy={dy}, dc={dc}")
         if mode not in ('average', 'mode'):
             raise NotImplementedError(mode)
-        mu, covar = np.empty((self.N, dy)), np.empty((self.N, dy, dy))
+        if variance not in ('full', 'diagonal'):
+            raise ValueError(variance)
+        diag = variance == 'diagonal'
+        mu = self._host_out((self.N, dy))
+        covar = self._host_out((2, self.N, dy)) if diag else self._host_out((self.N, dy, dy))
         nlpd = None
         if y is not None:
             y, P, ld = _f64(y).reshape(self.N, dy), _f64(P), _f64(ld)
             if P.shape != (K, dy, dy) or ld.shape != (K,):
                 raise ValueError("nlpd needs P (K,dy,dy) and ld (K,)")
             nlpd = np.empty(self.N)
-        self._check(self._lib.mimo_predict(
+        self._check(self._lib.mimo_predict_flags(
             self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(M), _ptr(Q), _ptr(Cc), dy, 1 if affine else 0,
             0 if mode == 'average' else 1, _ptr(y) if y is not None else None, _ptr(P) if y is not None else None,
-            _ptr(ld) if y is not None else None, _ptr(mu), _ptr(covar), _ptr(nlpd) if y is not None else None))
-        return mu, covar, nlpd
+            _ptr(ld) if y is not None else None, _ptr(mu), _ptr(covar), _ptr(nlpd) if y is not None else None,
+            _lib.F_DIAG_VAR if diag else 0))
+        return mu, ((covar[0], covar[1]) if diag else covar), nlpd
 
     def predict_device(self, c, b, W, M, Q, Cc, mu_ptr, covar_ptr, affine=True, mode='average', y_ptr=None, P=None, ld=None,
                        nlpd_ptr=None):

@@ -478,14 +478,27 @@ class BayesianMixtureOfLinearGaussians:
         yy = (self.output_transform.transform(y) if self.scale else y) if y is not None else None
         Ms, Q, Cc, P, ld = self.models.predictive_blocks()
         eng = _engine.bind(self.engine, np.ascontiguousarray(xx, dtype=float))
-        mu, covar, nlpd = eng.predict(*self._predictive_gate(), Ms, Q, Cc, affine=self.affine, mode=prediction,
-                                      y=None if yy is None else np.ascontiguousarray(yy), P=P, ld=ld)
-        if self.scale:
-            mu = self.output_transform.inverse_transform(mu)
-            mat = np.diag(np.sqrt(self.output_transform.var_))
-            covar = np.einsum('kh,...hj,ji->...ki', mat, covar, mat.T)
-        if incremental:
-            mu += x[:, :self.output_dim]
-        var = np.diagonal(covar, axis1=1, axis2=2).copy()     # (the reference stacks N np.diag calls, ilr.py:417)
-        out = (mu, var if variance == 'diagonal' else covar, np.sqrt(var))
+        diag = variance == 'diagonal'          # variances and standard deviations come from the kernel: no (N, dy, dy) block over PCIe
+        mu, second, nlpd = eng.predict(*self._predictive_gate(), Ms, Q, Cc, affine=self.affine, mode=prediction,
+                                       y=None if yy is None else np.ascontiguousarray(yy), P=P, ld=ld,
+                                       variance='diagonal' if diag else 'full')
+        if diag:
+            var, std = second
+            if self.scale:                         # diag(S covar S') = var * sigma^2 for the diagonal output scaling S
+                mu = self.output_transform.inverse_transform(mu)
+                var = var * self.output_transform.var_
+                std = np.sqrt(var)
+            if incremental:
+                mu += x[:, :self.output_dim]
+            out = (mu, var, std)
+        else:
+            covar = second
+            if self.scale:
+                mu = self.output_transform.inverse_transform(mu)
+                mat = np.diag(np.sqrt(self.output_transform.var_))
+                covar = np.einsum('kh,...hj,ji->...ki', mat, covar, mat.T)
+            if incremental:
+                mu += x[:, :self.output_dim]
+            var = np.diagonal(covar, axis1=1, axis2=2).copy()     # (the reference stacks N np.diag calls, ilr.py:417)
+            out = (mu, covar, np.sqrt(var))
         return out + (nlpd,) if y is not None else out

@@ -122,9 +122,13 @@ class OracleEngine:
         with np.errstate(invalid='ignore', divide='ignore'):
             return float(-np.nansum(t * np.log(t)))
 
-    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None):
+    def predict(self, c, b, W, M, Q, Cc, affine=True, mode='average', y=None, P=None, ld=None, variance='full'):
         f = lambda a: None if a is None else np.asarray(a, float)
-        return O.predict_canonical(self.Z, f(c), f(b), f(W), f(M), f(Q), f(Cc), affine, mode, f(y), f(P), f(ld))
+        mu, covar, nlpd = O.predict_canonical(self.Z, f(c), f(b), f(W), f(M), f(Q), f(Cc), affine, mode, f(y), f(P), f(ld))
+        if variance == 'diagonal':
+            var = np.diagonal(covar, axis1=1, axis2=2).copy()
+            return mu, (var, np.sqrt(var)), nlpd
+        return mu, covar, nlpd
 
     def get_resp(self, K=None):
         return self._resp

@@ -71,7 +71,7 @@ def test_tied_ilr_flow_and_prediction(name, engine):
 
 @pytest.mark.parametrize("N,dx,dy,K,affine", [(1000, 1, 1, 8, True), (777, 3, 2, 6, True), (4099, 8, 4, 64, True),
                                               (513, 16, 8, 50, False), (300, 32, 3, 5, True), (1, 2, 2, 3, True),
-                                              (40001, 8, 4, 64, True)])
+                                              (40001, 8, 4, 64, True), (2_000_003, 1, 1, 50, True), (9001, 5, 8, 7, True), (777, 8, 1, 3, False)])
 def test_predict_kernel_vs_oracle(engine, N, dx, dy, K, affine):
     """mimo_predict against its canonical-level restatement: mixture / arg-max moments and nlpd."""
     from oracle import mimo_oracle as O
@@ -90,6 +90,8 @@ def test_predict_kernel_vs_oracle(engine, N, dx, dy, K, affine):
         assert rel_err(mu, rmu) < 1e-11 and rel_err(covar, rcov) < 1e-10 and rel_err(nlpd, rnl) < 1e-11, mode
         mu2, covar2, none = engine.predict(c, b, W, M, Q, Cc, affine=affine, mode=mode)
         assert none is None and np.array_equal(mu2, mu) and np.array_equal(covar2, covar)
+        mu3, (var3, sd3), _ = engine.predict(c, b, W, M, Q, Cc, affine=affine, mode=mode, variance='diagonal')     # MIMO_F_DIAG_VAR
+        assert np.array_equal(mu3, mu) and np.array_equal(var3, np.diagonal(covar, axis1=1, axis2=2)) and np.array_equal(sd3, np.sqrt(var3))
 
 
 def test_predict_with_device_resident_outputs(engine):
