@@ -1064,6 +1064,15 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_kernel(const KernelArgs a)
 // 87 us, Dz = 8, K = 256, N = 2e6); and 512-thread workgroups over 1024-row tiles with 256 helper slots: indifferent to the
 // skew (309 us either way) but one workgroup per CU, whose five serial phases nothing overlaps (239 us before, uniform labels).
 // ------------------------------------------------------------------------------------------
+#ifndef MIMO_LS_PREFETCH2
+#define MIMO_LS_PREFETCH2 0          // 1: two tiles in flight ahead of the one in LDS — measured: no change (D=8 K=256 N=1e7 246.5 -> 244.7 us; D=9 spills: 271 -> 310 us)
+#endif
+#ifndef MIMO_LS_ROW_PIPELINE
+#define MIMO_LS_ROW_PIPELINE 0       // 1: next row's index and values fetched under this row's products — measured: slower (246.5 -> 267.1 us)
+#endif
+#ifndef MIMO_LS_PAIRS
+#define MIMO_LS_PAIRS 1              // even Dz: rows travel HBM -> registers -> LDS 16 bytes at a time (half the load / store instructions of the staging phase)
+#endif
 constexpr int kLsSlots = kWG;                  // aux layout (uint32): hist[256] | nparts[256] | first slot[256] | slot table[256]
 constexpr int kLsAuxWords = 256 * 4;
 
@@ -1116,6 +1125,8 @@ __global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kern
   constexpr int BS = NW + 4, PS = NW + 8;                  // padded row strides of the bitmap (words: 80 bytes) and of its prefix table (u16: 48 bytes)
   constexpr int RPT = T / kWG;                             // 2 rows per thread and tile
   constexpr int ZPT = (T * DZ + kWG - 1) / kWG;
+  constexpr int PFD = MIMO_LS_PREFETCH2 ? 2 : 1;            // tiles in flight ahead of the one in LDS
+  constexpr bool PAIRS = MIMO_LS_PAIRS && DZ % 2 == 0 && ZS % 2 == 0 && ZPT % 2 == 0;
   __shared__ __align__(16) double Zt[T * ZS > kWG * 8 ? T * ZS : kWG * 8];           // (the epilogue's red[256][8] aliases it)
   __shared__ __align__(16) uint32_t bitmap[kWG * BS];
   __shared__ __align__(16) uint16_t wpre[kWG * PS];                                  // set bits below word w of component k
@@ -1138,32 +1149,56 @@ __global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kern
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0;
 
-  double zr[ZPT];
-  int lab[RPT];
-  auto load_tile = [&](int64_t t) {
+  // TWO tiles in flight ahead of the one in LDS (round 4; one before: the stamps showed 38 % of a wave's time in the phase that waits
+  // for the prefetched rows — 16 KB per workgroup, 32 KB per CU in flight do not cover the HBM latency at 8 TB/s / 256 CUs)
+  double zr[ZPT], zr2[ZPT];
+  int lab[RPT], lab2[RPT];
+  auto load_tile = [&](int64_t t, double (&zd)[ZPT], int (&ld)[RPT]) {
     const int64_t base = t * T * DZ, total = N * DZ;
+    if constexpr (PAIRS) {             // element pair e = 2 (tid + 256 i): both in one row (Dz even), 16-byte aligned in HBM and in LDS
+      typedef double d2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < ZPT; ++i) {
-      const int64_t g = base + tid + (int64_t)kWG * i;
-      zr[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+      for (int i = 0; i < ZPT / 2; ++i) {
+        const int e = 2 * (tid + kWG * i);
+        const int64_t g = base + e;
+        d2 v = d2{0.0, 0.0};
+        if (e < T * DZ && g < total) v = *reinterpret_cast<const d2*>(a.Z + g);      // (g even, total even: the pair is inside the data)
+        zd[2 * i] = v.x; zd[2 * i + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ZPT; ++i) {
+        const int64_t g = base + tid + (int64_t)kWG * i;
+        zd[i] = (tid + kWG * i < T * DZ && g < total) ? a.Z[g] : 0.0;
+      }
     }
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
       const int64_t n = t * T + tid + kWG * h;
       const int l = n < N ? a.labels[n] : -1;
-      lab[h] = l < K ? l : -1;            // a label outside [0, K) (a caller's vector) is skipped, never an index
+      ld[h] = l < K ? l : -1;            // a label outside [0, K) (a caller's vector) is skipped, never an index
     }
   };
-  if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+  if (blockIdx.x < ntiles) load_tile(blockIdx.x, zr, lab);
+  if (PFD == 2 && (int64_t)blockIdx.x + gridDim.x < ntiles) load_tile((int64_t)blockIdx.x + gridDim.x, zr2, lab2);
   LS_STAMP_INIT
 
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  auto process = [&](int64_t t, double (&zb)[ZPT], int (&lb)[RPT]) {      // tile t from the register set (zb, lb), which is then refilled two tiles ahead
     wg_sync();                        // the previous tile's readers are done
     LS_STAMP(0)
+    if constexpr (PAIRS) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < ZPT; ++i) {
-      const int e = tid + kWG * i;
-      if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zr[i]; }
+      for (int i = 0; i < ZPT / 2; ++i) {
+        const int e = 2 * (tid + kWG * i);
+        if (e < T * DZ) { const int r = e / DZ; *reinterpret_cast<d2*>(Zt + r * ZS + (e - r * DZ)) = d2{zb[2 * i], zb[2 * i + 1]}; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ZPT; ++i) {
+        const int e = tid + kWG * i;
+        if (e < T * DZ) { const int r = e / DZ; Zt[r * ZS + (e - r * DZ)] = zb[i]; }
+      }
     }
     {
       uint4* bm = reinterpret_cast<uint4*>(bitmap + tid * BS);
@@ -1172,9 +1207,9 @@ __global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kern
     }
     int l01[RPT];
 #pragma unroll
-    for (int h = 0; h < RPT; ++h) l01[h] = lab[h];
+    for (int h = 0; h < RPT; ++h) l01[h] = lb[h];
 #ifndef MIMO_LS_WHATIF_NOLOAD          // (diagnostic what-if: every tile re-uses the first tile's rows — no HBM traffic)
-    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
+    if (t + PFD * (int64_t)gridDim.x < ntiles) load_tile(t + PFD * (int64_t)gridDim.x, zb, lb);
 #endif
     LS_STAMP(1)
     wg_sync();
@@ -1233,12 +1268,35 @@ __global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kern
     // slot (component myk, part mypart of nparts): every nparts-th row of the component's list, ascending
     if (live) {
       const int st = start[myk], cmine = cnts[myk];
+#if MIMO_LS_ROW_PIPELINE
+      // the next row's index and values travel LDS -> registers under this row's products (list entry -> row is a dependent pair of
+      // LDS round trips: exposed, it costs more than the F products of a row)
+      int p = mypart;
+      double zn[DZ];
+      int rown = p + nparts < cmine ? (int)list[st + p + nparts] : 0;
+      if (p < cmine) {
+        const double* zp0 = Zt + (int)list[st + p] * ZS;
+#pragma unroll
+        for (int d = 0; d < DZ; ++d) zn[d] = zp0[d];
+      }
+      for (; p < cmine; p += nparts) {
+        double z[DZ];
+#pragma unroll
+        for (int d = 0; d < DZ; ++d) z[d] = zn[d];
+        if (p + nparts < cmine) {
+          const double* zp1 = Zt + rown * ZS;
+#pragma unroll
+          for (int d = 0; d < DZ; ++d) zn[d] = zp1[d];
+          rown = p + 2 * nparts < cmine ? (int)list[st + p + 2 * nparts] : 0;
+        }
+#else
       for (int p = mypart; p < cmine; p += nparts) {
         const int row = list[st + p];
         const double* zp = Zt + row * ZS;
         double z[DZ];
 #pragma unroll
         for (int d = 0; d < DZ; ++d) z[d] = zp[d];
+#endif
         if constexpr (FS == 0) {
           int f = 0;
 #pragma unroll
@@ -1258,6 +1316,14 @@ __global__ __launch_bounds__(kWG, (DZ <= 2 ? 3 : 2)) void label_stats_slots_kern
       }
     }
     LS_STAMP(6)
+  };
+  if constexpr (PFD == 2) {
+    for (int64_t t = blockIdx.x; t < ntiles; t += 2 * (int64_t)gridDim.x) {     // two register sets in turn: no copies, every load two tiles ahead of its use
+      process(t, zr, lab);
+      if (t + gridDim.x < ntiles) process(t + gridDim.x, zr2, lab2);
+    }
+  } else {
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) process(t, zr, lab);
   }
   LS_STAMP_STORE
 
@@ -1968,6 +2034,240 @@ __global__ __launch_bounds__(kWG, 2) void label_stats_sorted_kernel(const Kernel
     }
   }
 }
+// ------------------------------------------------------------------------------------------
+// The same pass with the accumulation on the matrix cores (round 4).  label_stats_sorted_kernel gives every thread up to three
+// features and reads two factors per product from LDS: 2 F 8 bytes of LDS traffic per row (9 KB at Dz = 32) — the LDS pipe
+// bounds it at 1.3 - 1.6 TB/s of Z.  But the statistics of ONE component's rows are a Gram matrix, z~' z~ over those rows
+// (z~ = [z, 1]: second moments, sums and the count are its entries), and the rows arrive sorted by component: per group of
+// four rows one v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the upper triangle (1 tile up to Dz = 15, 3 up to Dz = 31, 6 at
+// Dz = 32), operands straight from the gathered rows in LDS — 1 - 2 reads of 512 bytes per matrix instruction, 1.5 KB per
+// row at Dz = 32.  Each wave owns tiles of the triangle (no cross-wave sum); a component's accumulators go to the partial
+// block when its last row is done (first range writes, later ranges add), rows of a group that belong to the next component
+// are masked to zero.  Ranges, id lists and the gather are those of the kernel above; run-to-run bit-identical.
+// ------------------------------------------------------------------------------------------
+#ifndef MIMO_GRAM_WHATIF
+#define MIMO_GRAM_WHATIF 0           // diagnostic builds: 1 no batches (bookkeeping only), 2 no flushes to the partial block (results are wrong)
+#endif
+#ifndef MIMO_GRAM_BATCH
+#define MIMO_GRAM_BATCH 0            // 0: 64 rows per step (128 measured 4 - 6 % faster at two workgroups per CU, but costs the third and fourth)
+#endif
+// ranges of at most 40 tiles (20 KB of ids) and 64-row batches: 37 - 45 KB of LDS, four (three at Dz = 32) workgroups per CU — the
+// pass has three phases of comparable length that one workgroup runs one after the other (range bookkeeping, gather + staging,
+// products: what-if builds, profiles/r04_label_stats_gram.txt), so it takes co-resident workgroups to overlap them
+// (measured, N = 1e7, two -> four workgroups per CU: Dz=20 K=64 981 -> 779 us, Dz=24 K=200 1149 -> 975, Dz=28 K=16 1052 -> 812, Dz=31 K=128
+//  1190 -> 1068 with three; Dz = 32 — six tiles, 45 KB, 1.2 MB of partial block per workgroup at K = 256 — loses with three
+//  (K=128 1672 -> 1900, K=256 1858 -> 2400) and keeps two workgroups over ranges of 80 tiles)
+constexpr int gram_range(int DZ) { return DZ <= 31 ? 40 : 80; }
+constexpr int gram_wgs_per_cu(int DZ) { return DZ <= 31 ? 4 : 2; }      // (registers: 85 .. 133; four per CU cap them at 128: Dz=31 1437 us with three, 1068 with four)
+template <int DZ>
+__global__ __launch_bounds__(kWG, gram_wgs_per_cu(DZ)) void label_stats_gram_kernel(const KernelArgs a, int R) {
+  constexpr int F = (DZ + 1) * (DZ + 2) / 2;
+  constexpr int TT = (DZ + 1 + 15) / 16;                               // 16-wide tiles per side of the Gram matrix of z~
+  constexpr int NTL = TT * (TT + 1) / 2;                               // tiles of the upper triangle: 1, 3 or 6
+  constexpr int TPW = (NTL + 3) / 4;                                   // tiles per wave: 1, 1 or 2
+  constexpr int T = kLsWideTile, B = MIMO_GRAM_BATCH > 0 ? MIMO_GRAM_BATCH : 64;    // rows gathered per step
+  constexpr int ZS = 16 * TT + 1;                                      // rows [z, 1, 0 ..] padded to whole tiles; odd stride
+  constexpr int GPT = (B * DZ + kWG - 1) / kWG;                        // gathered elements per thread and batch
+  __shared__ __align__(16) double zbuf[B * ZS];
+  __shared__ uint16_t ids[gram_range(DZ) * T];
+  __shared__ int kbase[kWG + 1];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int K = a.K;
+  const int64_t N = a.N;
+  const int64_t ntiles = (N + T - 1) / T, nranges = (ntiles + R - 1) / R;
+  const int FT = a.F16_total;
+  const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
+  double* P = a.partials + (size_t)blockIdx.x * pstride;
+
+  // this wave's tiles (ti <= tj) of the triangle, in row-major order of the triangle: tile index wave + 4 i
+  int ti[TPW], tj[TPW];
+  bool has[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave + 4 * i;
+    has[i] = t < NTL;
+    int r = 0, t0 = 0;
+    while (r + 1 < TT && t0 + (TT - r) <= t) { t0 += TT - r; ++r; }
+    ti[i] = r; tj[i] = has[i] ? r + (t - t0) : r;
+  }
+  for (int e = tid; e < a.K16 * 16 * FT; e += kWG) {                  // rows / columns of the block no accumulator reaches
+    const int k = e / FT, f = e - k * FT;
+    if (k >= K || f >= F) P[e] = 0.0;
+  }
+  if (tid == 0 && a.write_scalars) { double* Ps = P + (size_t)a.K16 * 16 * FT; Ps[0] = 0.0; Ps[1] = 0.0; Ps[2] = 0.0; Ps[3] = 0.0; }
+  for (int e = tid; e < B * ZS; e += kWG) zbuf[e] = 0.0;              // the padding columns stay zero: written once
+
+  d4 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  // component k is complete: this wave's tiles -> the partial block.  Register r of lane (q, j) of tile (ti, tj) is the entry
+  // (a, b) = (16 ti + 4 r + q, 16 tj + j) of z~' z~: feature (a, b) for a <= b <= Dz
+  auto flush = [&](int k, bool first) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      if (has[i]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ra = 16 * ti[i] + 4 * r + q, cb = 16 * tj[i] + j;
+          if (ra <= cb && cb <= DZ) {
+            double* dst = P + (size_t)k * FT + (ra * (DZ + 1) - ra * (ra - 1) / 2 + (cb - ra));
+            *dst = first ? acc[i][r] : *dst + acc[i][r];
+          }
+        }
+      }
+      acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+  };
+
+  bool first = true;
+  for (int64_t rg = blockIdx.x; rg < nranges; rg += gridDim.x) {
+    const int64_t t0 = rg * R;
+    const int nt = (int)(ntiles - t0 < R ? ntiles - t0 : R);
+    // ---- the rows of the range by component (thread k = component k): counts, prefix over the components, ids
+    wg_sync();
+    int cntk = 0;
+    if (tid < K) {
+#pragma unroll 8
+      for (int t = 0; t < nt; ++t) {
+        const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
+        cntk += (int)sg[1] - (int)sg[0];
+      }
+    }
+    int incl = cntk;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int v = __shfl_up(incl, sft);
+      if (lane >= sft) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    wg_sync();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off += w < wave ? wsum[w] : 0;
+    int o = off + incl - cntk;
+    kbase[tid] = o;
+    if (tid == kWG - 1) kbase[kWG] = off + incl;
+    if (tid < K)
+      for (int tb = 0; tb < nt; tb += 4) {
+        int s0[4], c[4];
+        uint16_t l0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i < nt ? tb + i : nt - 1;
+          const uint16_t* sg = a.sort_start + (size_t)(t0 + t) * 257 + tid;
+          s0[i] = sg[0]; c[i] = tb + i < nt ? (int)sg[1] - s0[i] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i < nt ? tb + i : nt - 1;
+          l0[i] = c[i] > 0 ? a.sort_list[(size_t)(t0 + t) * T + s0[i]] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = tb + i;
+          if (c[i] > 0) {
+            ids[o++] = (uint16_t)((t << 8) | l0[i]);
+            const uint16_t* lg = a.sort_list + (size_t)(t0 + t) * T + s0[i];
+            for (int m = 1; m < c[i]; ++m) ids[o++] = (uint16_t)((t << 8) | lg[m]);
+          }
+        }
+      }
+    wg_sync();
+    if (first) {                                         // components without a row in the workgroup's first range: zero rows
+      for (int e = tid; e < K * F; e += kWG) {
+        const int k = e / F, f = e - k * F;
+        if (kbase[k + 1] == kbase[k]) P[(size_t)k * FT + f] = 0.0;
+      }
+    }
+#if MIMO_GRAM_WHATIF == 1
+    const int nrows = 0;                                 // (diagnostic: ranges, counts and id lists only)
+#else
+    const int nrows = kbase[kWG];
+#endif
+    double gz[2][GPT];                                   // two batches in flight ahead of the one in LDS
+    auto fetch = [&](int pos, double (&g)[GPT]) {
+      const int nb = nrows - pos < B ? nrows - pos : B;
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int e = tid + kWG * i, r = e / DZ, col = e - r * DZ;
+        double v = 0.0;
+        if (e < B * DZ && r < nb) {
+          const int id = ids[pos + r];
+          const int64_t n = (t0 + (id >> 8)) * T + (id & 255);
+          v = a.Z[n * DZ + col];
+        }
+        g[i] = v;
+      }
+    };
+    if (nrows > 0) fetch(0, gz[0]);
+    if (nrows > B) fetch(B, gz[1]);
+    int k = 0;
+    auto step = [&](int pos, double (&g)[GPT]) {
+      const int nb = nrows - pos < B ? nrows - pos : B;
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int e = tid + kWG * i, r = e / DZ, col = e - r * DZ;
+        if (e < B * DZ) zbuf[r * ZS + col] = g[i];
+      }
+      for (int e = tid; e < B; e += kWG) zbuf[e * ZS + DZ] = 1.0;
+      wg_sync();
+      if (pos + 2 * B < nrows) fetch(pos + 2 * B, g);
+      int r = 0;
+      while (r < nb) {                                   // (uniform control flow: kbase is the same for every thread)
+        while (kbase[k + 1] <= pos + r) ++k;
+        const int kend = kbase[k + 1] - pos;
+        const int rend = kend < nb ? kend : nb;
+        // groups of four rows of component k; the lanes whose row lies past the segment read zeros
+        // (U groups per iteration, all their operand reads in flight before the first product: one group at a time is an LDS round
+        //  trip + a dependent matrix instruction per four rows — ~200 cycles whatever Dz is, measured as a pass whose time did not
+        //  depend on Dz: 0.97 - 1.2 ms per 1e7 rows from Dz = 17 to 31)
+        constexpr int U = 4;
+        for (; r < rend; r += 4 * U) {
+          double av[U][TPW], bv[U][TPW];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int rr = r + 4 * u + q;
+            const bool inside = rr < rend;
+            const double* zr = zbuf + (inside ? rr : 0) * ZS + j;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+              av[u][i] = inside ? zr[16 * ti[i]] : 0.0;
+              bv[u][i] = inside ? zr[16 * tj[i]] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+              if (has[i]) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][i], bv[u][i], acc[i], 0, 0, 0);
+        }
+        r = rend;
+#if MIMO_GRAM_WHATIF != 2
+        if (kend <= nb) flush(k, first);                 // component k is complete
+#endif
+      }
+      wg_sync();
+    };
+    for (int pos = 0; pos < nrows; pos += 2 * B) {
+      step(pos, gz[0]);
+      if (pos + B < nrows) step(pos + B, gz[1]);
+    }
+    first = false;
+  }
+  if (first) {                                           // a workgroup without a range: an all-zero block
+    for (int e = tid; e < K * FT; e += kWG) {
+      const int k = e / FT, f = e - k * FT;
+      if (f < F) P[(size_t)k * FT + f] = 0.0;
+    }
+  }
+}
+
+static bool label_gram_on() {
+  static const bool on = [] { const char* e = getenv("MIMO_LABEL_STATS_GRAM"); return !e || atoi(e) != 0; }();     // tuning knob: 0 = the VALU kernel
+  return on;
+}
 static int g_sorted_range_cap = kSortedRange;
 void set_sorted_range_cap(int tiles) { g_sorted_range_cap = tiles < 1 || tiles > kSortedRange ? kSortedRange : tiles; }
 static bool label_sorted_on() {
@@ -1991,7 +2291,9 @@ static hipError_t launch_sorted(const KernelArgs& a, int grid, hipStream_t strea
   const int64_t ntiles = (a.N + kLsWideTile - 1) / kLsWideTile;
   int R = (int)((ntiles + grid - 1) / (grid > 0 ? grid : 1));            // one range per workgroup where the cap allows (no second round for a few)
   R = R < 1 ? 1 : R > g_sorted_range_cap ? g_sorted_range_cap : R;      // (mimo_tune "sorted_range" lowers the cap: several ranges per workgroup at test sizes)
-  hipLaunchKernelGGL(label_stats_sorted_kernel<DZ>, dim3(grid), dim3(kWG), 0, stream, a, R);
+  const bool gram = label_gram_on();
+  if (gram) hipLaunchKernelGGL(label_stats_gram_kernel<DZ>, dim3(grid), dim3(kWG), 0, stream, a, R > gram_range(DZ) ? gram_range(DZ) : R);
+  else hipLaunchKernelGGL(label_stats_sorted_kernel<DZ>, dim3(grid), dim3(kWG), 0, stream, a, R);
   return hipGetLastError();
 }
 
@@ -2046,6 +2348,7 @@ int label_stats_grid(const KernelArgs& a, int num_cu) {
   const int tile = a.D <= (a.diag ? 10 : 9) ? kLsTile : kLsWideTile;
   const int64_t tiles = (a.N + tile - 1) / tile;
   int64_t g = (int64_t)num_cu * (label_stats_uses_slots(a.K, a.D, a.N) && a.D <= 2 ? 3 : 2);     // (52 KB of LDS, <= 88 registers: three per CU)
+  if (!a.diag && a.D >= 10 && label_stats_sorted_covers(a.K, a.D) && label_gram_on()) g = (int64_t)num_cu * gram_wgs_per_cu(a.D);
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
 }
