@@ -399,24 +399,45 @@ class HipEngine(BoundDataGuard):
         self._K = K
         return (self._nan_softmax_share(SuffStats.from_packed(S, K, self.D), c) if stats else None), sc
 
-    def estep_async(self, c, b, W):
+    def estep_async(self, c, b, W, row_weights=None):
         """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
-        The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs."""
+        The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs.  `row_weights` as in estep()
+        (two-stage shapes, which take their weights as a table, run synchronously here and hand the result to estep_wait)."""
         c, b, W, K = self._params(c, b, W)
-        self._async_args = (c, b, W) if self._verify is not None else None
+        self._async_args = (c, b, W, row_weights) if self._verify is not None else None
         self._async_W0 = None
+        self._async_done = None
         if self._linear():
             if not np.array_equal(W, np.broadcast_to(W[:1], W.shape)):
                 self.set_structure('full')      # not a tied block after all: stays full until the caller re-binds
             else:
-                self._xx_total()                # (a first call runs its own pass: before the asynchronous one)
+                (self._xx_total() if row_weights is None else self._xx(row_weights))     # (a first call runs its own pass: before the asynchronous one)
                 self._async_W0 = W[0].copy()
-        self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
+        self._async_wts = row_weights
+        if row_weights is not None:
+            w, base = _weights_key(row_weights)
+            if w.shape[0] != self.N:
+                raise ValueError(f"row_weights has {w.shape[0]} entries, data has {self.N} rows")
+            wkey = base + (id(self._keepalive), self.N)
+            resident = getattr(self, '_w_key', None) == wkey
+            rc = self._lib.mimo_estep_weighted(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _ptr(w),
+                                               _lib.F_ASYNC | (_lib.F_WEIGHTS_RESIDENT if resident else 0), None, None)
+            self._w_key = wkey if rc == 0 else None
+            if rc == _lib.E_UNSUPPORTED:
+                W0, self._async_W0 = self._async_W0, None
+                self._async_done = self.estep(c, b, W, row_weights=row_weights)
+                return
+            self._check(rc)
+        else:
+            self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
         self._K = K
         self._async_K = K
         self._async_c = np.array(c) if getattr(self, 'n_bad', 0) else None
 
     def estep_wait(self):
+        if getattr(self, '_async_done', None) is not None:
+            out, self._async_done = self._async_done, None
+            return out
         out = self._estep_wait()
         if self._verify is not None and getattr(self, '_async_args', None) is not None and not self._settle():
             self.estep_async(*self._async_args)          # stale rows: the pass again on the fresh upload
@@ -427,7 +448,8 @@ class HipEngine(BoundDataGuard):
         if getattr(self, '_async_c', None) is not None:
             self._nan_softmax_share(S, self._async_c)
         if getattr(self, '_async_W0', None) is not None:
-            return self._linear_stats(S, self._xx_total()), self._linear_scalars(sc, self._async_W0)
+            wts = getattr(self, '_async_wts', None)
+            return self._linear_stats(S, self._xx_total() if wts is None else self._xx(wts)), self._linear_scalars(sc, self._async_W0)
         return S, sc
 
     def _estep_wait(self):

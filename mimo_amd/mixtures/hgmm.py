@@ -114,8 +114,16 @@ class BayesianMixtureOfGaussiansWithHierarchicalPrior:
                   disable=not progress_bar) as pbar:
             for _ in range(maxiter):
                 self._update_from_stats(S, maxsubiter)
-                S, sc = eng.estep(*self.canonical_expected(), row_weights=weights)
-                vlb.append(self._vlb_prior_terms() + sc[0])
+                if hasattr(eng, "estep_async") and not hasattr(eng, "inner"):
+                    # the pass is launched first; the bound's prior terms (K log-partition functions, the hyper-posterior's
+                    # cross-entropies: 0.45 ms at K = 64, D = 16) are computed while it runs
+                    eng.estep_async(*self.canonical_expected(), row_weights=weights)
+                    prior_terms = self._vlb_prior_terms()
+                    S, sc = eng.estep_wait()
+                else:
+                    S, sc = eng.estep(*self.canonical_expected(), row_weights=weights)
+                    prior_terms = self._vlb_prior_terms()
+                vlb.append(prior_terms + sc[0])
                 if len(vlb) > 1 and abs(vlb[-1] - vlb[-2]) < tol:
                     return vlb
                 pbar.update(1)

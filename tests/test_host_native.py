@@ -274,9 +274,10 @@ def test_batched_rvs_consumes_numpy_random_like_the_component_loop():
 
 
 @pytest.mark.parametrize("nbytes", [0, 5, 8, 8 * 1000 + 3, 8 * 3_000_001 + 7])
-def test_host_checksum_is_sum_and_xor_of_the_words(nbytes):
-    """mimo_host_checksum (what bind() and the row-weight residency key on): wrapping sum and xor of every 64-bit word, the tail
-    zero-extended; threaded above 8 MB with the same result; any single-byte edit changes it."""
+def test_host_checksum_is_the_position_weighted_sum_of_the_mixed_words(nbytes):
+    """mimo_host_checksum (what bind() and the row-weight residency key on; include/mimo_hip.h): with m_i = w_i ^ (w_i >> 32) over the
+    64-bit words (the tail zero-extended) and nw their number, (sum m_i, sum (nw - i) m_i) mod 2^64 — threaded above 8 MB with the same
+    result; any single-byte edit changes it, and so does a swap of two unequal words."""
     import ctypes as C
     lib = _lib.load()
     rng = np.random.default_rng(nbytes)
@@ -284,13 +285,24 @@ def test_host_checksum_is_sum_and_xor_of_the_words(nbytes):
     out = (C.c_uint64 * 2)()
     assert lib.mimo_host_checksum(buf.ctypes.data_as(C.c_void_p), nbytes, out) == 0
     padded = np.zeros((nbytes + 7) // 8 * 8, dtype=np.uint8); padded[:nbytes] = buf
-    words = padded.view(np.uint64)
-    assert int(out[0]) == int(np.add.reduce(words, dtype=np.uint64)) and int(out[1]) == int(np.bitwise_xor.reduce(words)) if nbytes else (out[0], out[1]) == (0, 0)
+    words = [int(w) for w in padded.view(np.uint64)] if nbytes <= 10_000 else None
+    if words is not None:                                   # exact integers, no NumPy wrap-around semantics
+        mask = (1 << 64) - 1
+        m = [w ^ (w >> 32) for w in words]
+        assert int(out[0]) == sum(m) & mask and int(out[1]) == sum((len(m) - i) * v for i, v in enumerate(m)) & mask
+    else:
+        from mimo_amd.engine import _word_checksum_numpy
+        assert (int(out[0]), int(out[1])) == _word_checksum_numpy(buf)
     if nbytes:
         first = (int(out[0]), int(out[1]))
         buf[nbytes // 2] ^= 1
         assert lib.mimo_host_checksum(buf.ctypes.data_as(C.c_void_p), nbytes, out) == 0
         assert (int(out[0]), int(out[1])) != first
+        buf[nbytes // 2] ^= 1
+    if nbytes >= 16 and not np.array_equal(buf[:8], buf[8:16]):
+        buf[:8], buf[8:16] = buf[8:16].copy(), buf[:8].copy()
+        assert lib.mimo_host_checksum(buf.ctypes.data_as(C.c_void_p), nbytes, out) == 0
+        assert int(out[0]) == first[0] and int(out[1]) != first[1]                 # same words, another order
     assert lib.mimo_host_checksum(None, 8, out) == _lib.E_INVALID
 
 
