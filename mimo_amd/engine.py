@@ -399,12 +399,13 @@ class HipEngine(BoundDataGuard):
         self._K = K
         return (self._nan_softmax_share(SuffStats.from_packed(S, K, self.D), c) if stats else None), sc
 
-    def estep_async(self, c, b, W, row_weights=None):
+    def estep_async(self, c, b, W, row_weights=None, stats=True):
         """Enqueue the fused E-step and return immediately; estep_wait() returns (SuffStats, scalars).
         The host can do its own O(K D^3) work (ELBO prior terms) while the data pass runs.  `row_weights` as in estep()
         (two-stage shapes, which take their weights as a table, run synchronously here and hand the result to estep_wait)."""
         c, b, W, K = self._params(c, b, W)
-        self._async_args = (c, b, W, row_weights) if self._verify is not None else None
+        self._async_args = (c, b, W, row_weights, stats) if self._verify is not None else None
+        self._async_stats = bool(stats)
         self._async_W0 = None
         self._async_done = None
         if self._linear():
@@ -429,7 +430,8 @@ class HipEngine(BoundDataGuard):
                 return
             self._check(rc)
         else:
-            self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K, _lib.F_ASYNC, None, None))
+            self._check(self._lib.mimo_estep(self._ctx, _ptr(c), _ptr(b), _ptr(W), K,
+                                             _lib.F_ASYNC | (0 if stats else _lib.F_NO_STATS), None, None))
         self._K = K
         self._async_K = K
         self._async_c = np.array(c) if getattr(self, 'n_bad', 0) else None
@@ -454,8 +456,13 @@ class HipEngine(BoundDataGuard):
 
     def _estep_wait(self):
         K = self._async_K
-        S = np.empty((K, 1 + self.D + self.D * self.D))
         sc = np.empty(3)
+        if not getattr(self, '_async_stats', True):        # scalars only (the full-data bound of the SVI drivers)
+            self._check(self._lib.mimo_wait(self._ctx, None, _ptr(sc)))
+            if getattr(self, '_async_W0', None) is not None:
+                sc = self._linear_scalars(sc, self._async_W0)
+            return None, sc
+        S = np.empty((K, 1 + self.D + self.D * self.D))
         self._check(self._lib.mimo_wait(self._ctx, _ptr(S), _ptr(sc)))
         return self._finish_async(SuffStats.from_packed(S, K, self.D), sc)
 

@@ -419,6 +419,7 @@ class BayesianMixtureOfGaussians:
             self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
         vlb = []
+        pipelined, pending = hasattr(eng, "estep_async") and not hasattr(eng, "inner"), None
         # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
         # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
         scale = eng.global_rows(batch_size) / float(eng.global_rows(len(obs)))
@@ -438,9 +439,20 @@ class BayesianMixtureOfGaussians:
                     self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb, self.components),
                                                   sample=sample_likelihood)
                     self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
-                _, sc = eng.estep(*self.canonical_expected(), stats=False)
-                vlb.append(self._vlb_prior_terms() + sc[0])
+                # the full-data bound under the posterior of this iteration: launched now, collected after the NEXT iteration's
+                # minibatch step (a second context: the two do not touch each other's data), so the upload, the minibatch pass and
+                # the natural-gradient algebra hide under it; numpy.random / random are consumed in the same order as before
+                if pipelined:
+                    if pending is not None:
+                        vlb.append(pending + eng.estep_wait()[1][0])
+                    eng.estep_async(*self.canonical_expected(), stats=False)
+                    pending = self._vlb_prior_terms()
+                else:
+                    _, sc = eng.estep(*self.canonical_expected(), stats=False)
+                    vlb.append(self._vlb_prior_terms() + sc[0])
                 pbar.update(1)
+        if pending is not None:
+            vlb.append(pending + eng.estep_wait()[1][0])
         return vlb
 
     def meanfield_sgd_parameters(self, obs, resp, scale, step_size):

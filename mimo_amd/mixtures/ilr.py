@@ -376,6 +376,7 @@ class BayesianMixtureOfLinearGaussians:
             self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
         vlb = []
+        pipelined, pending = hasattr(eng, "estep_async") and not hasattr(eng, "inner"), None
         # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
         # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
         scale = eng.global_rows(batch_size) / float(eng.global_rows(len(xx)))
@@ -395,9 +396,18 @@ class BayesianMixtureOfLinearGaussians:
                     self.models.meanfield_sgd(None, None, None, scale, step_size, stats=mstats,
                                               sample=sample_likelihood)
                     self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
-                _, sc = eng.estep(*self.canonical_expected(), stats=False)
-                vlb.append(self._vlb_prior_terms() + sc[0])
+                # the full-data bound of this iteration runs under the next iteration's minibatch step (as in mixtures/gmm.py)
+                if pipelined:
+                    if pending is not None:
+                        vlb.append(pending + eng.estep_wait()[1][0])
+                    eng.estep_async(*self.canonical_expected(), stats=False)
+                    pending = self._vlb_prior_terms()
+                else:
+                    _, sc = eng.estep(*self.canonical_expected(), stats=False)
+                    vlb.append(self._vlb_prior_terms() + sc[0])
                 pbar.update(1)
+        if pending is not None:
+            vlb.append(pending + eng.estep_wait()[1][0])
         return vlb
 
     # ---- ELBO with explicit responsibilities (reference-shaped) -------------------------------------

@@ -926,6 +926,7 @@ def test_row_owner_softmax_pass(engine, D, K, N):
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
     narrow = (D, K) in ((2, 33), (1, 33)) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) or (D == 5 and K <= 64) or (D <= 4 and K >= (17 if D <= 2 else 9 if D == 3 else 12))   # (few components at Dz >= 5: the table-driven narrow kernels)
+    engine.tune("mid_min_d", 64)          # (K = 33 .. 48 at Dz = 9 goes to the mid kernels by default since round 4)
     assert engine.plan(K)["kind"] == ("narrow" if narrow else "rowwave-vi")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)
@@ -990,6 +991,7 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
     rng = np.random.default_rng(7000 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
+    engine.tune("mid_min_d", 64)          # (the mid kernels are preferred for some of these shapes since round 4: every narrow instantiation stays tested)
     assert engine.plan(K)["kind"] == "narrow" and (D > 16 or engine.plan(K, gibbs=True)["kind"] == "narrow")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)
