@@ -467,10 +467,11 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
   //   K <= 12: the narrow kernels where they exist (Dz=16 K=12 0.44 = 0.44, Dz=15 0.42 -> 0.38, Dz=20 K=8 0.37 -> 0.30) up to Dz = 23
   //            (Dz=24 K=8 0.31 -> 0.32, Dz=26 K=8 0.19 -> 0.34); beyond them the two-stage path was all there was (Dz=20 K=12 0.18 -> 0.47)
   //   K = 33 .. 48: from Dz = 9 (Dz=9 K=48 0.48 -> 0.55, Dz=12 0.56 -> 0.60, Dz=16 0.57 -> 0.67, Dz=20 0.46 -> 0.71, Dz=26 0.52 -> 0.80; Dz=10, 11: level)
-  //   K = 49 .. 64: from Dz = 18 (Dz=18 K=64 0.64 -> 0.68, Dz=20 0.61 -> 0.76, Dz=21 0.66 -> 0.79; below, ten column blocks do not divide over eight
-  //                 waves and the tile kernels keep K = 64: Dz=16 0.78 against 0.57)
+  //   K = 49 .. 64: from Dz = 18 (Dz=18 K=64 0.64 -> 0.68, Dz=20 0.61 -> 0.76, Dz=21 0.66 -> 0.79, one wave per SIMD from Dz = 22: Dz=24 0.57 -> 0.63,
+  //                 Dz=28 0.63 -> 0.68; below, ten column blocks do not divide over eight waves and the tile kernels keep K = 64: Dz=16 0.78 against 0.57)
   //   K = 65 .. 96: wherever the kernels exist from Dz = 6 (five / six row blocks instead of the eight the tile and two-stage kernels pay for:
-  //                 Dz=8 K=96 0.43 -> 0.56, Dz=9 K=72 0.35 -> 0.56, Dz=12 K=96 0.46 -> 0.62, Dz=14 K=80 0.35 -> 0.71, Dz=16 K=80 0.42 -> 0.60)
+  //                 Dz=8 K=96 0.43 -> 0.56, Dz=9 K=72 0.35 -> 0.56, Dz=12 K=96 0.46 -> 0.62, Dz=14 K=80 0.35 -> 0.71, Dz=16 K=80 0.42 -> 0.60; with one
+  //                 wave per SIMD: Dz=16 K=96 0.47 -> 0.61, Dz=20 K=96 0.48 -> 0.66, Dz=23 K=96 0.51 -> 0.66, Dz=26 K=80 0.49 -> 0.66, Dz=28 K=48 0.47 -> 0.66)
   if (K >= 65) return D >= 6;
   if (K >= 49) return D >= 18;
   if (K >= 33) return D >= 9;

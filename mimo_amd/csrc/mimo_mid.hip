@@ -34,14 +34,21 @@ constexpr int mid_regs(int D, int KB, int NW) { return 8 * KB * ((mid_ncb(D) + N
 // waves per workgroup: 4 (two workgroups per CU) while that fits 256 registers, else 8 (one workgroup per CU); up to ~50 bytes of
 // scratch outside the loops cost nothing measurable (Dz=26 K=48: 0.80 of the float64 rate with 52 bytes)
 constexpr int mid_nw(int D, int KB) { return mid_regs(D, KB, 4) <= 250 ? 4 : 8; }
-constexpr bool mid_exists(int D, int KB) { return KB >= 1 && KB <= 6 && D >= 5 && D <= 32 && mid_regs(D, KB, mid_nw(D, KB)) <= (KB <= 2 ? 275 : 264); }
+constexpr bool mid_fits(int D, int KB) { return mid_regs(D, KB, mid_nw(D, KB)) <= (KB <= 2 ? 275 : 264); }
+// ... and beyond that ONE wave per SIMD (a four-wave workgroup alone on its CU): the wave has the whole unified register file, 512
+// registers, the accumulators spill over into its second half; Theta slices 16 deep in flight (nothing else hides the L2 latency)
+constexpr bool mid_big(int D, int KB) { return !mid_fits(D, KB) && mid_regs(D, KB, 4) + 16 <= 470; }
+constexpr bool mid_exists(int D, int KB) { return KB >= 1 && KB <= 6 && D >= 5 && D <= 32 && (mid_fits(D, KB) || mid_big(D, KB)); }
+constexpr int mid_waves(int D, int KB) { return mid_big(D, KB) ? 4 : mid_nw(D, KB); }
 // the z and R tiles are double-buffered (one barrier per super-step) where two copies fit, else single (two barriers)
-constexpr size_t mid_tile_bytes(int D, int KB) { return sizeof(double) * (size_t)16 * mid_nw(D, KB) * (mid_zs(D) + 16 * KB + 1); }
-constexpr int mid_nbuf(int D, int KB) { return 2 * mid_tile_bytes(D, KB) * (mid_nw(D, KB) == 4 ? 2 : 1) + 2048 <= 160 * 1024 ? 2 : 1; }
+constexpr size_t mid_tile_bytes(int D, int KB) { return sizeof(double) * (size_t)16 * mid_waves(D, KB) * (mid_zs(D) + 16 * KB + 1); }
+constexpr int mid_wgs_per_cu(int D, int KB) { return mid_big(D, KB) ? 1 : mid_nw(D, KB) == 4 ? 2 : 1; }
+constexpr int mid_nbuf(int D, int KB) { return 2 * mid_tile_bytes(D, KB) * mid_wgs_per_cu(D, KB) + 2048 <= 160 * 1024 ? 2 : 1; }
 constexpr size_t mid_lds_bytes(int D, int KB) { return mid_nbuf(D, KB) * mid_tile_bytes(D, KB) + sizeof(double) * (64 + 8); }
 
 template <int DT, int KB, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mid_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(const KernelArgs a) {
+  constexpr int PF = mid_big(DT, KB) ? 16 : kMidPF;
   constexpr NarrowGroup<DT> GR{};
   constexpr int NSG = narrow_group_steps(DT);
   constexpr int NCB = mid_ncb(DT), NCBW = (NCB + NW - 1) / NW;
@@ -130,17 +137,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mid_kernel(const Ker
       // opaque scalar base per super-step: slice addresses = scalar base + lane offset + immediates, not 2 NSG KB hoisted registers
       gptr_t thg = (gptr_t)a.theta;
       asm volatile("" : "+s"(thg));
-      double ring[kMidPF];
+      double ring[PF];
 #pragma unroll
-      for (int e = 0; e < kMidPF; ++e) ring[e] = thg[e * 64 + lane];
+      for (int e = 0; e < PF; ++e) ring[e] = thg[e * 64 + lane];
 #pragma unroll
       for (int s = 0; s < NSG; ++s) {
         const double bcur = zrow[GR.a[s]] * zS[GR.b0[s]];
 #pragma unroll
         for (int rb = 0; rb < KB; ++rb) {
           const int e = s * KB + rb;
-          const double av = ring[e % kMidPF];
-          ring[e % kMidPF] = thg[(e + kMidPF) * 64 + lane];            // (the last reads take the zero slices behind the image)
+          const double av = ring[e % PF];
+          ring[e % PF] = thg[(e + PF) * 64 + lane];                    // (the last reads take the zero slices behind the image)
           acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bcur, acc[rb], 0, 0, 0);
         }
         // (the matrix instructions form one dependent chain per row block: without a fence hipcc hoists every row read and
@@ -254,12 +261,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mid_kernel(const Ker
 typedef void (*mid_fn)(const KernelArgs);
 template <int D>
 static mid_fn pick_mid_d(int kb) {
-  if constexpr (mid_exists(D, 1)) { if (kb == 1) return mid_kernel<D, 1, mid_nw(D, 1)>; }
-  if constexpr (mid_exists(D, 2)) { if (kb == 2) return mid_kernel<D, 2, mid_nw(D, 2)>; }
-  if constexpr (mid_exists(D, 3)) { if (kb == 3) return mid_kernel<D, 3, mid_nw(D, 3)>; }
-  if constexpr (mid_exists(D, 4)) { if (kb == 4) return mid_kernel<D, 4, mid_nw(D, 4)>; }
-  if constexpr (mid_exists(D, 5)) { if (kb == 5) return mid_kernel<D, 5, mid_nw(D, 5)>; }
-  if constexpr (mid_exists(D, 6)) { if (kb == 6) return mid_kernel<D, 6, mid_nw(D, 6)>; }
+  if constexpr (mid_exists(D, 1)) { if (kb == 1) return mid_kernel<D, 1, mid_waves(D, 1)>; }
+  if constexpr (mid_exists(D, 2)) { if (kb == 2) return mid_kernel<D, 2, mid_waves(D, 2)>; }
+  if constexpr (mid_exists(D, 3)) { if (kb == 3) return mid_kernel<D, 3, mid_waves(D, 3)>; }
+  if constexpr (mid_exists(D, 4)) { if (kb == 4) return mid_kernel<D, 4, mid_waves(D, 4)>; }
+  if constexpr (mid_exists(D, 5)) { if (kb == 5) return mid_kernel<D, 5, mid_waves(D, 5)>; }
+  if constexpr (mid_exists(D, 6)) { if (kb == 6) return mid_kernel<D, 6, mid_waves(D, 6)>; }
   return nullptr;
 }
 static mid_fn pick_mid(int D, int kb) {
@@ -280,13 +287,35 @@ bool mid_covers(int K, int D, int structure) {
   return on && structure == 0 && K >= 1 && K <= 96 && D >= 5 && D <= 32 && pick_mid(D, (K + 15) / 16) != nullptr;
 }
 int mid_steps(int D) { return narrow_group_steps(D); }
-int mid_pf() { return kMidPF; }
-int mid_rows_per_step(int K, int D) { return 16 * mid_nw(D, (K + 15) / 16); }
+int mid_pf() { return 16; }            // zero slices behind the image: the deepest ring
+static int mid_waves_rt(int D, int kb);
+int mid_rows_per_step(int K, int D) { return 16 * mid_waves_rt(D, (K + 15) / 16); }
+
+template <int D>
+static void mid_geom_d(int kb, int* waves, int* wgs, size_t* lds) {
+  switch (kb) {
+#define MIMO_MG(k) case k: *waves = mid_waves(D, k); *wgs = mid_wgs_per_cu(D, k); *lds = mid_lds_bytes(D, k); return;
+    MIMO_MG(1) MIMO_MG(2) MIMO_MG(3) MIMO_MG(4) MIMO_MG(5) MIMO_MG(6)
+#undef MIMO_MG
+  }
+  *waves = 4; *wgs = 1; *lds = 0;
+}
+static void mid_geom(int D, int kb, int* waves, int* wgs, size_t* lds) {
+  switch (D) {
+#define MIMO_MD(d) case d: mid_geom_d<d>(kb, waves, wgs, lds); return;
+    MIMO_MD(5) MIMO_MD(6) MIMO_MD(7) MIMO_MD(8) MIMO_MD(9) MIMO_MD(10) MIMO_MD(11) MIMO_MD(12) MIMO_MD(13) MIMO_MD(14) MIMO_MD(15) MIMO_MD(16)
+    MIMO_MD(17) MIMO_MD(18) MIMO_MD(19) MIMO_MD(20) MIMO_MD(21) MIMO_MD(22) MIMO_MD(23) MIMO_MD(24) MIMO_MD(25) MIMO_MD(26) MIMO_MD(27)
+    MIMO_MD(28) MIMO_MD(29) MIMO_MD(30) MIMO_MD(31) MIMO_MD(32)
+#undef MIMO_MD
+  }
+  *waves = 4; *wgs = 1; *lds = 0;
+}
+static int mid_waves_rt(int D, int kb) { int w, g; size_t l; mid_geom(D, kb, &w, &g, &l); return w; }
 
 int mid_grid(const KernelArgs& a, int num_cu) {
-  const int kb = (a.K + 15) / 16, nw = mid_nw(a.D, kb);
-  int per_cu = nw == 4 ? 2 : 1;
-  if (mid_lds_bytes(a.D, kb) * per_cu > 160 * 1024) per_cu = 1;
+  const int kb = (a.K + 15) / 16;
+  int nw, per_cu; size_t ldsb;
+  mid_geom(a.D, kb, &nw, &per_cu, &ldsb);
   const int64_t need = (a.N + 16 * nw - 1) / (16 * nw);
   int64_t g = (int64_t)num_cu * per_cu;
   if (g > need) g = need;
@@ -297,10 +326,11 @@ hipError_t launch_mid(const KernelArgs& a, int grid, hipStream_t stream) {
   const int kb = (a.K + 15) / 16;
   mid_fn fn = pick_mid(a.D, kb);
   if (!fn || a.K > 96 || a.K16 != kb) return hipErrorInvalidValue;
-  const size_t lds = mid_lds_bytes(a.D, kb);
+  int nw, per_cu; size_t lds;
+  mid_geom(a.D, kb, &nw, &per_cu, &lds);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * mid_nw(a.D, kb)), lds, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * nw), lds, stream, a);
   return hipGetLastError();
 }
 
