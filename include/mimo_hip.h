@@ -373,7 +373,7 @@ int mimo_profile_kernels(mimo_ctx* ctx, char* buf, int len);
 #define MIMO_PLAN_ROWWAVE    4   /* label pass: row-owner label kernel + label-indexed statistics kernel            */
 #define MIMO_PLAN_ROWWAVE_VI 5   /* softmax pass at K <= 64, Dz <= 9: row-owner kernel for both matrix products     */
 #define MIMO_PLAN_NARROW     6   /* Dz <= 4 with 32 < K <= 128: 4x4x4 matrix-instruction kernels (+ label statistics) */
-#define MIMO_PLAN_MID        7   /* softmax pass of the mid shapes (K <= 96; mimo_mid.hip): row-owner E-step + column-owner statistics waves */
+#define MIMO_PLAN_MID        7   /* softmax pass of the mid shapes (K <= 128; mimo_mid.hip): row-owner E-step + column-owner statistics waves */
 int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8);
 
 /* The same routing decision for a SHAPE — rows of Dz columns, N of them, K components, structure MIMO_STRUCT_*, softmax pass

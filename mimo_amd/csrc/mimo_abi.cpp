@@ -472,6 +472,11 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
   //   K = 65 .. 96: wherever the kernels exist from Dz = 6 (five / six row blocks instead of the eight the tile and two-stage kernels pay for:
   //                 Dz=8 K=96 0.43 -> 0.56, Dz=9 K=72 0.35 -> 0.56, Dz=12 K=96 0.46 -> 0.62, Dz=14 K=80 0.35 -> 0.71, Dz=16 K=80 0.42 -> 0.60; with one
   //                 wave per SIMD: Dz=16 K=96 0.47 -> 0.61, Dz=20 K=96 0.48 -> 0.66, Dz=23 K=96 0.51 -> 0.66, Dz=26 K=80 0.49 -> 0.66, Dz=28 K=48 0.47 -> 0.66)
+  //   K = 97 .. 128 (seven / eight row blocks, one wave per SIMD): K <= 112 from Dz = 8 (Dz=8 K=112 0.49 -> 0.58, Dz=12 0.53 -> 0.62, Dz=20 0.58 -> 0.65);
+  //                 K = 113 .. 128 at Dz = 10 .. 15 (Dz=10 0.43 -> 0.51, Dz=14 0.54 -> 0.64; Dz <= 8: the tile kernels, 0.56 against 0.40; Dz >= 16:
+  //                 the wide two-stage kernels are level or ahead, Dz=18 0.74 against 0.70)
+  if (K >= 113) return D >= 10 && D <= 15;
+  if (K >= 97) return D >= 8;
   if (K >= 65) return D >= 6;
   if (K >= 49) return D >= 18;
   if (K >= 33) return D >= 9;

@@ -38,7 +38,7 @@ constexpr bool mid_fits(int D, int KB) { return mid_regs(D, KB, mid_nw(D, KB)) <
 // ... and beyond that ONE wave per SIMD (a four-wave workgroup alone on its CU): the wave has the whole unified register file, 512
 // registers, the accumulators spill over into its second half; Theta slices 16 deep in flight (nothing else hides the L2 latency)
 constexpr bool mid_big(int D, int KB) { return !mid_fits(D, KB) && mid_regs(D, KB, 4) + 16 <= 470; }
-constexpr bool mid_exists(int D, int KB) { return KB >= 1 && KB <= 6 && D >= 5 && D <= 32 && (mid_fits(D, KB) || mid_big(D, KB)); }
+constexpr bool mid_exists(int D, int KB) { return KB >= 1 && KB <= 8 && D >= 5 && D <= 32 && (mid_fits(D, KB) || mid_big(D, KB)); }
 constexpr int mid_waves(int D, int KB) { return mid_big(D, KB) ? 4 : mid_nw(D, KB); }
 // the z and R tiles are double-buffered (one barrier per super-step) where two copies fit, else single (two barriers)
 constexpr size_t mid_tile_bytes(int D, int KB) { return sizeof(double) * (size_t)16 * mid_waves(D, KB) * (mid_zs(D) + 16 * KB + 1); }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(co
       }
     }
     if constexpr (NBUF == 1) wg_sync();                 // single tiles: the next super-step's rows overwrite what the slowest wave still reads
-    if (++since_flush == 32) {           // 96^32 < 2^211 stays inside the float64 range
+    if (++since_flush == 32) {           // 128^32 = 2^224 stays inside the float64 range
       sc_lse += log(sc_prod);
       sc_prod = 1.0;
       since_flush = 0;
@@ -267,6 +267,8 @@ static mid_fn pick_mid_d(int kb) {
   if constexpr (mid_exists(D, 4)) { if (kb == 4) return mid_kernel<D, 4, mid_waves(D, 4)>; }
   if constexpr (mid_exists(D, 5)) { if (kb == 5) return mid_kernel<D, 5, mid_waves(D, 5)>; }
   if constexpr (mid_exists(D, 6)) { if (kb == 6) return mid_kernel<D, 6, mid_waves(D, 6)>; }
+  if constexpr (mid_exists(D, 7)) { if (kb == 7) return mid_kernel<D, 7, mid_waves(D, 7)>; }
+  if constexpr (mid_exists(D, 8)) { if (kb == 8) return mid_kernel<D, 8, mid_waves(D, 8)>; }
   return nullptr;
 }
 static mid_fn pick_mid(int D, int kb) {
@@ -284,7 +286,7 @@ static mid_fn pick_mid(int D, int kb) {
 // mimo_abi.cpp decides where it is preferred over the narrow / tile / row-owner kernels)
 bool mid_covers(int K, int D, int structure) {
   static const bool on = [] { const char* e = getenv("MIMO_MID"); return !e || atoi(e) != 0; }();       // tuning knob
-  return on && structure == 0 && K >= 1 && K <= 96 && D >= 5 && D <= 32 && pick_mid(D, (K + 15) / 16) != nullptr;
+  return on && structure == 0 && K >= 1 && K <= 128 && D >= 5 && D <= 32 && pick_mid(D, (K + 15) / 16) != nullptr;
 }
 int mid_steps(int D) { return narrow_group_steps(D); }
 int mid_pf() { return 16; }            // zero slices behind the image: the deepest ring
@@ -295,7 +297,7 @@ template <int D>
 static void mid_geom_d(int kb, int* waves, int* wgs, size_t* lds) {
   switch (kb) {
 #define MIMO_MG(k) case k: *waves = mid_waves(D, k); *wgs = mid_wgs_per_cu(D, k); *lds = mid_lds_bytes(D, k); return;
-    MIMO_MG(1) MIMO_MG(2) MIMO_MG(3) MIMO_MG(4) MIMO_MG(5) MIMO_MG(6)
+    MIMO_MG(1) MIMO_MG(2) MIMO_MG(3) MIMO_MG(4) MIMO_MG(5) MIMO_MG(6) MIMO_MG(7) MIMO_MG(8)
 #undef MIMO_MG
   }
   *waves = 4; *wgs = 1; *lds = 0;
@@ -325,7 +327,7 @@ int mid_grid(const KernelArgs& a, int num_cu) {
 hipError_t launch_mid(const KernelArgs& a, int grid, hipStream_t stream) {
   const int kb = (a.K + 15) / 16;
   mid_fn fn = pick_mid(a.D, kb);
-  if (!fn || a.K > 96 || a.K16 != kb) return hipErrorInvalidValue;
+  if (!fn || a.K > 128 || a.K16 != kb) return hipErrorInvalidValue;
   int nw, per_cu; size_t lds;
   mid_geom(a.D, kb, &nw, &per_cu, &lds);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

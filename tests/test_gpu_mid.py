@@ -38,7 +38,8 @@ MID_SHAPES = [(D, K) for D in range(17, 33) for K in ((9, 32) if D % 2 else (16,
              [(27, 8), (32, 7), (30, 5), (24, 24), (32, 31), (20, 12), (28, 20),
               (13, 33), (16, 48), (19, 48), (20, 40), (21, 35), (24, 48), (25, 41), (26, 48), (14, 16), (12, 13),
               (8, 96), (6, 80), (9, 72), (12, 96), (14, 90), (16, 80), (10, 65), (18, 64), (21, 50), (20, 60), (9, 33), (11, 48),
-              (20, 96), (23, 90), (16, 96), (24, 80), (26, 70), (28, 64), (22, 49), (32, 48), (29, 40), (27, 33)]     # three to six row blocks; the last line: one wave per SIMD
+              (20, 96), (23, 90), (16, 96), (24, 80), (26, 70), (28, 64), (22, 49), (32, 48), (29, 40), (27, 33),
+              (12, 112), (14, 128), (20, 100), (8, 112), (10, 128)]     # three to eight row blocks; the last two lines: one wave per SIMD
 
 
 @pytest.mark.parametrize("D,K", MID_SHAPES)
