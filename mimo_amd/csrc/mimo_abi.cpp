@@ -88,6 +88,7 @@ struct mimo_ctx {
   int comm_world = 1;
   bool rowwave_vi_call = false; // set by mimo_estep for the call in progress: row-owner softmax + statistics kernel
   bool rowwave_call = false;    // set by mimo_gibbs_labels for the call in progress: Theta was uploaded in the row-owner layout
+  bool mid_labels_call = false; // set for the call in progress: label pass on the mid kernel (Theta in the permuted grouped image)
   bool mid_call = false;        // set for the call in progress: Theta is in the grouped image of the mid kernel (mimo_mid.hip)
   int narrow_call = 0;          // set for the call in progress: Theta is in the narrow image (1: softmax + statistics pass, 2: label pass, 3: label pass + statistics fused)
 
@@ -486,9 +487,23 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
   return D >= 24 || !use_narrow(ctx, K, false, plain, true);
 }
 
+// Label pass of the mid shapes (mimo_mid.hip, label mode + the label-statistics kernels): K <= 48 at Dz >= 10, plain requests, where it
+// measured ahead of the row-owner label kernels (profiles/r04_mid_label_sweep.txt); "mid_labels_min_d" (mimo_tune) moves the lower end
+static int g_mid_labels_min_d = [] { const char* e = getenv("MIMO_MID_LABELS_MIN_D"); return e ? atoi(e) : 0; }();
+static bool use_mid_labels(const mimo_ctx* ctx, int K, bool wants_tables) {
+  if (wants_tables || !mid_labels_covers(K, ctx->D, ctx->structure) || !label_stats_covers(K, ctx->D, ctx->structure)) return false;
+  if (g_mid_labels_min_d > 0) return ctx->D >= g_mid_labels_min_d;
+  // measured (tools/mid_label_sweep.py, N = 2e6, fraction of the float64 rate of the whole sweep, row-owner label kernels -> mid label mode):
+  //   K <= 16 from Dz = 17 (the streamed kernel pads to 32 components: Dz=17 K=16 0.23 -> 0.34, Dz=24 0.28 -> 0.45, Dz=32 0.29 -> 0.47; Dz=28 K=8 0.15 -> 0.26)
+  //   K = 33 .. 48 from Dz = 14 (Dz=14 0.45 -> 0.49, Dz=20 0.46 -> 0.55, Dz=28 0.48 -> 0.64); K = 17 .. 32 from Dz = 20 (0.48 -> 0.51, Dz=32 0.56 -> 0.58)
+  //   below: the row-owner kernels with Theta resident in LDS stay ahead (Dz=16 K=32 0.51 against 0.41)
+  const int D = ctx->D;
+  return K >= 33 ? D >= 14 : K >= 17 ? D >= 20 : D >= 17;
+}
+
 // Theta image of the mid kernel: [steps][KB][64] in the grouped feature order + mid_pf() zero slices
-static int upload_theta_mid(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K) {
-  const int D = ctx->D, KB = (K + 15) / 16, NS = mid_steps(D);
+static int upload_theta_mid(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K, bool labels = false) {
+  const int D = ctx->D, KB = (K + 15) / 16, NS = mid_steps(D), V = 4 * KB;
   const size_t count = ((size_t)NS * KB + mid_pf()) * 64;
   int rc;
   if ((rc = ensure_dev(ctx, &ctx->theta_d, &ctx->theta_cap, count))) return rc;
@@ -501,7 +516,12 @@ static int upload_theta_mid(mimo_ctx* ctx, const double* c, const double* b, con
     int st, jj;
     narrow_group_pos(D, aa, bb, &st, &jj);
     finite = finite && std::fabs(v) <= 1.7976931348623157e308;
-    img[((size_t)st * KB + k / 16) * 64 + 16 * jj + k % 16] = v;
+    int rb = k / 16, i = k % 16;
+    if (labels) {                       // label pass: lane quarter q holds components q V .. q V + V - 1 (slot i of row block rb: q = i & 3, r = i >> 2)
+      const int qq = k / V, t = k % V;
+      rb = t / 4; i = 4 * (t % 4) + qq;
+    }
+    img[((size_t)st * KB + rb) * 64 + 16 * jj + i] = v;
   };
   for (int k = 0; k < K; ++k) {
     const double* bk = b + (size_t)k * D;
@@ -640,7 +660,8 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
   const bool narrow_g1 = src == kSrcEstep && ctx->narrow_call == 3;                 // narrow label pass with the statistics of the labels in the same kernel
   const bool narrow_vi = src == kSrcEstep && (ctx->narrow_call == 1 || narrow_g1);  // narrow softmax + statistics pass (or the above: same launch shape)
   const bool narrow_g = src == kSrcEstep && ctx->narrow_call == 2;                  // narrow label pass + label statistics
-  const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave || narrow_g);
+  const bool mid_g = src == kSrcEstep && ctx->mid_labels_call;                       // mid label pass + label statistics
+  const bool lstats = !small && ((src == kSrcLabels && label_stats_covers(K, D, ctx->structure)) || rowwave || narrow_g || mid_g);
   const bool mid = src == kSrcEstep && ctx->mid_call;                               // mid shapes: row-owner E-step + column-owner statistics
   int grid = small ? small_grid(a, ctx->num_cu, src) : lstats ? label_stats_grid(a, ctx->num_cu)
              : rowvi ? rowwave_grid(a, ctx->num_cu) : narrow_vi ? narrow_grid(a, ctx->num_cu, ctx->F, narrow_g1 ? 2 : 0)
@@ -676,6 +697,12 @@ static int run_pass(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S,
       rc = timed_launch(ctx, "gibbs_rowwave_kernel", [&]() -> int {
         if (a.fuse_hist) HIP_TRY(ctx, launch_label_hist_reset(a, ctx->stream));
         HIP_TRY(ctx, launch_gibbs_rowwave(a, rowwave_grid(a, ctx->num_cu), ctx->stream));
+        return MIMO_OK;
+      });
+      if (rc) return rc;
+    } else if (mid_g) {
+      rc = timed_launch(ctx, "mid_kernel (labels)", [&]() -> int {
+        HIP_TRY(ctx, launch_mid_labels(a, mid_labels_grid(a, ctx->num_cu), ctx->stream));
         return MIMO_OK;
       });
       if (rc) return rc;
@@ -882,6 +909,7 @@ static int run_fused(mimo_ctx* ctx, KernelArgs& a, int src, int flags, double* S
       if ((rc = run_pass(ctx, a, kSrcEstep, flags & ~(MIMO_F_DEVICE_OUT), nullptr, nullptr))) return rc;
       ctx->rowwave_call = false;
       ctx->narrow_call = 0;
+      ctx->mid_labels_call = false;
     }
     if ((rc = ensure_dev(ctx, &ctx->labels_tmp, &ctx->labels_tmp_cap, (size_t)N))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->cnt_d + 1, 0, 256 * sizeof(unsigned long long), ctx->stream));
@@ -1214,14 +1242,18 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
   }
   const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
   const int nw = use_narrow(ctx, K, true, !wants_tables, !no_stats);
-  const bool rw = !nw && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
-  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, nw - 1) : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
+  const bool ml = !nw && !use_small(ctx, K) && use_mid_labels(ctx, K, wants_tables);
+  const bool rw = !nw && !ml && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
+  if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, nw - 1) : ml ? upload_theta_mid(ctx, c, b, W, K, true)
+            : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
   a.theta = ctx->theta_d;
   ctx->rowwave_call = rw;
   ctx->narrow_call = nw;
+  ctx->mid_labels_call = ml;
   rc = run_fused(ctx, a, kSrcEstep, flags, no_stats ? nullptr : S, nullptr);
   ctx->rowwave_call = false;
   ctx->narrow_call = 0;
+  ctx->mid_labels_call = false;
   if (rc) return rc;
   if (labels_out && !(flags & MIMO_F_DEVICE_OUT)) {
     HIP_TRY(ctx, hipMemcpyAsync(labels_out, ctx->labels, (size_t)ctx->N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1600,6 +1632,11 @@ int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value) {
       set_sorted_range_cap((int)value);
       return MIMO_OK;
     }
+    if (!strcmp(key, "mid_labels_min_d")) {
+      if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_labels_min_d = %lld outside [0, 64]", (long long)value);
+      g_mid_labels_min_d = (int)value;
+      return MIMO_OK;
+    }
     if (!strcmp(key, "mid_narrow_k")) {
       if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_narrow_k = %lld outside [0, 64]", (long long)value);
       g_mid_narrow_k = (int)value;
@@ -1691,6 +1728,10 @@ static void plan_route(const mimo_ctx* ctx, const KernelArgs& a, int K, int gibb
   } else if (!gibbs && ctx->n_bad == 0 && D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     if (desc) snprintf(desc, dlen, "vi_rowwave_kernel<%d row blocks>", K <= 32 ? 2 : 4);
+  } else if (gibbs && use_mid_labels(ctx, K, false)) {
+    const int ll = label_stage();
+    out8[0] = MIMO_PLAN_MID; out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
+    if (desc) snprintf(desc, dlen, "mid_kernel<Dz=%d, row blocks %d, label draw> + %s", D, (K + 15) / 16, lst);
   } else if (gibbs && use_rowwave(ctx, K, false)) {
     const int ll = label_stage();     // (> 1: the sliced statistics of the large shapes)
     out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 1 + ll;
@@ -1732,7 +1773,7 @@ int mimo_plan(mimo_ctx* ctx, int K, int gibbs, int64_t* out8) {
   a.gibbs = gibbs ? 1 : 0;
   plan_route(ctx, a, K, gibbs, out8, nullptr, 0);
   switch (out8[0]) {
-    case MIMO_PLAN_MID: out8[6] = mid_grid(a, ctx->num_cu); break;
+    case MIMO_PLAN_MID: out8[6] = gibbs ? mid_labels_grid(a, ctx->num_cu) : mid_grid(a, ctx->num_cu); break;
     case MIMO_PLAN_NARROW: out8[6] = narrow_grid(a, ctx->num_cu, ctx->F, use_narrow(ctx, K, gibbs != 0, true, true) - 1); break;
     case MIMO_PLAN_SMALL: out8[6] = small_grid(a, ctx->num_cu, kSrcEstep); break;
     case MIMO_PLAN_ROWWAVE_VI: case MIMO_PLAN_ROWWAVE: out8[6] = rowwave_grid(a, ctx->num_cu); break;

@@ -72,5 +72,10 @@ int mid_pf();
 int mid_rows_per_step(int K, int D);
 int mid_grid(const KernelArgs& a, int num_cu);
 hipError_t launch_mid(const KernelArgs& a, int grid, hipStream_t stream);
+// ... and their label pass (K <= 48, Dz = 10 .. 32): E-step + draw on row-owner waves; theta in the grouped image with the components
+// permuted as in the row-owner label kernels (slot i of row block rb = component (i & 3) V + 4 rb + (i >> 2), V = 4 KB)
+bool mid_labels_covers(int K, int D, int structure);
+int mid_labels_grid(const KernelArgs& a, int num_cu);
+hipError_t launch_mid_labels(const KernelArgs& a, int grid, hipStream_t stream);
 
 }  // namespace mimo

@@ -46,19 +46,24 @@ constexpr int mid_wgs_per_cu(int D, int KB) { return mid_big(D, KB) ? 1 : mid_nw
 constexpr int mid_nbuf(int D, int KB) { return 2 * mid_tile_bytes(D, KB) * mid_wgs_per_cu(D, KB) + 2048 <= 160 * 1024 ? 2 : 1; }
 constexpr size_t mid_lds_bytes(int D, int KB) { return mid_nbuf(D, KB) * mid_tile_bytes(D, KB) + sizeof(double) * (64 + 8); }
 
-template <int DT, int KB, int NW>
-__global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(const KernelArgs a) {
-  constexpr int PF = mid_big(DT, KB) ? 16 : kMidPF;
+// MODE 0: softmax + statistics.  MODE 1: label draw (Gibbs sweep of the same shapes): the E-step as above, then the inverse-CDF draw on
+// the unnormalised cumulative sums in registers (mimo/utils/stats.py:8-21) — the operand image is permuted so that lane (q, j) holds
+// the CONTIGUOUS quarter q V .. q V + V - 1 (V = 4 KB) of row j's components (upload_theta_mid, as the row-owner label kernels);
+// no R tile, no second product, no workgroup barrier: the waves run on their own, the statistics of the labels come from the
+// label-statistics kernels behind it.
+template <int DT, int KB, int NW, int MODE = 0>
+__global__ __launch_bounds__(64 * NW, MODE == 1 ? 2 : mid_wgs_per_cu(DT, KB)) void mid_kernel(const KernelArgs a) {
+  constexpr int PF = (MODE == 0 && mid_big(DT, KB)) ? 16 : kMidPF;
   constexpr NarrowGroup<DT> GR{};
   constexpr int NSG = narrow_group_steps(DT);
   constexpr int NCB = mid_ncb(DT), NCBW = (NCB + NW - 1) / NW;
   constexpr int ZS = mid_zs(DT), RS = 16 * KB + 1, ROWS = 16 * NW, WG = 64 * NW;
   constexpr int ZI = (16 * DT + 63) / 64;
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NBUF = mid_nbuf(DT, KB);
+  constexpr int NBUF = MODE == 1 ? 1 : mid_nbuf(DT, KB);
   double* Zt = reinterpret_cast<double*>(smem);         // [NBUF][ROWS][ZS]
   double* Rt = Zt + (size_t)NBUF * ROWS * ZS;           // [NBUF][ROWS][RS]
-  double* etab = Rt + (size_t)NBUF * ROWS * RS;         // [64]: 2^(i/64)
+  double* etab = Rt + (MODE == 1 ? 0 : (size_t)NBUF * ROWS * RS);         // [64]: 2^(i/64)  (label mode: no R tile)
   double* sred = etab + 64;                             // [NW]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -91,20 +96,21 @@ __global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(co
 
   // second product: byte offsets of the two factors of feature 16 cb + j (this wave's column blocks cb = wave + NW i) inside
   // row q of a group; a block past the last one reads the zero slot twice
-  int spa[NCBW], spb[NCBW];
+  constexpr int NCBS = MODE == 1 ? 1 : NCBW;              // (label mode: no statistics in this kernel)
+  int spa[NCBS], spb[NCBS];
 #pragma unroll
-  for (int i = 0; i < NCBW; ++i) {
+  for (int i = 0; i < NCBS; ++i) {
     const int cb = wave + NW * i;
     const int f = 16 * cb + j;
     const bool real = cb < NCB;
     spa[i] = q * ZS + (real ? a.feat[2 * f] : DT + 1);
     spb[i] = q * ZS + (real ? a.feat[2 * f + 1] : DT + 1);
   }
-  d4 sacc[KB][NCBW];
+  d4 sacc[KB][NCBS];
 #pragma unroll
   for (int rb = 0; rb < KB; ++rb)
 #pragma unroll
-    for (int i = 0; i < NCBW; ++i) sacc[rb][i] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NCBS; ++i) sacc[rb][i] = d4{0.0, 0.0, 0.0, 0.0};
   double sc_lse = 0.0, sc_prod = 1.0;
   int since_flush = 0;
   wg_sync();
@@ -169,6 +175,38 @@ __global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(co
       m = fmax(m, __shfl_xor(m, 16));
       m = fmax(m, __shfl_xor(m, 32));
     }
+    if constexpr (MODE == 1) {
+      // inclusive cumulative sums of e = exp(l - max) over the lane's quarter (component q V + 4 rb + r sits in acc[rb][r]), then over
+      // the four quarters of the row (lanes j, j + 16, j + 32, j + 48); label = #{k : u cum_K > cum_k}
+      double run = 0.0;
+#pragma unroll
+      for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          run += exp_nonpos(acc[rb][r] - m, etab);
+          acc[rb][r] = run;
+        }
+      double incl = run;
+      {
+        double v = __shfl_up(incl, 16);  if (q >= 1) incl += v;
+        v = __shfl_up(incl, 32);         if (q >= 2) incl += v;
+      }
+      double excl = __shfl_up(incl, 16);
+      if (q == 0) excl = 0.0;
+      const double ctot = __shfl(incl, 48 + j);
+      const double uu = a.u ? (valid ? a.u[n] : 0.0) : philox_uniform(a.seed, (uint64_t)(a.row0 + n), a.sweep);
+      const double tl = uu * ctot - excl;
+      int cnt = 0;
+#pragma unroll
+      for (int rb = 0; rb < KB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cnt += tl > acc[rb][r] ? 1 : 0;
+      cnt += __shfl_xor(cnt, 16);
+      cnt += __shfl_xor(cnt, 32);
+      if (q == 0 && valid) a.labels[n] = cnt < K ? cnt : K - 1;
+      __builtin_amdgcn_s_setprio(0);
+      continue;
+    }
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int rb = 0; rb < KB; ++rb)
@@ -225,6 +263,7 @@ __global__ __launch_bounds__(64 * NW, mid_wgs_per_cu(DT, KB)) void mid_kernel(co
     }
   }
 
+  if constexpr (MODE == 1) return;
   // ---- per-workgroup partial block: every column block has exactly one owner
   const int FT = a.F16_total;
   const size_t pstride = (size_t)a.K16 * 16 * FT + 4;
@@ -280,6 +319,36 @@ static mid_fn pick_mid(int D, int kb) {
 #undef MIMO_MD
   }
   return nullptr;
+}
+
+// label-draw instantiations: K <= 48 (one to three row blocks), four waves
+static mid_fn pick_mid_labels(int D, int kb) {
+  switch (D) {
+#define MIMO_ML(d) case d: return kb == 1 ? mid_kernel<d, 1, 4, 1> : kb == 2 ? mid_kernel<d, 2, 4, 1> : kb == 3 ? mid_kernel<d, 3, 4, 1> : nullptr;
+    MIMO_ML(10) MIMO_ML(11) MIMO_ML(12) MIMO_ML(13) MIMO_ML(14) MIMO_ML(15) MIMO_ML(16)
+    MIMO_ML(17) MIMO_ML(18) MIMO_ML(19) MIMO_ML(20) MIMO_ML(21) MIMO_ML(22) MIMO_ML(23) MIMO_ML(24) MIMO_ML(25) MIMO_ML(26) MIMO_ML(27)
+    MIMO_ML(28) MIMO_ML(29) MIMO_ML(30) MIMO_ML(31) MIMO_ML(32)
+#undef MIMO_ML
+  }
+  return nullptr;
+}
+bool mid_labels_covers(int K, int D, int structure) {
+  static const bool on = [] { const char* e = getenv("MIMO_MID_LABELS"); return !e || atoi(e) != 0; }();       // tuning knob
+  return on && structure == 0 && K >= 1 && K <= 48 && pick_mid_labels(D, (K + 15) / 16) != nullptr;
+}
+int mid_labels_grid(const KernelArgs& a, int num_cu) {
+  const int64_t need = (a.N + 63) / 64;
+  int64_t g = (int64_t)num_cu * 2;
+  if (g > need) g = need;
+  return (int)(g < 1 ? 1 : g);
+}
+hipError_t launch_mid_labels(const KernelArgs& a, int grid, hipStream_t stream) {
+  const int kb = (a.K + 15) / 16;
+  mid_fn fn = pick_mid_labels(a.D, kb);
+  if (!fn || a.K16 != kb || !a.labels) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * ((size_t)64 * mid_zs(a.D) + 64 + 8);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, stream, a);
+  return hipGetLastError();
 }
 
 // Which (K, Dz) the kernel exists for: full feature map, K <= 32, Dz = 9 .. 32 (MIMO_MID=0: route off; the router in

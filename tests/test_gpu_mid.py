@@ -121,3 +121,50 @@ def test_rows_with_nan_on_the_mid_kernels(engine, D, K):
     assert abs(sc[0] - lse.sum()) < 1e-12 * max(1., abs(lse.sum()))
     assert abs(S.gating_counts.sum() - N) < 1e-9 * N
     engine.upload(Z)
+
+
+@pytest.mark.parametrize("D,K", [(10, 24), (12, 40), (14, 33), (16, 48), (17, 16), (20, 32), (24, 12), (28, 40), (32, 17), (32, 48), (21, 9), (30, 5)])
+def test_mid_label_pass_vs_oracle(engine, D, K):
+    """The mid kernel's label mode (E-step on row-owner waves with register features, inverse-CDF draw on the unnormalised cumulative sums
+    over the lane's contiguous quarter of the components) + the label-statistics kernels: labels bit-exact for host uniforms and the
+    Philox stream, counts exact, statistics against the oracle, a second sweep bit-identical, rows with NaN, few workgroups."""
+    from oracle import mimo_oracle as O
+    rng = np.random.default_rng(9100 + 40 * D + K)
+    engine.tune("mid_labels_min_d", 10)
+    try:
+        for N in (1, 17, 20011):
+            Z, c, b, W = _random_problem(rng, N, D, K)
+            engine.upload(Z)
+            assert engine.plan(K, gibbs=True)["kind"] == "mid"
+            if N == 20011:
+                engine.tune("num_cu", 3)
+            L = O.canonical_eval(Z, c, b, W)
+            u = rng.random(N)
+            lab, S = engine.gibbs_labels(c, b, W, u=u)
+            ref = O.sample_discrete_from_log(L, u)
+            assert np.array_equal(lab, ref)
+            n, sx, sxx = O.packed_stats(Z, O.one_hot(ref, K))
+            assert np.array_equal(S.n, n) and rel_err(S.sx, sx) < 1e-11 and rel_err(S.sxx, sxx) < 1e-11
+            lab_p, Sp = engine.gibbs_labels(c, b, W, seed=3, sweep=7)
+            assert np.array_equal(lab_p, O.sample_discrete_from_log(L, O.philox_uniforms(3, np.arange(N), 7)))
+            lab_q, Sq = engine.gibbs_labels(c, b, W, seed=3, sweep=7)
+            assert np.array_equal(lab_q, lab_p) and np.array_equal(Sq.sxx, Sp.sxx)
+            engine.set_row_offset(1000)
+            lab_o, _ = engine.gibbs_labels(c, b, W, seed=3, sweep=7, stats=False)
+            assert np.array_equal(lab_o, O.sample_discrete_from_log(L, O.philox_uniforms(3, 1000 + np.arange(N), 7)))
+            engine.set_row_offset(0)
+            engine.tune("num_cu", 0)
+        # rows with NaN: every label is drawn (normaliser-only log-density), the statistics leave the rows out
+        bad = rng.choice(N, size=23, replace=False)
+        Zn = Z.copy(); Zn[bad, 0] = np.nan
+        Zc = Z.copy(); Zc[bad] = 0.
+        mask = np.ones(N); mask[bad] = 0.
+        engine.upload(Zn)
+        Lc = O.canonical_eval(Zc, c, b, W)
+        labn, G = engine.gibbs_labels(c, b, W, seed=4, sweep=2)
+        refn = O.sample_discrete_from_log(Lc, O.philox_uniforms(4, np.arange(N), 2))
+        gn, _, gsxx = O.packed_stats(Zc, O.one_hot(refn, K) * mask[None, :])
+        assert np.array_equal(labn, refn) and np.array_equal(G.n, gn) and rel_err(G.sxx, gsxx) < 1e-11 and G.gating_counts.sum() == N
+    finally:
+        engine.tune("mid_labels_min_d", 0)
+        engine.tune("num_cu", 0)

@@ -703,7 +703,8 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(900 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "rowwave")
+    mid = K <= 48 and (D >= 14 if K >= 33 else D >= 20 if K >= 17 else D >= 17)          # the mid kernel's label mode (round 4)
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "mid" if mid else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
@@ -740,7 +741,7 @@ def test_sliced_label_statistics(engine, D, K, N):
     rng = np.random.default_rng(1300 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
-    assert engine.plan(K, gibbs=True)["kind"] in ("two-stage", "fused", "rowwave")     # (rowwave: Theta streamed through LDS)
+    assert engine.plan(K, gibbs=True)["kind"] in ("two-stage", "fused", "rowwave", "mid")     # (rowwave: Theta streamed through LDS; mid: K <= 48)
     L = O.canonical_eval(Z, c, b, W)
     lab_p, Sp = engine.gibbs_labels(c, b, W, seed=9, sweep=2)
     ref_p = O.sample_discrete_from_log(L, O.philox_uniforms(9, np.arange(N), 2))
@@ -1051,6 +1052,7 @@ def test_streamed_label_kernel_many_steps(engine, D, K):
     rng = np.random.default_rng(2100 + 10 * D + K)
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
+    engine.tune("mid_labels_min_d", 64)      # ((32, 40) runs on the mid kernel's label mode by default since round 4: the streamed kernel stays tested)
     assert engine.plan(K, gibbs=True)["kind"] == "rowwave"
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)

@@ -31,6 +31,7 @@ def test_baseline_and_example_shapes_keep_their_families():
         ((20, 16, False), "mid"), ((32, 32, False), "mid"), ((28, 8, False), "mid"), ((12, 96, False), "mid"), ((24, 48, False), "mid"),
         ((16, 8, False), "narrow"), ((28, 4, False), "narrow"),
         ((8, 32, False), "rowwave-vi"), ((32, 128, True), "rowwave"), ((20, 96, True), "rowwave"),
+        ((20, 16, True), "mid"), ((28, 48, True), "mid"), ((16, 32, True), "rowwave"), ((12, 112, False), "mid"), ((20, 96, False), "mid"),
     ]
     for (D, K, gibbs), kind in pins:
         assert rt.route(lib, D, K, gibbs)[0] == kind, (D, K, gibbs, rt.route(lib, D, K, gibbs))

@@ -89,10 +89,11 @@ def test_two_hip_ranks_ilr_fixture(engine, tmp_path):
         assert rel_err(res[0][f"post{i}"], p) < 1e-9
 
 
-# one shape per kernel family (softmax pass / label pass): fused tile, row-owner, two-stage (wide), narrow, small,
-# streamed label kernel + one-pass label statistics
-FAMILIES = [(16, 64, "fused", "rowwave"), (8, 256, "fused", "rowwave"), (20, 80, "two-stage", "rowwave"), (2, 50, "narrow", "narrow"),
-            (2, 4, "small", "small"), (8, 32, "rowwave-vi", "rowwave"), (12, 6, "narrow", "narrow")]
+# one shape per kernel family (softmax pass / label pass): fused tile, row-owner, mid (softmax and label mode), two-stage (wide), narrow,
+# small, streamed label kernel + one-pass label statistics
+FAMILIES = [(16, 64, "fused", "rowwave"), (8, 256, "fused", "rowwave"), (20, 80, "mid", "rowwave"), (2, 50, "narrow", "narrow"),
+            (2, 4, "small", "small"), (8, 32, "rowwave-vi", "rowwave"), (12, 6, "narrow", "narrow"), (24, 128, "two-stage", "rowwave"),
+            (20, 16, "mid", "mid")]
 
 
 @pytest.mark.parametrize("D,K,softmax_kind,label_kind", FAMILIES)
