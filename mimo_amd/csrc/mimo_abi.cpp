@@ -490,6 +490,7 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
 // Label pass of the mid shapes (mimo_mid.hip, label mode + the label-statistics kernels): K <= 48 at Dz >= 10, plain requests, where it
 // measured ahead of the row-owner label kernels (profiles/r04_mid_label_sweep.txt); "mid_labels_min_d" (mimo_tune) moves the lower end
 static int g_mid_labels_min_d = [] { const char* e = getenv("MIMO_MID_LABELS_MIN_D"); return e ? atoi(e) : 0; }();
+static int g_mid_labels_narrow_k = 0;      // (mimo_tune "mid_labels_narrow_k": K from which the label mode goes before the narrow label kernels; 0: measured rule)
 static bool use_mid_labels(const mimo_ctx* ctx, int K, bool wants_tables) {
   if (wants_tables || !mid_labels_covers(K, ctx->D, ctx->structure) || !label_stats_covers(K, ctx->D, ctx->structure)) return false;
   if (g_mid_labels_min_d > 0) return ctx->D >= g_mid_labels_min_d;
@@ -499,6 +500,13 @@ static bool use_mid_labels(const mimo_ctx* ctx, int K, bool wants_tables) {
   //   below: the row-owner kernels with Theta resident in LDS stay ahead (Dz=16 K=32 0.51 against 0.41)
   const int D = ctx->D;
   return K >= 33 ? D >= 14 : K >= 17 ? D >= 20 : D >= 17;
+}
+
+static bool mid_labels_before_narrow(const mimo_ctx* ctx, int K) {
+  if (g_mid_labels_narrow_k > 0) return K >= g_mid_labels_narrow_k;
+  // measured (profiles/r04_mid_label_sweep.txt, second block): the narrow label kernels stay ahead up to Dz = 20 (Dz=16 K=16 0.34 against 0.33,
+  // K=8 0.23 against 0.17); from Dz = 24 their one-wave-per-SIMD variants fall behind for K = 5 .. 8 (Dz=24 K=8 1.11 -> 0.67 ms, Dz=26 1.29 -> 0.74)
+  return K >= 5 && ctx->D >= 24;
 }
 
 // Theta image of the mid kernel: [steps][KB][64] in the grouped feature order + mid_pf() zero slices
@@ -1241,8 +1249,9 @@ int mimo_gibbs_labels(mimo_ctx* ctx, const double* c, const double* b, const dou
     }
   }
   const bool wants_tables = (flags & (MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE)) != 0;
-  const int nw = use_narrow(ctx, K, true, !wants_tables, !no_stats);
-  const bool ml = !nw && !use_small(ctx, K) && use_mid_labels(ctx, K, wants_tables);
+  int nw = use_narrow(ctx, K, true, !wants_tables, !no_stats);
+  const bool ml = !use_small(ctx, K) && use_mid_labels(ctx, K, wants_tables) && (!nw || mid_labels_before_narrow(ctx, K));
+  if (ml) nw = 0;
   const bool rw = !nw && !ml && !use_small(ctx, K) && use_rowwave(ctx, K, wants_tables);
   if ((rc = nw ? upload_theta_narrow(ctx, c, b, W, K, nw - 1) : ml ? upload_theta_mid(ctx, c, b, W, K, true)
             : rw ? upload_theta_rowwave(ctx, c, b, W, K) : upload_theta(ctx, c, b, W, K, &a))) return rc;
@@ -1632,6 +1641,11 @@ int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value) {
       set_sorted_range_cap((int)value);
       return MIMO_OK;
     }
+    if (!strcmp(key, "mid_labels_narrow_k")) {
+      if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_labels_narrow_k = %lld outside [0, 64]", (long long)value);
+      g_mid_labels_narrow_k = (int)value;
+      return MIMO_OK;
+    }
     if (!strcmp(key, "mid_labels_min_d")) {
       if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_labels_min_d = %lld outside [0, 64]", (long long)value);
       g_mid_labels_min_d = (int)value;
@@ -1715,6 +1729,10 @@ static void plan_route(const mimo_ctx* ctx, const KernelArgs& a, int K, int gibb
   if (!gibbs && use_mid(ctx, K, true)) {
     out8[0] = MIMO_PLAN_MID; out8[1] = 1;
     if (desc) snprintf(desc, dlen, "mid_kernel<Dz=%d, row blocks %d, %d waves>", D, (K + 15) / 16, mid_rows_per_step(K, D) / 16);
+  } else if (gibbs && use_mid_labels(ctx, K, false) && !use_small(ctx, K) && (mid_labels_before_narrow(ctx, K) || !use_narrow(ctx, K, true, true, true))) {
+    const int ll = label_stage();
+    out8[0] = MIMO_PLAN_MID; out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
+    if (desc) snprintf(desc, dlen, "mid_kernel<Dz=%d, row blocks %d, label draw> + %s", D, (K + 15) / 16, lst);
   } else if (const int nm = use_narrow(ctx, K, gibbs != 0, true, true)) {
     out8[0] = MIMO_PLAN_NARROW; out8[1] = nm == 2 ? 2 : 1;
     if (nm == 2) { out8[4] = 2; out8[5] = 2; }       // label kernel + label-statistics kernel (nm == 3: one kernel, labels written once)
@@ -1728,10 +1746,6 @@ static void plan_route(const mimo_ctx* ctx, const KernelArgs& a, int K, int gibb
   } else if (!gibbs && ctx->n_bad == 0 && D <= 16 && vi_rowwave_covers(K, ctx->F16, a.ZS)) {
     out8[0] = MIMO_PLAN_ROWWAVE_VI; out8[1] = 1;
     if (desc) snprintf(desc, dlen, "vi_rowwave_kernel<%d row blocks>", K <= 32 ? 2 : 4);
-  } else if (gibbs && use_mid_labels(ctx, K, false)) {
-    const int ll = label_stage();
-    out8[0] = MIMO_PLAN_MID; out8[1] = 1 + ll; out8[4] = 1 + ll; out8[5] = 1 + ll;
-    if (desc) snprintf(desc, dlen, "mid_kernel<Dz=%d, row blocks %d, label draw> + %s", D, (K + 15) / 16, lst);
   } else if (gibbs && use_rowwave(ctx, K, false)) {
     const int ll = label_stage();     // (> 1: the sliced statistics of the large shapes)
     out8[0] = MIMO_PLAN_ROWWAVE; out8[1] = 1 + ll;

@@ -21,12 +21,12 @@ for D, K in shapes:
     flops = N * K * FE + N * FS
     out = []
     for mind in (64, 10):
-        eng.tune("mid_labels_min_d", mind)
+        eng.tune("mid_labels_min_d", mind); eng.tune("mid_labels_narrow_k", int(os.environ.get("MID_LABELS_NARROW_K", "0")))
         kind = eng.plan(K, gibbs=True)["kind"]
         for it in range(2): eng.gibbs_labels(c, b, W, seed=1, sweep=it, return_labels=False)
         eng.profile(True); eng.profile_read(reset=True)
         for it in range(4): eng.gibbs_labels(c, b, W, seed=1, sweep=it, return_labels=False)
         ms, n = eng.profile_read(reset=True); eng.profile(False)
         out.append((kind, ms / n, flops / (ms / n * 1e-3) / 78.6e12))
-    eng.tune("mid_labels_min_d", 0)
+    eng.tune("mid_labels_min_d", 0); eng.tune("mid_labels_narrow_k", 0)
     print(f"Dz={D:2d} K={K:3d}: " + "  |  ".join(f"{o[0]:8s} {o[1]:7.3f} ms ({o[2]:.2f})" for o in out), flush=True)
