@@ -110,7 +110,7 @@ class TiedGaussiansWithScaledPrecision:
         self.dim = dim
         f = lambda v: None if v is None else np.array(v, dtype=float)
         self.kappas, self.mus = f(kappas), f(mus)
-        self._lmbdas, self._chol = f(lmbdas), None
+        self._lmbdas, self._chol, self._lmbdas_inv = f(lmbdas), None, None
 
     @property
     def lmbdas(self):
@@ -123,7 +123,7 @@ class TiedGaussiansWithScaledPrecision:
         reference's draws and entropies then use the factors of the OLD kappa (bayesian.py:662-664 updates
         posterior.kappas every sweep, :764 reads the entropy).  Kept, because the bound is compared bit for bit."""
         self._lmbdas = None if value is None else np.asarray(value, dtype=float)
-        self._chol = None
+        self._chol = self._lmbdas_inv = None
 
     @property
     def params(self):
@@ -164,6 +164,13 @@ class TiedGaussiansWithScaledPrecision:
     @property
     def sigmas(self):
         return np.linalg.inv(self.omegas)
+
+    def trace_with_sigmas(self, a):
+        """tr(a Omega_k^-1) for all k, a symmetric: the inverses of the precisions are kept until `lmbdas` is assigned
+        again (the mean-field sweeps change kappa only), so that an iteration costs one (K, D^2) x (D^2,) product."""
+        if self._lmbdas_inv is None:
+            self._lmbdas_inv = np.linalg.inv(self._lmbdas).reshape(self.size, -1)
+        return (self._lmbdas_inv @ np.ravel(a)) / self.kappas
 
     def rvs(self, sizes):
         """Per block, same RNG use as gaussian.py:975-977."""
@@ -210,20 +217,24 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
     def _stats(self, data, weights, stats):
         return stats if stats is not None else self.likelihood.weighted_statistics(data, weights)
 
-    def _hyper_params(self, mus, xk, nk, xxTk):
+    def _hyper_params(self, mus, xk, nk, xxTk, pooled=None):
         """The pooled hyper-posterior of (tau, Lambda) given the component means `mus`
-        (bayesian.py:641-653, identical at :670-682 and :708-720)."""
+        (bayesian.py:641-653, identical at :670-682 and :708-720).  `pooled` = `_pooled(xxTk)`, the part that
+        does not depend on `mus`, computed once per update by the callers that iterate."""
         hp, K = self.hyper_prior, self.size
         kap, m0 = self.prior.kappas, hp.gaussian.mu
         rho = np.sum(kap[:, None] * mus + hp.kappa * m0, axis=0) / np.sum(kap + hp.kappa)
         kappa = np.sum(kap + hp.kappa) / K
         d = m0[None, :] - mus
-        shrink = np.sum((hp.kappa * kap / (hp.kappa + kap))[:, None, None] * np.einsum('kd,kl->kdl', d, d), axis=0) / K
-        psi = np.linalg.inv(np.linalg.inv(hp.wishart.psi) + shrink
-                            + np.sum(xxTk, axis=0) / K - np.einsum('kd,kl->dl', mus, xk) / K
-                            - np.einsum('kd,kl->dl', xk, mus) / K + np.einsum('k,kd,kl->dl', nk, mus, mus) / K)
+        shrink = (d * (hp.kappa * kap / (hp.kappa + kap))[:, None]).T @ d
+        cross = mus.T @ xk
+        psi = np.linalg.inv((self._pooled(xxTk) if pooled is None else pooled)
+                            + (shrink - cross - cross.T + (mus * nk[:, None]).T @ mus) / K)
         nu = np.sum(hp.wishart.nu + nk + 1) / K
         return rho, kappa, psi, nu
+
+    def _pooled(self, xxTk):
+        return np.linalg.inv(self.hyper_prior.wishart.psi) + np.sum(xxTk, axis=0) / self.size
 
     # ---- Gibbs sampling (bayesian.py:619-659) ------------------------------------------------------
     def resample(self, data, labels=None, nb_iter=5, stats=None):
@@ -242,10 +253,11 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
     def meanfield_update(self, data, weights=None, nb_iter=25, stats=None):
         xk, nk, xxTk, _ = self._stats(data, weights, stats)
         kap = self.prior.kappas
+        pooled = self._pooled(xxTk)
         for _ in range(nb_iter):
             self.posterior.kappas = kap + nk
             self.posterior.mus = (kap[:, None] * self.hyper_posterior.gaussian.mu[None, :] + xk) / (kap + nk)[:, None]
-            self.hyper_posterior.params = self._hyper_params(self.posterior.mus, xk, nk, xxTk)
+            self.hyper_posterior.params = self._hyper_params(self.posterior.mus, xk, nk, xxTk, pooled)
         _, lmbda = self.hyper_posterior.mode()
         self.likelihood.mus = self.posterior.mode()
         self.likelihood.lmbdas = np.stack(self.size * [lmbda])
@@ -253,6 +265,7 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
     # ---- stochastic mean field (bayesian.py:691-732) --------------------------------------------------
     def meanfield_sgd(self, data, weights, nb_iter, scale, step_size, stats=None):
         xk, nk, xxTk, _ = 1. / scale * Stats(self._stats(data, weights, stats))
+        pooled = self._pooled(xxTk)
         for _ in range(nb_iter):
             tau, lmbda = self.hyper_posterior.mean()
             self.prior.mus = np.stack(self.size * [tau])
@@ -260,7 +273,7 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
             self.posterior.nat_param = (1. - step_size) * self.posterior.nat_param\
                 + step_size * (self.prior.nat_param + Stats([xk, nk]))
             self.posterior.lmbdas = np.stack(self.size * [lmbda])
-            params = self._hyper_params(self.posterior.mean(), xk, nk, xxTk)
+            params = self._hyper_params(self.posterior.mean(), xk, nk, xxTk, pooled)
             self.hyper_posterior.nat_param = (1. - step_size) * self.hyper_posterior.nat_param\
                 + step_size * self.hyper_posterior.std_to_nat(params)
         _, lmbda = self.hyper_posterior.mode()
@@ -273,11 +286,10 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
         + 1/2 E[logdet Lambda] - D/2 log 2pi, with E[Lambda] = nu psi of the hyper-posterior shared by all k."""
         w = self.hyper_posterior.wishart
         nupsi = w.nu * w.psi
-        b = np.einsum('dl,kl->kd', nupsi, self.posterior.mus)
+        b = self.posterior.mus @ nupsi.T
         c = - 0.5 * self.dim * np.log(2. * np.pi) - 0.5 * np.einsum('kd,kd->k', self.posterior.mus, b)\
-            - 0.5 * np.einsum('dl,kdl->k', nupsi, np.linalg.inv(self.posterior.omegas))\
-            + 0.5 * wishart_expected_logdet(w.psi, w.nu)
-        return c, b, np.stack(self.size * [nupsi])
+            - 0.5 * self.posterior.trace_with_sigmas(nupsi) + 0.5 * wishart_expected_logdet(w.psi, w.nu)
+        return c, b, np.broadcast_to(nupsi, (self.size,) + nupsi.shape)
 
     def expected_log_likelihood(self, x):
         eng = self.likelihood._bind(x)
@@ -292,8 +304,8 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
         d = self.posterior.mus - hq.gaussian.mu[None, :]
         per_k = self.posterior.entropies() - 0.5 * self.dim * np.log(2. * np.pi) + 0.5 * self.dim * np.log(kap)\
             + 0.5 * wishart_expected_logdet(w.psi, w.nu) - 0.5 * kap * self.dim / hq.kappa\
-            - 0.5 * kap * np.einsum('kd,dl,kl->k', d, nupsi, d)\
-            - 0.5 * kap * np.einsum('dl,kld->k', nupsi, np.linalg.inv(self.posterior.omegas))
+            - 0.5 * kap * np.einsum('kd,kd->k', d @ nupsi, d)\
+            - 0.5 * kap * self.posterior.trace_with_sigmas(nupsi)
         return self.size * (hq.entropy() - hq.cross_entropy(self.hyper_prior)) + np.sum(per_k)
 
     # ---- posterior predictive (bayesian.py:785-793) ---------------------------------------------------
