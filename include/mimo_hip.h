@@ -305,6 +305,15 @@ int mimo_host_nw_vi(int K, int D, const double* a, const double* b, const double
                     double* mus, double* psis, double* nus, double* half_logdet_psi,
                     double* cc, double* bb, double* W, double* E2, double* E4);
 
+/* The same for TIED Normal-Wishart blocks (one Wishart factor shared by all k): replaces
+ * TiedNormalWishart.nat_to_std (composite.py:273-283: psi = inv(mean_k(c_k - kappa_k m_k m_k')), nu = mean_k(d_k + D))
+ * and the std_to_nat that the reference recomputes on every read of the tied natural parameters
+ * (composite.py:166-172): nat_c (K,D,D) = psi^-1 + kappa_k m_k m_k' of the POOLED psi.  psis, nus,
+ * half_logdet_psi, W, E4 hold K copies of the shared value. */
+int mimo_host_nw_vi_tied(int K, int D, const double* a, const double* b, const double* c, const double* d,
+                         double* mus, double* psis, double* nus, double* half_logdet_psi, double* nat_c,
+                         double* cc, double* bb, double* W, double* E2, double* E4);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

@@ -222,6 +222,68 @@ int mimo_host_nw_vi(int K, int D, const double* a, const double* b, const double
   });
 }
 
+int mimo_host_nw_vi_tied(int K, int D, const double* a, const double* b, const double* c, const double* d,
+                         double* mus, double* psis, double* nus, double* half_logdet_psi, double* nat_c,
+                         double* cc, double* bb, double* W, double* E2, double* E4) {
+  return guarded_host([&]() -> int {
+  if (K < 1 || D < 1 || !a || !b || !c || !d || !mus || !psis || !nus || !half_logdet_psi || !nat_c || !cc ||
+      !bb || !W || !E2 || !E4)
+    return MIMO_E_INVALID;
+  const size_t DD = (size_t)D * D;
+  std::vector<double> P(DD, 0.0), psi(DD), Pinv(DD), scratch(3 * DD);
+  std::vector<v4d> work(2 * DD);
+  double nu = 0.0;
+  for (int k = 0; k < K; ++k) {                      // the pooled block, summed over k in order (np.mean, axis 0)
+    const double kap = b[k];
+    double* m = mus + (size_t)k * D;
+    for (int i = 0; i < D; ++i) m[i] = a[(size_t)k * D + i] / kap;
+    const double* ck = c + (size_t)k * DD;
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) P[i * D + j] += ck[i * D + j] - kap * (m[i] * m[j]);
+    nu += d[k] + D;
+  }
+  for (size_t i = 0; i < DD; ++i) P[i] /= K;
+  nu /= K;
+  double sl[4];
+  {                                                   // psi = P^-1, then psi^-1 as std_to_nat reads it back
+    double* spare[3] = {scratch.data(), scratch.data() + DD, scratch.data() + 2 * DD};   // the three idle lanes
+    const double* Ain[4] = {P.data(), P.data(), P.data(), P.data()};
+    double* Aout[4] = {psi.data(), spare[0], spare[1], spare[2]};
+    spd_inverse4(Ain, D, Aout, sl, work.data());
+    if (std::isnan(sl[0])) return MIMO_E_INVALID;
+    const double hld = -sl[0];
+    const double* Bin[4] = {psi.data(), psi.data(), psi.data(), psi.data()};
+    double* Bout[4] = {Pinv.data(), spare[0], spare[1], spare[2]};
+    spd_inverse4(Bin, D, Bout, sl, work.data());
+    if (std::isnan(sl[0])) return MIMO_E_INVALID;
+    const double e4 = 0.5 * expected_logdet(nu, D, hld);
+    for (int k = 0; k < K; ++k) {
+      const double kap = b[k];
+      const double* m = mus + (size_t)k * D;
+      double* Wk = W + (size_t)k * DD;
+      double* bk = bb + (size_t)k * D;
+      double* nk = nat_c + (size_t)k * DD;
+      std::copy(psi.begin(), psi.end(), psis + (size_t)k * DD);
+      nus[k] = nu;
+      half_logdet_psi[k] = hld;
+      for (size_t i = 0; i < DD; ++i) Wk[i] = nu * psi[i];
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) nk[i * D + j] = Pinv[i * D + j] + kap * (m[i] * m[j]);
+      double mWm = 0.0;
+      for (int i = 0; i < D; ++i) {
+        const double s = dot(Wk + (size_t)i * D, m, D);
+        bk[i] = s;
+        mWm += m[i] * s;
+      }
+      E2[k] = -0.5 * (D / kap + mWm);
+      E4[k] = e4;
+      cc[k] = -0.5 * D * kLog2Pi + E2[k] + E4[k];
+    }
+  }
+  return MIMO_OK;
+  });
+}
+
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {

@@ -456,6 +456,38 @@ class TiedNormalWisharts(_TiedNatParam, StackedNormalWisharts):
         nu = np.mean(d + self.dim)
         return mus, b, np.array(self.size * [psi]), np.array(self.size * [nu])
 
+    @property
+    def nat_param(self):
+        return self._cached('nat', lambda: self.std_to_nat(self.params))
+
+    @nat_param.setter
+    def nat_param(self, natparam):
+        if not self._assign_native_tied(natparam):
+            self.params = self.nat_to_std(natparam)
+
+    def _assign_native_tied(self, natparam):
+        """mimo_host_nw_vi_tied: the pooled standard parameters, the natural parameters they read back as, and every
+        derived quantity of the sweep in one call."""
+        lib = _native()
+        if lib is None or type(self).nat_to_std is not TiedNormalWisharts.nat_to_std:
+            return False
+        a, b, c, d = (_c64(v) for v in natparam)
+        K, D = self.size, self.dim
+        if a.shape != (K, D) or b.shape != (K,) or c.shape != (K, D, D) or d.shape != (K,):
+            return False
+        mus, psis, nus, hld, nat_c = np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty(K), np.empty((K, D, D))
+        cc, bb, W, E2, E4 = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty(K)
+        if lib.mimo_host_nw_vi_tied(K, D, _p(a), _p(b), _p(c), _p(d), _p(mus), _p(psis), _p(nus), _p(hld), _p(nat_c),
+                                    _p(cc), _p(bb), _p(W), _p(E2), _p(E4)) != 0:
+            return False
+        kap = b.copy()
+        self.params = (mus, kap, psis, nus)
+        self._cached('nat', lambda: Stats([kap[:, None] * mus, kap, nat_c, nus - D]))
+        self._cached('hld', lambda: hld)
+        self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
+        self._cached('canon', lambda: (cc, bb, W))
+        return True
+
 
 class TiedMatrixNormalWisharts(_TiedNatParam, StackedMatrixNormalWisharts):
     """composite.py:798-808."""

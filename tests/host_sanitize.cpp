@@ -23,6 +23,12 @@ int main() {
     int rc = mimo_host_nw_vi(K, D, a.data(), b.data(), c.data(), d.data(), mus.data(), psis.data(), nus.data(), hld.data(),
                              cc.data(), bb.data(), W.data(), E2.data(), E4.data());
     if (rc != 0 || !std::isfinite(cc[K - 1])) { printf("nw K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    {   // the tied flavour on the same natural parameters (its pooled block is an average of SPD blocks)
+      std::vector<double> natc((size_t)K * D * D), tp((size_t)K * D * D), tm(K * D), tn(K), th(K);
+      rc = mimo_host_nw_vi_tied(K, D, a.data(), b.data(), c.data(), d.data(), tm.data(), tp.data(), tn.data(), th.data(),
+                                natc.data(), cc.data(), bb.data(), W.data(), E2.data(), E4.data());
+      if (rc != 0 || !std::isfinite(cc[K - 1])) { printf("tied nw K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    }
     {   // Gibbs draw from the posterior just computed (psis is SPD here)
       const int nt = D * (D - 1) / 2;
       std::vector<double> z((size_t)K * nt + 1), gg(K * D), ee(K * D), omu(K * D), olam((size_t)K * D * D), oc(K), ob(K * D);

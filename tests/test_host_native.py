@@ -58,6 +58,33 @@ def test_normal_wishart_native_equals_numpy(K, D):
         assert np.array_equal(a, b)                                    # the assigned block is kept exactly
 
 
+@pytest.mark.parametrize("K,D", [(1, 1), (3, 2), (64, 16), (130, 32), (7, 33)])
+def test_tied_normal_wishart_native_equals_numpy(K, D):
+    """mimo_host_nw_vi_tied: the pooled Wishart block (composite.py:273-283) and the natural parameters the tied
+    class reads back (composite.py:166-172), against the NumPy route."""
+    from mimo_amd.distributions import TiedNormalWisharts
+    rng = np.random.default_rng(K * 100 + D + 7)
+    A = rng.standard_normal((K, D, D))
+    kappas = rng.uniform(0.5, 200., K)
+    mus = rng.standard_normal((K, D))
+    nat = [kappas[:, None] * mus, kappas, A @ A.transpose(0, 2, 1) + D * np.eye(D)
+           + kappas[:, None, None] * np.einsum('kd,kl->kdl', mus, mus), rng.uniform(1., 5000., K)]
+    nat_p, np_p = _both(lambda: TiedNormalWisharts(K, D), nat)
+    assert 'canon' in nat_p._memo and 'nat' in nat_p._memo and 'canon' not in np_p._memo
+    assert np.array_equal(nat_p.psis[0], nat_p.psis[-1]) and np.array_equal(nat_p.nus[0], nat_p.nus[-1])
+    for a, b in zip(nat_p.params, np_p.params):
+        assert rel_err(a, b) < 1e-12
+    for a, b in zip(nat_p.nat_param, np_p.nat_param):                  # the pooled block read back, not the assigned one
+        assert rel_err(a, b) < 1e-12
+    assert rel_err(nat_p.nat_param[2], nat[2]) > 1e-3 or K == 1
+    for a, b in zip(nat_p.canonical_expected(), np_p.canonical_expected()):
+        assert rel_err(a, b) < 1e-12
+    for a, b in zip(nat_p.expected_statistics(), np_p.expected_statistics()):
+        assert rel_err(a, b) < 1e-12
+    assert rel_err(nat_p.log_partition(), np_p.log_partition()) < 1e-12
+    assert rel_err(nat_p.entropy(), np_p.entropy()) < 1e-9
+
+
 @pytest.mark.parametrize("K,dy,dc", [(1, 1, 2), (6, 2, 4), (64, 4, 9), (33, 8, 17), (9, 3, 33)])
 def test_matrix_normal_wishart_native_equals_numpy(K, dy, dc):
     rng = np.random.default_rng(K + 10 * dy + 100 * dc)
