@@ -314,6 +314,15 @@ int mimo_host_nw_vi_tied(int K, int D, const double* a, const double* b, const d
                          double* mus, double* psis, double* nus, double* half_logdet_psi, double* nat_c,
                          double* cc, double* bb, double* W, double* E2, double* E4);
 
+/* The Normal-Wishart blocks' term of the variational lower bound, entropy(q_k) - cross_entropy(q_k, p_k) per k
+ * (bayesian.py:258-265 with composite.py:95-98,120-128 and wishart.py:129-132), from the quantities the two calls
+ * above return: (qa..qd) the posterior's natural parameters, (pa..pd) the prior's, prior_logZ (K) the prior's
+ * log-partition, nus / half_logdet_psi / E1 = bb / E2 / W / E4 of the posterior.  out (K). */
+int mimo_host_nw_vlb(int K, int D, const double* qa, const double* qb, const double* qc, const double* qd,
+                     const double* pa, const double* pb, const double* pc, const double* pd, const double* prior_logZ,
+                     const double* nus, const double* half_logdet_psi, const double* E1, const double* E2,
+                     const double* W, const double* E4, double* out);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mimo_random_resp_stats": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     "mimo_host_nw_vi": (C.c_int, [C.c_int, C.c_int] + [_vp] * 13),
     "mimo_host_nw_vi_tied": (C.c_int, [C.c_int, C.c_int] + [_vp] * 14),
+    "mimo_host_nw_vlb": (C.c_int, [C.c_int, C.c_int] + [_vp] * 16),
     "mimo_host_mnw_vi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_vp] * 15),
     "mimo_host_nw_gibbs": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "mimo_host_digamma": (C.c_double, [C.c_double]),

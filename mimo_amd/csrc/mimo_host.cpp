@@ -284,6 +284,32 @@ int mimo_host_nw_vi_tied(int K, int D, const double* a, const double* b, const d
   });
 }
 
+int mimo_host_nw_vlb(int K, int D, const double* qa, const double* qb, const double* qc, const double* qd,
+                     const double* pa, const double* pb, const double* pc, const double* pd, const double* prior_logZ,
+                     const double* nus, const double* half_logdet_psi, const double* E1, const double* E2,
+                     const double* W, const double* E4, double* out) {
+  return guarded_host([&]() -> int {
+  if (K < 1 || D < 1 || !qa || !qb || !qc || !qd || !pa || !pb || !pc || !pd || !prior_logZ || !nus ||
+      !half_logdet_psi || !E1 || !E2 || !W || !E4 || !out)
+    return MIMO_E_INVALID;
+  const size_t DD = (size_t)D * D;
+  const double log_base = -0.5 * D * kLog2Pi;
+  for (int k = 0; k < K; ++k) {
+    const double nu = nus[k];
+    double mg = 0.25 * D * (D - 1) * std::log(M_PI);          // ln Gamma_D(nu / 2)
+    for (int j = 0; j < D; ++j) { int sign; mg += lgamma_r(0.5 * nu - 0.5 * j, &sign); }
+    const double logZq = -0.5 * D * std::log(qb[k]) + (0.5 * nu * D * kLog2 + mg + nu * half_logdet_psi[k]);
+    const double* e1 = E1 + (size_t)k * D;
+    const double* w = W + (size_t)k * DD;
+    // <eta, E[t]> with E3 = -W/2 (composite.py:120-128), for the posterior's and the prior's eta
+    const double iq = dot(qa + (size_t)k * D, e1, D) + qb[k] * E2[k] - 0.5 * dot(qc + (size_t)k * DD, w, (int)DD) + qd[k] * E4[k];
+    const double ip = dot(pa + (size_t)k * D, e1, D) + pb[k] * E2[k] - 0.5 * dot(pc + (size_t)k * DD, w, (int)DD) + pd[k] * E4[k];
+    out[k] = (logZq - log_base - iq) - (prior_logZ[k] - log_base - ip);
+  }
+  return MIMO_OK;
+  });
+}
+
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {

@@ -46,6 +46,9 @@ class _CategoricalWrapper:
             else self.likelihood.weighted_statistics(data, weights)
 
     def variational_lowerbound(self):
+        fused = getattr(self.posterior, 'entropy_minus_cross_entropy', None)
+        if fused is not None:
+            return fused(self.prior)
         return self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
 
     def refresh_likelihood(self):
@@ -134,7 +137,9 @@ class _ConjugateBlock:
             + step_size * (self.prior.nat_param + 1. / scale * stats)
 
     def variational_lowerbound(self):
-        return self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
+        native = getattr(self.posterior, 'native_vlb', None)
+        v = native(self.prior) if native is not None else None
+        return v if v is not None else self.posterior.entropy() - self.posterior.cross_entropy(self.prior)
 
     def log_marginal_likelihood(self):
         return self.posterior.log_partition() - self.prior.log_partition()

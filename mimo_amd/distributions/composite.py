@@ -121,7 +121,28 @@ class StackedNormalWisharts:
         self._cached('hld', lambda: hld)
         self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
         self._cached('canon', lambda: (cc, bb, W))
+        self._cached('native', lambda: True)
         return True
+
+    def native_vlb(self, prior):
+        """entropy() - cross_entropy(prior) per block through mimo_host_nw_vlb, when this posterior was assigned by the
+        native sweep (its natural parameters, expectations and half log-determinants are then at hand); None otherwise."""
+        memo = self.__dict__.get('_memo') or {}
+        if memo.get('key') != tuple(map(id, self.params)) or not memo.get('native'):   # (native: contiguous float64 blocks)
+            return None
+        lib = _native()
+        if lib is None or not isinstance(prior, StackedNormalWisharts) or (prior.size, prior.dim) != (self.size, self.dim):
+            return None
+        q = [_c64(v) for v in memo['nat']]
+        pn = prior._cached('nat_c64', lambda: tuple(_c64(v) for v in prior.nat_param))
+        plz = prior._cached('logZ_c64', lambda: _c64(prior.log_partition()))
+        E1, E2, _, E4 = memo['estats']
+        out = np.empty(self.size)
+        if lib.mimo_host_nw_vlb(self.size, self.dim, _p(q[0]), _p(q[1]), _p(q[2]), _p(q[3]), _p(pn[0]), _p(pn[1]),
+                                _p(pn[2]), _p(pn[3]), _p(plz), _p(self.nus), _p(memo['hld']), _p(E1), _p(E2),
+                                _p(memo['canon'][2]), _p(E4), _p(out)) != 0:
+            return None
+        return out
 
     def std_to_nat(self, params):
         """eta = [kappa m, kappa, psi^-1 + kappa m m', nu - D]  (composite.py:50-65)."""
@@ -486,6 +507,7 @@ class TiedNormalWisharts(_TiedNatParam, StackedNormalWisharts):
         self._cached('hld', lambda: hld)
         self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
         self._cached('canon', lambda: (cc, bb, W))
+        self._cached('native', lambda: True)
         return True
 
 

@@ -123,19 +123,25 @@ class Dirichlet:
         return np.log(self.base)
 
     def log_partition(self):
-        return np.sum(gammaln(self.alphas)) - gammaln(np.sum(self.alphas))
+        return np.add.reduce(gammaln(self.alphas)) - gammaln(np.add.reduce(self.alphas))
 
     def log_likelihood(self, x):
         return - self.log_partition() + self.log_base() + np.sum((self.alphas - 1.) * np.log(x))
 
     def expected_statistics(self):
-        return digamma(self.alphas) - digamma(np.sum(self.alphas))
+        return digamma(self.alphas) - digamma(np.add.reduce(self.alphas))
 
     def entropy(self):
         return self.log_partition() - self.log_base() - self.nat_param.dot(self.expected_statistics())
 
     def cross_entropy(self, dist):
         return dist.log_partition() - dist.log_base() - dist.nat_param.dot(self.expected_statistics())
+
+    def entropy_minus_cross_entropy(self, dist):
+        """entropy() - cross_entropy(dist), the expected statistics computed once (same terms, same order)."""
+        E = self.expected_statistics()
+        return (self.log_partition() - self.log_base() - self.nat_param.dot(E))\
+            - (dist.log_partition() - dist.log_base() - dist.nat_param.dot(E))
 
 
 class TruncatedStickBreaking:

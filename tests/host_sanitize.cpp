@@ -23,6 +23,12 @@ int main() {
     int rc = mimo_host_nw_vi(K, D, a.data(), b.data(), c.data(), d.data(), mus.data(), psis.data(), nus.data(), hld.data(),
                              cc.data(), bb.data(), W.data(), E2.data(), E4.data());
     if (rc != 0 || !std::isfinite(cc[K - 1])) { printf("nw K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    {   // the bound's term from the outputs above (prior := the same block; its log-partition value is arbitrary here)
+      std::vector<double> out(K);
+      rc = mimo_host_nw_vlb(K, D, a.data(), b.data(), c.data(), d.data(), a.data(), b.data(), c.data(), d.data(), E4.data(),
+                            nus.data(), hld.data(), bb.data(), E2.data(), W.data(), E4.data(), out.data());
+      if (rc != 0 || !std::isfinite(out[K - 1])) { printf("nw vlb K=%d D=%d rc=%d\n", K, D, rc); return 1; }
+    }
     {   // the tied flavour on the same natural parameters (its pooled block is an average of SPD blocks)
       std::vector<double> natc((size_t)K * D * D), tp((size_t)K * D * D), tm(K * D), tn(K), th(K);
       rc = mimo_host_nw_vi_tied(K, D, a.data(), b.data(), c.data(), d.data(), tm.data(), tp.data(), tn.data(), th.data(),

@@ -56,6 +56,11 @@ def test_normal_wishart_native_equals_numpy(K, D):
     assert rel_err(nat_p.entropy(), np_p.entropy()) < 1e-9
     for a, b in zip(nat_p.nat_param, nat):
         assert np.array_equal(a, b)                                    # the assigned block is kept exactly
+    prior = _random_nw(K, D, seed=K + D)                              # the bound's term: one native call
+    v = nat_p.native_vlb(prior)
+    assert v is not None and np_p.native_vlb(prior) is None
+    want = np_p.entropy() - np_p.cross_entropy(prior)
+    assert np.max(np.abs(v - want)) < 1e-9 * max(1., np.max(np.abs(np_p.entropy())), np.max(np.abs(np_p.cross_entropy(prior))))
 
 
 @pytest.mark.parametrize("K,D", [(1, 1), (3, 2), (64, 16), (130, 32), (7, 33)])
@@ -83,6 +88,10 @@ def test_tied_normal_wishart_native_equals_numpy(K, D):
         assert rel_err(a, b) < 1e-12
     assert rel_err(nat_p.log_partition(), np_p.log_partition()) < 1e-12
     assert rel_err(nat_p.entropy(), np_p.entropy()) < 1e-9
+    prior = _random_nw(K, D, seed=K + D)
+    v, want = nat_p.native_vlb(prior), np_p.entropy() - np_p.cross_entropy(prior)
+    assert v is not None
+    assert np.max(np.abs(v - want)) < 1e-9 * max(1., np.max(np.abs(np_p.entropy())), np.max(np.abs(np_p.cross_entropy(prior))))
 
 
 @pytest.mark.parametrize("K,dy,dc", [(1, 1, 2), (6, 2, 4), (64, 4, 9), (33, 8, 17), (9, 3, 33)])
