@@ -323,6 +323,30 @@ int mimo_host_nw_vlb(int K, int D, const double* qa, const double* qb, const dou
                      const double* nus, const double* half_logdet_psi, const double* E1, const double* E2,
                      const double* W, const double* E4, double* out);
 
+/* One mean-field sweep's host algebra for a mixture of Gaussians with Normal-Wishart blocks (tied != 0: one shared
+ * Wishart factor) and Dirichlet gating, i.e. what BayesianMixtureOfGaussians.meanfield_coordinate_descent runs between two
+ * data passes (gmm.py:275-285) in TWO calls: _sweep before the next pass is launched (meanfield_update of components and
+ * gating, bayesian.py:78-83,225-230; the expected log-densities, gmm.py:244-254), _bound while it runs (the bound's prior
+ * terms, bayesian.py:93-96,258-265; dirichlet.py:78-97).
+ *   _sweep in : alpha0 (K) prior concentrations, counts (K) = sum_n r_kn; (pa..pd) the components' prior natural
+ *               parameters; (sx, sn, sxx) = the statistics block of the last pass (K,D) (K) (K,D,D)
+ *   _sweep out: alpha (K) posterior concentrations; (qa..qd) the posterior natural parameters as assigned; the outputs of
+ *               mimo_host_nw_vi / _tied (nat_c may be NULL when tied == 0); e_log_pi (K) = E[log pi_k];
+ *               c_total (K) = cc + e_log_pi: (c_total, bb, W) is what the next mimo_estep takes
+ *   _bound    : the same arrays back, prior_logZ (K) the components' prior log-partition;
+ *               vlb[0] = gating term, vlb[1] = sum over k of the component terms. */
+int mimo_host_gmm_vi_sweep(int K, int D, int tied, const double* alpha0, const double* counts,
+                           const double* pa, const double* pb, const double* pc, const double* pd,
+                           const double* sx, const double* sn, const double* sxx,
+                           double* alpha, double* qa, double* qb, double* qc, double* qd,
+                           double* mus, double* psis, double* nus, double* half_logdet_psi, double* nat_c,
+                           double* cc, double* bb, double* W, double* E2, double* E4, double* e_log_pi, double* c_total);
+int mimo_host_gmm_vi_bound(int K, int D, int tied, const double* alpha0, const double* alpha, const double* e_log_pi,
+                           const double* pa, const double* pb, const double* pc, const double* pd, const double* prior_logZ,
+                           const double* qa, const double* qb, const double* qc, const double* qd,
+                           const double* mus, const double* nus, const double* half_logdet_psi, const double* nat_c,
+                           const double* bb, const double* E2, const double* W, const double* E4, double* vlb);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

@@ -310,6 +310,74 @@ int mimo_host_nw_vlb(int K, int D, const double* qa, const double* qb, const dou
   });
 }
 
+int mimo_host_gmm_vi_sweep(int K, int D, int tied, const double* alpha0, const double* counts,
+                           const double* pa, const double* pb, const double* pc, const double* pd,
+                           const double* sx, const double* sn, const double* sxx,
+                           double* alpha, double* qa, double* qb, double* qc, double* qd,
+                           double* mus, double* psis, double* nus, double* half_logdet_psi, double* nat_c,
+                           double* cc, double* bb, double* W, double* E2, double* E4, double* e_log_pi, double* c_total) {
+  return guarded_host([&]() -> int {
+  if (K < 1 || D < 1 || !alpha0 || !counts || !pa || !pb || !pc || !pd || !sx || !sn || !sxx || !alpha || !qa || !qb ||
+      !qc || !qd || !mus || !psis || !nus || !half_logdet_psi || (tied && !nat_c) || !cc || !bb || !W || !E2 || !E4 ||
+      !e_log_pi || !c_total)
+    return MIMO_E_INVALID;
+  const size_t DD = (size_t)D * D;
+  for (size_t i = 0; i < (size_t)K * D; ++i) qa[i] = pa[i] + sx[i];           // eta_post = eta_prior + statistics
+  for (int k = 0; k < K; ++k) { qb[k] = pb[k] + sn[k]; qd[k] = pd[k] + sn[k]; }
+  for (size_t i = 0; i < (size_t)K * DD; ++i) qc[i] = pc[i] + sxx[i];
+  const int rc = tied ? mimo_host_nw_vi_tied(K, D, qa, qb, qc, qd, mus, psis, nus, half_logdet_psi, nat_c, cc, bb, W, E2, E4)
+                      : mimo_host_nw_vi(K, D, qa, qb, qc, qd, mus, psis, nus, half_logdet_psi, cc, bb, W, E2, E4);
+  if (rc != MIMO_OK) return rc;
+  // Dirichlet gating (dirichlet.py:31-33,85-87; bayesian.py:78-83): alpha = ((alpha0 - 1) + counts) + 1
+  double s = 0.0;
+  for (int k = 0; k < K; ++k) { alpha[k] = ((alpha0[k] - 1.0) + counts[k]) + 1.0; s += alpha[k]; }
+  const double ds = digamma(s);
+  for (int k = 0; k < K; ++k) {
+    e_log_pi[k] = digamma(alpha[k]) - ds;
+    c_total[k] = cc[k] + e_log_pi[k];
+  }
+  return MIMO_OK;
+  });
+}
+
+int mimo_host_gmm_vi_bound(int K, int D, int tied, const double* alpha0, const double* alpha, const double* e_log_pi,
+                           const double* pa, const double* pb, const double* pc, const double* pd, const double* prior_logZ,
+                           const double* qa, const double* qb, const double* qc, const double* qd,
+                           const double* mus, const double* nus, const double* half_logdet_psi, const double* nat_c,
+                           const double* bb, const double* E2, const double* W, const double* E4, double* vlb) {
+  return guarded_host([&]() -> int {
+  if (K < 1 || D < 1 || !alpha0 || !alpha || !e_log_pi || !pa || !pb || !pc || !pd || !prior_logZ || !qa || !qb || !qc ||
+      !qd || !mus || !nus || !half_logdet_psi || (tied && !nat_c) || !bb || !E2 || !W || !E4 || !vlb)
+    return MIMO_E_INVALID;
+  std::vector<double> per_k(K), ta, td;
+  const double *va = qa, *vc = qc, *vd = qd;
+  if (tied) {                       // the tied block's natural parameters are read back from the pooled standard ones
+    ta.resize((size_t)K * D); td.resize(K);
+    for (int k = 0; k < K; ++k) {
+      for (int i = 0; i < D; ++i) ta[(size_t)k * D + i] = qb[k] * mus[(size_t)k * D + i];
+      td[k] = nus[k] - D;
+    }
+    va = ta.data(); vc = nat_c; vd = td.data();
+  }
+  const int rc = mimo_host_nw_vlb(K, D, va, qb, vc, vd, pa, pb, pc, pd, prior_logZ, nus, half_logdet_psi, bb, E2, W, E4,
+                                  per_k.data());
+  if (rc != MIMO_OK) return rc;
+  double comp = 0.0;
+  for (int k = 0; k < K; ++k) comp += per_k[k];
+  double s = 0.0, s0 = 0.0, lq = 0.0, lp = 0.0, iq = 0.0, ip = 0.0;       // dirichlet.py:78-79,89-97
+  int sign;
+  for (int k = 0; k < K; ++k) {
+    s += alpha[k]; s0 += alpha0[k];
+    lq += lgamma_r(alpha[k], &sign); lp += lgamma_r(alpha0[k], &sign);
+    iq += (alpha[k] - 1.0) * e_log_pi[k];
+    ip += (alpha0[k] - 1.0) * e_log_pi[k];
+  }
+  vlb[0] = ((lq - lgamma_r(s, &sign)) - iq) - ((lp - lgamma_r(s0, &sign)) - ip);
+  vlb[1] = comp;
+  return MIMO_OK;
+  });
+}
+
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {

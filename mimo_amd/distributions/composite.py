@@ -32,6 +32,7 @@ def _outer(a, b):
 # a block is not positive definite, so errors surface exactly as before).  MIMO_HOST_NATIVE=0
 # switches it off.
 # ---------------------------------------------------------------------------------------------
+import ctypes as _ctypes
 import os as _os
 
 NATIVE_HOST = _os.environ.get("MIMO_HOST_NATIVE", "1") != "0"
@@ -47,8 +48,13 @@ def _native():
         return None
 
 
-def _p(a):
-    return a.__array_interface__['data'][0]      # plain address: ctypes' data_as() costs ~7 us per array
+def _p(a, _from_buffer=_ctypes.c_char.from_buffer, _addressof=_ctypes.addressof):
+    """plain address of an array's first element: 0.4 us through the buffer protocol (ctypes' data_as() costs ~7 us per
+    array, __array_interface__ 1.2 us); read-only or empty arrays take the slower way."""
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError):
+        return a.__array_interface__['data'][0]
 
 
 def _c64(a):

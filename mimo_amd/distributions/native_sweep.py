@@ -1,0 +1,79 @@
+"""The host side of one mean-field sweep in two native calls (csrc/mimo_host.cpp): mimo_host_gmm_vi_sweep BEFORE the
+next data pass is launched — conjugate update of the K Normal-Wishart blocks and of the Dirichlet gating from the
+statistics of the last pass, the canonical form the next pass takes — and mimo_host_gmm_vi_bound WHILE it runs — the
+prior terms of the bound; what BayesianMixtureOfGaussians.meanfield_iteration otherwise assembles from ~40 NumPy calls
+(gmm.py:275-285, bayesian.py:78-83,225-230,258-265 of the reference).  The Python objects are left exactly as the step-by-step route
+leaves them (posterior parameters, cached expectations), so every other method keeps working on them."""
+import numpy as np
+
+from mimo_amd.distributions import composite
+from mimo_amd.distributions.composite import StackedNormalWisharts, TiedNormalWisharts, _c64, _p
+from mimo_amd.distributions.gating import Dirichlet
+from mimo_amd.utils.abstraction import Statistics as Stats
+
+
+def _prior_block(prior):
+    """contiguous natural parameters and log-partition of the (fixed) prior, kept with the prior's other derived values."""
+    return prior._cached('sweep_c64', lambda: tuple(_c64(v) for v in prior.nat_param) + (_c64(prior.log_partition()),))
+
+
+def gmm_vi_sweep(gating, components, stats, counts):
+    """-> ((c, b, W), prior_terms) with prior_terms() -> float to be called after the pass is launched, or None when the
+    models are not the ones the native calls cover.
+
+    gating: CategoricalWithDirichlet; components: Stacked/TiedGaussiansWithNormalWisharts whose prior / posterior are exactly
+    Stacked/TiedNormalWisharts; stats = Stats([sum r x, n, sum r xx', n]); counts = what the gating update consumes."""
+    from mimo_amd.distributions.bayesian import (CategoricalWithDirichlet, StackedGaussiansWithNormalWisharts,
+                                                 TiedGaussiansWithNormalWisharts)
+    lib = composite._native()
+    if lib is None or type(gating) is not CategoricalWithDirichlet\
+            or type(components) not in (StackedGaussiansWithNormalWisharts, TiedGaussiansWithNormalWisharts):
+        return None
+    prior, post = components.prior, components.posterior
+    if type(post) not in (StackedNormalWisharts, TiedNormalWisharts) or type(prior) is not type(post)\
+            or type(gating.prior) is not Dirichlet or type(gating.posterior) is not Dirichlet:
+        return None
+    tied = type(post) is TiedNormalWisharts
+    K, D = post.size, post.dim
+    sx, sn, sxx = _c64(stats[0]), _c64(stats[1]), _c64(stats[2])
+    alpha0, cnt = _c64(gating.prior.alphas), _c64(counts)
+    if sx.shape != (K, D) or sn.shape != (K,) or sxx.shape != (K, D, D) or alpha0.shape != (K,) or cnt.shape != (K,)\
+            or stats[3] is not stats[1]:
+        return None
+    pa, pb, pc, pd, plz = _prior_block(prior)
+    DD = D * D
+    # one block for every output: alpha K | qa KD | qb K | qc KDD | qd K | mus KD | psis KDD | nus K | hld K | nat_c KDD |
+    # cc K | bb KD | W KDD | E2 K | E4 K | E[log pi] K | c_total K | vlb 2
+    sizes = (K, K * D, K, K * DD, K, K * D, K * DD, K, K, K * DD if tied else 0, K, K * D, K * DD, K, K, K, K, 2)
+    blk = np.empty(sum(sizes))
+    base, views, ptrs, o = _p(blk), [], [], 0
+    for n in sizes:
+        views.append(blk[o:o + n])
+        ptrs.append(base + 8 * o if n else None)
+        o += n
+    if lib.mimo_host_gmm_vi_sweep(K, D, int(tied), _p(alpha0), _p(cnt), _p(pa), _p(pb), _p(pc), _p(pd),
+                                  _p(sx), _p(sn), _p(sxx), *ptrs[:17]) != 0:
+        return None            # (a block that is not positive definite: the NumPy route raises like the reference)
+    (alpha, qa, qb, qc, qd, mus, psis, nus, hld, nat_c, cc, bb, W, E2, E4, elp, c_total, vlb) = views
+    (p_alpha, p_qa, p_qb, p_qc, p_qd, p_mus, _, p_nus, p_hld, p_natc, _, p_bb, p_W, p_E2, p_E4, p_elp, _, p_vlb) = ptrs
+    qa, mus, bb = qa.reshape(K, D), mus.reshape(K, D), bb.reshape(K, D)
+    qc, psis, W = qc.reshape(K, D, D), psis.reshape(K, D, D), W.reshape(K, D, D)
+    gating.posterior.alphas = alpha
+    post.params = (mus, qb, psis, nus)
+    if tied:
+        post._cached('nat', lambda: Stats([qb[:, None] * mus, qb, nat_c.reshape(K, D, D), nus - D]))
+    else:
+        post._cached('nat', lambda: Stats([qa, qb, qc, qd]))
+    post._cached('hld', lambda: hld)
+    post._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
+    post._cached('canon', lambda: (cc, bb, W))
+    post._cached('native', lambda: True)
+
+    def prior_terms():
+        rc = lib.mimo_host_gmm_vi_bound(K, D, int(tied), _p(alpha0), p_alpha, p_elp, _p(pa), _p(pb), _p(pc), _p(pd), _p(plz),
+                                        p_qa, p_qb, p_qc, p_qd, p_mus, p_nus, p_hld, p_natc, p_bb, p_E2, p_W, p_E4, p_vlb)
+        if rc != 0:
+            raise RuntimeError("mimo_host_gmm_vi_bound failed (%d)" % rc)
+        return float(vlb[0] + vlb[1])       # (blk stays alive through the views captured here)
+
+    return (c_total, bb, W), prior_terms

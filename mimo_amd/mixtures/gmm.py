@@ -20,6 +20,7 @@ import numpy.random as npr
 from tqdm import tqdm
 
 from mimo_amd import engine as _engine
+from mimo_amd.distributions import native_sweep as _native_sweep
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
 
@@ -372,18 +373,24 @@ class BayesianMixtureOfGaussians:
         Bartlett draws, 2.6 ms at K = 64, D = 16.  The next E-step reads the posterior only, so the pass is launched
         first and the draws (same numpy.random call order: components, then gating) and the bound's prior terms run
         on the host while the kernel is in flight."""
-        self._update_from_stats(S, sample=False)
+        fused = _native_sweep.gmm_vi_sweep(self.gating, self.components, _component_stats(S, self.components),
+                                           S.gating_counts)
+        if fused is not None:           # update + canonical form in one native call, the bound's prior terms in a second
+            canon, bound = fused         # one, issued once the pass is in flight
+        else:
+            self._update_from_stats(S, sample=False)
+            canon = self.canonical_expected()
         if hasattr(eng, "estep_async"):
-            eng.estep_async(*self.canonical_expected())
+            eng.estep_async(*canon)
             if sample_likelihood:
                 self._refresh_likelihoods()
-            prior_terms = self._vlb_prior_terms()
+            prior_terms = self._vlb_prior_terms() if fused is None else bound()
             S, sc = eng.estep_wait()
         else:
-            S, sc = eng.estep(*self.canonical_expected())
+            S, sc = eng.estep(*canon)
             if sample_likelihood:
                 self._refresh_likelihoods()
-            prior_terms = self._vlb_prior_terms()
+            prior_terms = self._vlb_prior_terms() if fused is None else bound()
         return S, prior_terms + sc[0]
 
     def _refresh_likelihoods(self):

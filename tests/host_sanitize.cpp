@@ -29,6 +29,19 @@ int main() {
                             nus.data(), hld.data(), bb.data(), E2.data(), W.data(), E4.data(), out.data());
       if (rc != 0 || !std::isfinite(out[K - 1])) { printf("nw vlb K=%d D=%d rc=%d\n", K, D, rc); return 1; }
     }
+    for (int tied : {0, 1}) {   // the whole sweep in two calls (prior := the block above, statistics := the same block again)
+      const size_t DD = (size_t)D * D;
+      std::vector<double> al0(K, 1.5), cnt(K, 3.0), al(K), qa(K * D), qb(K), qc(K * DD), qd(K), m2(K * D), p2(K * DD), n2(K), h2(K),
+          natc(K * DD), c2(K), b2(K * D), W2(K * DD), e2(K), e4(K), elp(K), ct(K), plz(K, 0.25), vlb(2);
+      rc = mimo_host_gmm_vi_sweep(K, D, tied, al0.data(), cnt.data(), a.data(), b.data(), c.data(), d.data(), a.data(), b.data(),
+                                  c.data(), al.data(), qa.data(), qb.data(), qc.data(), qd.data(), m2.data(), p2.data(), n2.data(),
+                                  h2.data(), natc.data(), c2.data(), b2.data(), W2.data(), e2.data(), e4.data(), elp.data(), ct.data());
+      if (rc == 0)
+        rc = mimo_host_gmm_vi_bound(K, D, tied, al0.data(), al.data(), elp.data(), a.data(), b.data(), c.data(), d.data(), plz.data(),
+                                    qa.data(), qb.data(), qc.data(), qd.data(), m2.data(), n2.data(), h2.data(), natc.data(),
+                                    b2.data(), e2.data(), W2.data(), e4.data(), vlb.data());
+      if (rc != 0 || !std::isfinite(vlb[0] + vlb[1] + ct[K - 1])) { printf("sweep K=%d D=%d tied=%d rc=%d\n", K, D, tied, rc); return 1; }
+    }
     {   // the tied flavour on the same natural parameters (its pooled block is an average of SPD blocks)
       std::vector<double> natc((size_t)K * D * D), tp((size_t)K * D * D), tm(K * D), tn(K), th(K);
       rc = mimo_host_nw_vi_tied(K, D, a.data(), b.data(), c.data(), d.data(), tm.data(), tp.data(), tn.data(), th.data(),

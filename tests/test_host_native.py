@@ -357,3 +357,95 @@ def test_frozen_weights_are_fingerprinted_once_and_plain_arrays_on_every_call():
     _, k2 = E._weights_key(w)
     assert k2 != k1 and E._weights_key(fw)[1] == key        # the plain array is re-hashed, the frozen one is not
     assert np.allclose(2.0 * np.asarray(fw), 2.0 * w)
+
+
+def _gmm(K, D, tied, seed, gating='dirichlet'):
+    from oracle_engine import OracleEngine
+    from mimo_amd.distributions import (Dirichlet, CategoricalWithDirichlet, TruncatedStickBreaking,
+                                        CategoricalWithStickBreaking, StackedGaussiansWithNormalWisharts,
+                                        TiedNormalWisharts, TiedGaussiansWithNormalWisharts)
+    from mimo_amd.mixtures import BayesianMixtureOfGaussians
+    rs = np.random.default_rng(seed)
+    eng = OracleEngine()
+    eng.upload(rs.standard_normal((1500, D)) * 2. + rs.integers(0, 3, size=(1500, 1)))
+    np.random.seed(seed)
+    if gating == 'dirichlet':
+        gate = CategoricalWithDirichlet(K, Dirichlet(K, rs.uniform(0.5, 3., K)))
+    else:
+        gate = CategoricalWithStickBreaking(K, TruncatedStickBreaking(K, np.ones(K), 2. * np.ones(K)))
+    A = rs.standard_normal((D, D))
+    args = (K, D, rs.standard_normal((K, D)), rs.uniform(0.01, 2., K), np.stack(K * [A @ A.T / D + np.eye(D)]),
+            (D + 1.5) * np.ones(K))
+    if tied:
+        comp = TiedGaussiansWithNormalWisharts(K, D, TiedNormalWisharts(*args), engine=eng)
+    else:
+        comp = StackedGaussiansWithNormalWisharts(K, D, StackedNormalWisharts(*args), engine=eng)
+    S = eng.label_stats(rs.integers(0, K, size=1500), K)
+    return BayesianMixtureOfGaussians(gate, comp, engine=eng), eng, S
+
+
+@pytest.mark.parametrize("K,D,tied", [(1, 1, 0), (4, 2, 0), (64, 16, 0), (7, 33, 0), (4, 2, 1), (64, 16, 1), (5, 9, 1)])
+def test_fused_sweep_equals_the_step_by_step_route(K, D, tied):
+    """mimo_host_gmm_vi_sweep / _bound against meanfield_update + canonical_expected + variational_lowerbound of the
+    same objects on the NumPy route (which the golden vectors pin to the reference)."""
+    from mimo_amd.distributions import native_sweep
+    from mimo_amd.mixtures.gmm import _component_stats
+    m1, _, S = _gmm(K, D, tied, seed=K + D)
+    m2, _, _ = _gmm(K, D, tied, seed=K + D)
+    fused = native_sweep.gmm_vi_sweep(m1.gating, m1.components, _component_stats(S, m1.components), S.gating_counts)
+    assert fused is not None
+    canon, bound = fused
+    old = composite.NATIVE_HOST
+    composite.NATIVE_HOST = False
+    try:
+        m2._update_from_stats(S, sample=False)
+        want_canon, want_terms = m2.canonical_expected(), m2._vlb_prior_terms()
+        ent = np.abs(m2.components.posterior.entropy()).sum() + np.abs(m2.components.posterior.cross_entropy(m2.components.prior)).sum()
+    finally:
+        composite.NATIVE_HOST = old
+    for a, b in zip(canon, want_canon):
+        assert rel_err(a, b) < 1e-12
+    assert abs(bound() - want_terms) < 1e-10 * max(1., ent)
+    for a, b in zip(m1.components.posterior.params, m2.components.posterior.params):
+        assert rel_err(a, b) < 1e-12
+    assert np.array_equal(m1.gating.posterior.alphas, m2.gating.posterior.alphas)
+    # the objects are left as the step-by-step route leaves them: every derived quantity answers from them
+    for a, b in zip(m1.components.posterior.nat_param, m2.components.posterior.nat_param):
+        assert rel_err(a, b) < 1e-12
+    for a, b in zip(m1.canonical_expected(), want_canon):
+        assert rel_err(a, b) < 1e-12
+    assert abs(m1._vlb_prior_terms() - want_terms) < 1e-10 * max(1., ent)
+
+
+def test_fused_sweep_declines_what_it_does_not_cover():
+    from mimo_amd.distributions import native_sweep
+    from mimo_amd.mixtures.gmm import _component_stats
+    m, _, S = _gmm(4, 2, 0, seed=3, gating='stick')
+    assert native_sweep.gmm_vi_sweep(m.gating, m.components, _component_stats(S, m.components), S.gating_counts) is None
+    m, _, S = _gmm(4, 2, 0, seed=3)
+    bad = _component_stats(S, m.components)
+    bad = Stats([bad[0], bad[1], -1e6 * np.abs(bad[2]), bad[3]])            # no longer positive definite
+    assert native_sweep.gmm_vi_sweep(m.gating, m.components, bad, S.gating_counts) is None
+    old = composite.NATIVE_HOST
+    composite.NATIVE_HOST = False
+    try:
+        assert native_sweep.gmm_vi_sweep(m.gating, m.components, _component_stats(S, m.components), S.gating_counts) is None
+    finally:
+        composite.NATIVE_HOST = old
+
+
+def test_the_driver_runs_the_fused_sweep(monkeypatch):
+    """meanfield_coordinate_descent goes through the two native calls per iteration (and gets the same bound as without)."""
+    from mimo_amd.distributions import native_sweep
+    calls = []
+    real = native_sweep.gmm_vi_sweep
+    monkeypatch.setattr(native_sweep, "gmm_vi_sweep", lambda *a: calls.append(1) or real(*a))
+    m1, eng, _ = _gmm(6, 3, 0, seed=11)
+    np.random.seed(5)
+    v1 = m1.meanfield_coordinate_descent(eng.Z, maxiter=6, progress_bar=False)
+    assert len(calls) == len(v1) == 6
+    monkeypatch.setattr(native_sweep, "gmm_vi_sweep", lambda *a: None)
+    m2, eng2, _ = _gmm(6, 3, 0, seed=11)
+    np.random.seed(5)
+    v2 = m2.meanfield_coordinate_descent(eng2.Z, maxiter=6, progress_bar=False)
+    assert np.allclose(v1, v2, rtol=1e-11, atol=0)
