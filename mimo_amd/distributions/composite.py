@@ -53,7 +53,7 @@ def _p(a, _from_buffer=_ctypes.c_char.from_buffer, _addressof=_ctypes.addressof)
     array, __array_interface__ 1.2 us); read-only or empty arrays take the slower way."""
     try:
         return _addressof(_from_buffer(a))
-    except (TypeError, ValueError):
+    except (TypeError, ValueError, BufferError):
         return a.__array_interface__['data'][0]
 
 
@@ -594,13 +594,14 @@ class StackedNormalGammas:
         if rng is not None:
             lmbdas = rng.gamma(self.alphas, 1. / self.betas)
             return self.mus + rng.standard_normal(self.mus.shape) / np.sqrt(self.kappas * lmbdas), lmbdas
-        mus, lmbdas = [], []
+        # the generator is called per block as the reference calls it (D gammas, then D normals); the algebra after the loop is
+        # the same arithmetic for all K at once: z.dot(diag(s).T) adds exact zeros to z_i s_i
+        lmbdas, zs = np.empty_like(self.mus), np.empty_like(self.mus)
+        scales = 1. / self.betas
         for k in range(self.size):
-            lmbda = npr.gamma(self.alphas[k], 1. / self.betas[k])
-            chol_inv = np.diag(1. / np.sqrt(self.kappas[k] * lmbda))
-            mus.append(self.mus[k] + npr.normal(size=self.dim).dot(chol_inv.T))
-            lmbdas.append(lmbda)
-        return np.stack(mus, axis=0), np.stack(lmbdas, axis=0)
+            lmbdas[k] = npr.gamma(self.alphas[k], scales[k])
+            zs[k] = npr.normal(size=self.dim)
+        return self.mus + zs * (1. / np.sqrt(self.kappas * lmbdas)), lmbdas
 
     @property
     def base(self):

@@ -47,8 +47,13 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def _ptr(a):
-    return a.ctypes.data_as(C.c_void_p)
+def _ptr(a, _from_buffer=C.c_char.from_buffer, _addressof=C.addressof):
+    """address of the array's first element for a void* argument: through the buffer protocol (0.4 us; data_as() costs 7 us,
+    five to eight of them per call of the hot path); read-only or empty arrays take ctypes' route."""
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError, BufferError):
+        return a.ctypes.data_as(C.c_void_p)
 
 
 class _HostSum:
