@@ -246,3 +246,24 @@ def test_rows_with_nan_in_a_linear_gaussian_mixture():
     """the reference's element-wise NaN rules of the experts' density (lingauss.py:150-151, ilr.py:71-75), host classes over the
     oracle-backed engine double against outputs of the reference"""
     mc.check_nan_rows_ilr("nan_rows_ilr_dx2_dy1_k6", OracleEngine())
+
+
+@pytest.mark.parametrize("n,k", [(4_000_000, 4096), (10_000_000, 128), (5000, 4096), (4097, 4096), (1 << 31, 1000),
+                                 (100000, 99990), (1000, 70), (300, 64), (20000, 4096), ((1 << 32) - 1, 5000),
+                                 (1 << 32, 5000), (50, 10), (4_000_000, 5)])
+def test_sample_indices_is_random_sample(n, k):
+    """utils.data.sample_indices (the minibatch draw of the SVI drivers, data.py:9-12 of the reference) returns what
+    random.sample(range(n), k) returns and leaves Python's generator in the same state — on the NumPy block route and on
+    the fallbacks alike."""
+    import random
+    from mimo_amd.utils.data import sample_indices
+    for seed in (0, 1, 12345):
+        random.seed(seed)
+        random.gauss(0., 1.)                            # (a pending gauss_next value must survive the state round trip)
+        want = [random.sample(range(n), k) for _ in range(3)]
+        state, nxt = random.getstate(), (random.gauss(0., 1.), random.random())
+        random.seed(seed)
+        random.gauss(0., 1.)
+        got = [sample_indices(n, k) for _ in range(3)]
+        assert got == want and all(type(i) is int for i in got[0])
+        assert random.getstate() == state and (random.gauss(0., 1.), random.random()) == nxt
