@@ -82,7 +82,20 @@ FEd, FSd = 2 * (2 * D + 1) + 8, 2 * (2 * D + 1) + 1      # both products over th
 report("diagonal-precision GMM, mean-field VI (MIMO_STRUCT_DIAG: 2D+1 feature kernels; reference-shaped driver)", t,
        N * K, N * K * (FEd + FSd), "flops of the diagonal form: 2(2D+1)+8 and 2(2D+1)+1 per evaluation; the iteration "
        "includes ~1 ms of host posterior.rvs()")
-t = per_iter(lambda it: diag.resample(X, maxiter=it, progress_bar=False, label_rng='philox', seed=1))
+# the sweeps themselves (gibbs_iteration, what `resample` loops over): the driver's label initialisation draws N labels on the
+# host once per call (0.1 s at 4e6 rows) and its jitter is ten sweeps' worth — the per_iter difference swung 0.4 - 1.1 ms on it
+diag.resample(X, maxiter=2, progress_bar=False, label_rng='philox', seed=1, init_labels='posterior')
+_eng = diag._bind(X)
+_state = [_eng.label_stats(diag.labels_, K)]
+
+
+def _sweeps(n):
+    for it in range(n):
+        _state[0] = diag.gibbs_iteration(_eng, _state[0], it + 1, 'philox', 1)[1]
+
+
+_sweeps(5)
+t0 = time.perf_counter(); _sweeps(60); t = (time.perf_counter() - t0) / 60
 report("diagonal-precision GMM, Gibbs sweep (Philox labels)", t, N * K, N * K * FEd + N * FSd)
 
 hyper = NormalWishart(D, np.zeros(D), 1e-2, np.eye(D), D + 2.)
