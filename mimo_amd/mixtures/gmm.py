@@ -21,6 +21,7 @@ from tqdm import tqdm
 
 from mimo_amd import engine as _engine
 from mimo_amd.distributions import native_sweep as _native_sweep
+from mimo_amd.mixtures import _svi
 from mimo_amd.utils.abstraction import Statistics as Stats
 from mimo_amd.utils.data import batches
 
@@ -425,42 +426,24 @@ class BayesianMixtureOfGaussians:
         if self._batch_engine is None:
             self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
-        vlb = []
-        pipelined, pending = hasattr(eng, "estep_async") and not hasattr(eng, "inner"), None
         # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
         # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
         scale = eng.global_rows(batch_size) / float(eng.global_rows(len(obs)))
+
+        def upload(batch):
+            if hasattr(beng, 'set_structure'):
+                beng.set_structure(self._structure())
+            beng.upload(obs[batch, :])
+
+        def step(Sb):
+            self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb, self.components),
+                                          sample=sample_likelihood)
+            self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
+
         with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
                   disable=not progress_bar) as pbar:
-            for i in range(maxiter):
-                for batch in batches(batch_size, len(obs)):
-                    if hasattr(beng, 'set_structure'):
-                        beng.set_structure(self._structure())
-                    beng.upload(obs[batch, :])
-                    if i == 0 and randomize is True:
-                        resp = npr.rand(self.size, len(batch))
-                        resp /= np.sum(resp, axis=0)
-                        Sb = beng.weighted_stats(resp)
-                    else:
-                        Sb, _ = beng.estep(*self.canonical_expected())
-                    self.components.meanfield_sgd(None, None, scale, step_size, stats=_component_stats(Sb, self.components),
-                                                  sample=sample_likelihood)
-                    self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
-                # the full-data bound under the posterior of this iteration: launched now, collected after the NEXT iteration's
-                # minibatch step (a second context: the two do not touch each other's data), so the upload, the minibatch pass and
-                # the natural-gradient algebra hide under it; numpy.random / random are consumed in the same order as before
-                if pipelined:
-                    if pending is not None:
-                        vlb.append(pending + eng.estep_wait()[1][0])
-                    eng.estep_async(*self.canonical_expected(), stats=False)
-                    pending = self._vlb_prior_terms()
-                else:
-                    _, sc = eng.estep(*self.canonical_expected(), stats=False)
-                    vlb.append(self._vlb_prior_terms() + sc[0])
-                pbar.update(1)
-        if pending is not None:
-            vlb.append(pending + eng.estep_wait()[1][0])
-        return vlb
+            return _svi.run(eng, beng, len(obs), maxiter, batch_size, randomize, self.size, upload, self.canonical_expected,
+                            step, self._vlb_prior_terms, lambda: pbar.update(1))
 
     def meanfield_sgd_parameters(self, obs, resp, scale, step_size):
         eng = self._bind(obs)

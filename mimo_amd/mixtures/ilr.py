@@ -16,6 +16,7 @@ from scipy.special import logsumexp
 
 from mimo_amd.distributions.lingauss import split_joint_stats, joint_rows, canonical_rows, nan_row_sets
 from mimo_amd.mixtures.gmm import canonical_inner, random_start, LazyTable
+from mimo_amd.mixtures import _svi
 
 
 class Standardizer:
@@ -375,40 +376,20 @@ class BayesianMixtureOfLinearGaussians:
         if self._batch_engine is None:
             self._batch_engine = eng.spawn()      # same kind of engine (sharded stays sharded: see below)
         beng = self._batch_engine
-        vlb = []
-        pipelined, pending = hasattr(eng, "estep_async") and not hasattr(eng, "inner"), None
         # fraction of the data one minibatch covers.  Sharded: every rank draws `batch_size` of ITS rows and the
         # statistics are all-reduced, so the minibatch is the union over ranks and the data set is all shards
         scale = eng.global_rows(batch_size) / float(eng.global_rows(len(xx)))
+
+        def step(Sb):
+            bstats, mstats = self._block_stats(Sb)
+            self.basis.meanfield_sgd(None, None, scale, step_size, stats=bstats, sample=sample_likelihood)
+            self.models.meanfield_sgd(None, None, None, scale, step_size, stats=mstats, sample=sample_likelihood)
+            self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
+
         with tqdm(total=maxiter, desc=f'SVI #{procces_id + 1}', position=procces_id,
                   disable=not progress_bar) as pbar:
-            for i in range(maxiter):
-                for batch in batches(batch_size, len(xx)):
-                    beng.upload(zz[batch, :])
-                    if i == 0 and randomize is True:
-                        resp = npr.rand(self.size, len(batch))
-                        resp /= np.sum(resp, axis=0)
-                        Sb = beng.weighted_stats(resp)
-                    else:
-                        Sb, _ = beng.estep(*self.canonical_expected())
-                    bstats, mstats = self._block_stats(Sb)
-                    self.basis.meanfield_sgd(None, None, scale, step_size, stats=bstats, sample=sample_likelihood)
-                    self.models.meanfield_sgd(None, None, None, scale, step_size, stats=mstats,
-                                              sample=sample_likelihood)
-                    self.gating.meanfield_sgd(None, Sb.gating_counts, scale, step_size, sample=sample_likelihood)
-                # the full-data bound of this iteration runs under the next iteration's minibatch step (as in mixtures/gmm.py)
-                if pipelined:
-                    if pending is not None:
-                        vlb.append(pending + eng.estep_wait()[1][0])
-                    eng.estep_async(*self.canonical_expected(), stats=False)
-                    pending = self._vlb_prior_terms()
-                else:
-                    _, sc = eng.estep(*self.canonical_expected(), stats=False)
-                    vlb.append(self._vlb_prior_terms() + sc[0])
-                pbar.update(1)
-        if pending is not None:
-            vlb.append(pending + eng.estep_wait()[1][0])
-        return vlb
+            return _svi.run(eng, beng, len(xx), maxiter, batch_size, randomize, self.size, lambda batch: beng.upload(zz[batch, :]),
+                            self.canonical_expected, step, self._vlb_prior_terms, lambda: pbar.update(1))
 
     # ---- ELBO with explicit responsibilities (reference-shaped) -------------------------------------
     def variational_lowerbound_data(self, x, y, resp):

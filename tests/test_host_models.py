@@ -1,5 +1,6 @@
 """CPU: host logic of mimo_amd (canonical forms, conjugate updates, drivers) against the reference's
 golden vectors, with the oracle-backed engine double standing in for the GPU (tests/oracle_engine.py)."""
+import numpy as np
 import pytest
 
 from conftest import GMM_CASES, ILR_CASES, GIBBS_CASES
@@ -267,3 +268,30 @@ def test_sample_indices_is_random_sample(n, k):
         got = [sample_indices(n, k) for _ in range(3)]
         assert got == want and all(type(i) is int for i in got[0])
         assert random.getstate() == state and (random.gauss(0., 1.), random.random()) == nxt
+
+
+class DeferredOracleEngine(OracleEngine):
+    """OracleEngine with HipEngine's asynchronous pair, evaluated at estep_wait(): the drivers take their pipelined branches
+    (the fused pass launched before the host algebra that overlaps it; the SVI loop's reordered queue), and a result that is
+    read before it was waited for, or a pass launched with the wrong iteration's parameters, shows up against the goldens."""
+
+    def spawn(self):
+        return DeferredOracleEngine()
+
+    def estep_async(self, c, b, W, row_weights=None, stats=True):
+        assert getattr(self, "_pending", None) is None, "a second pass was launched on a context that has one in flight"
+        self._pending = (np.array(c), np.array(b), np.array(W), row_weights, stats)
+
+    def estep_wait(self):
+        c, b, W, w, stats = self._pending
+        self._pending = None
+        kw = {} if w is None else {"row_weights": w}
+        return self.estep(c, b, W, stats=stats, **kw)
+
+
+def test_pipelined_drivers_reproduce_the_reference_traces():
+    """The golden VI / SVI traces (generated by the reference) through the asynchronous branches of the drivers."""
+    mc.check_gmm_case("gmm_c1_d2_k4_dir", DeferredOracleEngine())
+    mc.check_driver_traces("drivers_d3_k5_dir", DeferredOracleEngine())
+    mc.check_ilr_svi("ilr_svi_dx2_dy1_k8", DeferredOracleEngine())
+    mc.check_tied_gmm("tied_gmm_d3_k5", DeferredOracleEngine())
