@@ -347,6 +347,16 @@ int mimo_host_gmm_vi_bound(int K, int D, int tied, const double* alpha0, const d
                            const double* mus, const double* nus, const double* half_logdet_psi, const double* nat_c,
                            const double* bb, const double* E2, const double* W, const double* E4, double* vlb);
 
+/* K blocks of variates from numpy.random's LEGACY stream (RandomState over MT19937), bit for bit what the reference's
+ * per-component calls consume and return: per block k, n_before x normal(), then standard_gamma(shapes[k][i]) for i < n_gamma
+ * (chisquare(df) = 2 standard_gamma(df / 2), gamma(a, scale) = scale standard_gamma(a): the caller scales), then n_after x
+ * normal().  Replaces the Python loops over k around wishart.py:72-92 (Bartlett factors), composite.py:82-86,347-351,612-617
+ * (the mean / matrix draw that follows) and gamma.py:53-55.  The generator state travels in and out:
+ * (mt_key[624], *mt_pos, *has_gauss, *gauss) = numpy.random.get_state()[1:], to be handed back with set_state. */
+int mimo_host_legacy_draws(uint32_t* mt_key, int* mt_pos, int* has_gauss, double* gauss, int K, int n_before,
+                           int n_gamma, int n_after, const double* shapes, double* before, double* gammas,
+                           double* after);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

@@ -9,6 +9,7 @@
 // :577-599,635-647 (Matrix-Normal-Wishart), wishart.py:139-143, bayesian.py:287-301,933-947.
 #include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -166,6 +167,117 @@ int for_component_groups(int K, int n, double work_per_component, F&& body) {
 }
 
 }  // namespace
+
+// ---- numpy.random's legacy stream (RandomState over MT19937), restated -----------------------------------------------
+// What numpy/random/src/mt19937/mt19937.c and src/legacy/legacy-distributions.c compute, so that the per-component draws the
+// reference makes (wishart.py:72-92: normal(n) then chisquare(nu - i) per i; gamma.py:53-55) can be taken K blocks at a time in
+// native code and still leave numpy.random's generator exactly where K x (2 + D) Python calls would have left it.  The value of
+// every variate depends on the order and rounding of a handful of float64 operations: no contraction to fused multiply-adds here
+// (numpy's baseline build has none), libm's log / sqrt / pow as numpy calls them.
+#if defined(__clang__)
+#define MIMO_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define MIMO_NO_CONTRACT
+#endif
+#if defined(__GNUC__) && !defined(__clang__)
+#define MIMO_NO_CONTRACT_FN __attribute__((optimize("fp-contract=off")))
+#else
+#define MIMO_NO_CONTRACT_FN
+#endif
+
+struct LegacyStream {
+  uint32_t* key;      // [624]
+  int pos;
+  int has_gauss;
+  double gauss;
+
+  void refill() {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
+    int kk = 0;
+    uint32_t y;
+    for (; kk < N - M; ++kk) {
+      y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+      key[kk] = key[kk + M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAG);
+    }
+    for (; kk < N - 1; ++kk) {
+      y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+      key[kk] = key[kk + (M - N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAG);
+    }
+    y = (key[N - 1] & UPPER) | (key[0] & LOWER);
+    key[N - 1] = key[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAG);
+    pos = 0;
+  }
+  uint32_t next32() {
+    if (pos == 624) refill();
+    uint32_t y = key[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  MIMO_NO_CONTRACT_FN double next_double() {
+    MIMO_NO_CONTRACT
+    const int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+  MIMO_NO_CONTRACT_FN double gauss_next() {            // legacy_gauss: polar method, the second variate kept for the next call
+    MIMO_NO_CONTRACT
+    if (has_gauss) {
+      const double t = gauss;
+      has_gauss = 0;
+      gauss = 0.0;
+      return t;
+    }
+    double f, x1, x2, r2;
+    do {
+      x1 = 2.0 * next_double() - 1.0;
+      x2 = 2.0 * next_double() - 1.0;
+      r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = std::sqrt(-2.0 * std::log(r2) / r2);
+    gauss = f * x1;
+    has_gauss = 1;
+    return f * x2;
+  }
+  MIMO_NO_CONTRACT_FN double standard_exponential() {
+    MIMO_NO_CONTRACT
+    return -std::log(1.0 - next_double());
+  }
+  MIMO_NO_CONTRACT_FN double standard_gamma(double shape) {   // legacy_standard_gamma (Marsaglia & Tsang above 1)
+    MIMO_NO_CONTRACT
+    double b, c, U, V, X, Y;
+    if (shape == 1.0) return standard_exponential();
+    if (shape == 0.0) return 0.0;
+    if (shape < 1.0) {
+      for (;;) {
+        U = next_double();
+        V = standard_exponential();
+        if (U <= 1.0 - shape) {
+          X = std::pow(U, 1. / shape);
+          if (X <= V) return X;
+        } else {
+          Y = -std::log((1 - U) / shape);
+          X = std::pow(1.0 - shape + shape * Y, 1. / shape);
+          if (X <= (V + Y)) return X;
+        }
+      }
+    }
+    b = shape - 1. / 3.;
+    c = 1. / std::sqrt(9 * b);
+    for (;;) {
+      do {
+        X = gauss_next();
+        V = 1.0 + c * X;
+      } while (V <= 0.0);
+      V = V * V * V;
+      U = next_double();
+      if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return (b * V);
+      if (std::log(U) < 0.5 * X * X + b * (1. - V + std::log(V))) return (b * V);
+    }
+  }
+};
 
 extern "C" {
 
@@ -374,6 +486,27 @@ int mimo_host_gmm_vi_bound(int K, int D, int tied, const double* alpha0, const d
   }
   vlb[0] = ((lq - lgamma_r(s, &sign)) - iq) - ((lp - lgamma_r(s0, &sign)) - ip);
   vlb[1] = comp;
+  return MIMO_OK;
+  });
+}
+
+MIMO_NO_CONTRACT_FN int mimo_host_legacy_draws(uint32_t* mt_key, int* mt_pos, int* has_gauss, double* gauss, int K, int n_before,
+                                               int n_gamma, int n_after, const double* shapes, double* before, double* gammas,
+                                               double* after) {
+  return guarded_host([&]() -> int {
+  MIMO_NO_CONTRACT
+  if (!mt_key || !mt_pos || !has_gauss || !gauss || K < 0 || n_before < 0 || n_gamma < 0 || n_after < 0 ||
+      *mt_pos < 0 || *mt_pos > 624 || (n_gamma && !shapes) || (n_before && !before) || (n_gamma && !gammas) || (n_after && !after))
+    return MIMO_E_INVALID;
+  for (size_t i = 0; i < (size_t)K * n_gamma; ++i)
+    if (!(shapes[i] >= 0.0)) return MIMO_E_INVALID;       // (numpy raises on a negative or NaN shape: the caller's route)
+  LegacyStream g{mt_key, *mt_pos, *has_gauss, *gauss};
+  for (int k = 0; k < K; ++k) {
+    for (int i = 0; i < n_before; ++i) before[(size_t)k * n_before + i] = 0.0 + 1.0 * g.gauss_next();   // legacy_normal(0, 1)
+    for (int i = 0; i < n_gamma; ++i) gammas[(size_t)k * n_gamma + i] = g.standard_gamma(shapes[(size_t)k * n_gamma + i]);
+    for (int i = 0; i < n_after; ++i) after[(size_t)k * n_after + i] = 0.0 + 1.0 * g.gauss_next();
+  }
+  *mt_pos = g.pos; *has_gauss = g.has_gauss; *gauss = g.gauss;
   return MIMO_OK;
   });
 }

@@ -15,7 +15,7 @@ import scipy.linalg as sla
 from scipy.special import gammaln, digamma
 
 from mimo_amd.utils.abstraction import Statistics as Stats
-from mimo_amd.distributions.wishart import (bartlett_variates_in_reference_order, wishart_from_bartlett,
+from mimo_amd.distributions.wishart import (bartlett_variates_in_reference_order, wishart_from_bartlett, legacy_draws,
                                             wishart_log_partition, wishart_expected_logdet, wishart_rvs,
                                             wishart_rvs_batched, sum_log_diag_chol)
 
@@ -596,11 +596,9 @@ class StackedNormalGammas:
             return self.mus + rng.standard_normal(self.mus.shape) / np.sqrt(self.kappas * lmbdas), lmbdas
         # the generator is called per block as the reference calls it (D gammas, then D normals); the algebra after the loop is
         # the same arithmetic for all K at once: z.dot(diag(s).T) adds exact zeros to z_i s_i
-        lmbdas, zs = np.empty_like(self.mus), np.empty_like(self.mus)
-        scales = 1. / self.betas
-        for k in range(self.size):
-            lmbdas[k] = npr.gamma(self.alphas[k], scales[k])
-            zs[k] = npr.normal(size=self.dim)
+        # gamma(a, scale) IS scale * standard_gamma(a) in the legacy generator: K blocks of (D gammas, D normals) in one call
+        _, gam, zs = legacy_draws(0, self.alphas, self.dim)
+        lmbdas = (1. / self.betas) * gam
         return self.mus + zs * (1. / np.sqrt(self.kappas * lmbdas)), lmbdas
 
     @property

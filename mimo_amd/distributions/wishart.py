@@ -1,5 +1,7 @@
 """Wishart distribution (host-side, O(D^3)) and batched helpers shared by the Normal-Wishart and
 Matrix-Normal-Wishart blocks.  Reference: mimo/distributions/wishart.py:11-153."""
+import ctypes as C
+
 import numpy as np
 import numpy.random as npr
 from scipy.special import multigammaln, digamma
@@ -43,20 +45,48 @@ def wishart_rvs(psi, nu):
     return T @ T.T
 
 
+def legacy_draws(n_before, shapes, n_after):
+    """Per block k of `shapes` (K, G): numpy.random.normal(size=n_before), numpy.random.standard_gamma(shapes[k]) (G values, in
+    order), numpy.random.normal(size=n_after) — the variates and the final state of numpy.random's global generator are those of
+    the 3 K Python calls; computed by mimo_host_legacy_draws (a restatement of numpy's legacy MT19937 stream) when the library is
+    there and the global generator is the stock one.  -> (before (K, n_before), gammas (K, G), after (K, n_after))."""
+    shapes = np.ascontiguousarray(shapes, dtype=np.float64)
+    K, G = shapes.shape
+    before, gam, after = np.empty((K, n_before)), np.empty((K, G)), np.empty((K, n_after))
+    lib = _native_lib()
+    if lib is not None and K > 1 and np.all(shapes >= 0.):
+        st = npr.get_state()
+        if st[0] == 'MT19937':
+            key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+            pos, has, g = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+            if lib.mimo_host_legacy_draws(ptr(key), C.byref(pos), C.byref(has), C.byref(g), K, n_before, G, n_after,
+                                          ptr(shapes), ptr(before), ptr(gam), ptr(after)) == 0:
+                npr.set_state(('MT19937', key, pos.value, has.value, g.value))
+                return before, gam, after
+    for k in range(K):
+        before[k] = npr.normal(size=n_before)
+        gam[k] = npr.standard_gamma(shapes[k])
+        after[k] = npr.normal(size=n_after)
+    return before, gam, after
+
+
+def _native_lib():
+    from mimo_amd.distributions import composite
+    return composite._native()
+
+
 def bartlett_variates_in_reference_order(nus, D, extra):
     """The variates of K Bartlett draws, each followed by `extra` standard normals, taken from numpy.random in the
     order the reference consumes them per component (wishart.py:72-92, then the caller's normal(size=extra)):
-    normal(D(D-1)/2), chisquare(nu - i) for i < D, normal(extra).  The D chi-square draws of a component are ONE
-    vector call: the legacy generator walks a vector of degrees of freedom in order, so the stream is the stream of D
-    scalar calls (tests/test_host_native.py holds that).  Returns (lower (K, n_tril), diag (K, D), eps (K, extra))."""
-    K, n_tril = len(nus), D * (D - 1) // 2
-    lower, diag, eps = np.empty((K, n_tril)), np.empty((K, D)), np.empty((K, extra))
-    dof_off = np.arange(D)
-    for k in range(K):
-        lower[k] = npr.normal(size=n_tril)
-        diag[k] = npr.chisquare(nus[k] - dof_off)
-        eps[k] = npr.normal(size=extra)
-    return lower, np.sqrt(diag), eps
+    normal(D(D-1)/2), chisquare(nu - i) for i < D, normal(extra).  chisquare(df) IS 2 standard_gamma(df / 2) in the legacy
+    generator (both operations exact in float64), and a vector of shapes is walked in order, so the K blocks are one
+    `legacy_draws` call (tests/test_host_native.py holds the stream against the per-call form).
+    Returns (lower (K, n_tril), diag (K, D), eps (K, extra))."""
+    n_tril = D * (D - 1) // 2
+    dof = np.asarray(nus, dtype=float)[:, None] - np.arange(D)[None, :]
+    lower, gam, eps = legacy_draws(n_tril, dof / 2.0, extra)
+    return lower, np.sqrt(2.0 * gam), eps
 
 
 def wishart_from_bartlett(psis, lower, diag):

@@ -76,6 +76,18 @@ int main() {
       if (rc != 0 && dc >= 2) { printf("mnw K=%d dy=%d dc=%d affine=%d rc=%d\n", K, dy, dc, affine, rc); return 1; }
     }
   }
+  {   // numpy's legacy stream: every branch of the gamma sampler, the refill of the Mersenne Twister, the cached gaussian
+    std::vector<uint32_t> key(624);
+    for (int i = 0; i < 624; ++i) key[i] = 1812433253u * (i + 7) + 12345u * i;
+    int pos = 624, has = 0; double gs = 0.0;
+    const int K = 50, nb = 13, ng = 6, na = 5;
+    std::vector<double> sh((size_t)K * ng), ob((size_t)K * nb), og((size_t)K * ng), oa((size_t)K * na);
+    for (int k = 0; k < K; ++k) for (int i = 0; i < ng; ++i) sh[(size_t)k * ng + i] = i == 0 ? 1.0 : i == 1 ? 0.0 : i == 2 ? 0.07 * (k + 1) : 0.4 * k + i;
+    int rc = mimo_host_legacy_draws(key.data(), &pos, &has, &gs, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data());
+    if (rc != 0 || !std::isfinite(og[(size_t)K * ng - 1]) || pos < 0 || pos > 624) { printf("legacy draws rc=%d\n", rc); return 1; }
+    sh[3] = -1.0;
+    if (mimo_host_legacy_draws(key.data(), &pos, &has, &gs, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data()) >= 0) { printf("negative shape accepted\n"); return 1; }
+  }
   // a block that is not positive definite must come back as an error, not as a crash
   double a1[2] = {0, 0}, b1[1] = {1}, c1[4] = {1, 2, 2, 1}, d1[1] = {3}, o[64];
   int rc = mimo_host_nw_vi(1, 2, a1, b1, c1, d1, o, o + 2, o + 6, o + 7, o + 8, o + 9, o + 11, o + 15, o + 16);

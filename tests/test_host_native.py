@@ -449,3 +449,72 @@ def test_the_driver_runs_the_fused_sweep(monkeypatch):
     np.random.seed(5)
     v2 = m2.meanfield_coordinate_descent(eng2.Z, maxiter=6, progress_bar=False)
     assert np.allclose(v1, v2, rtol=1e-11, atol=0)
+
+
+def _legacy_reference(nb, shapes, na):
+    K, G = shapes.shape
+    b, g, a = np.empty((K, nb)), np.empty((K, G)), np.empty((K, na))
+    for k in range(K):
+        b[k] = np.random.normal(size=nb)
+        g[k] = np.random.standard_gamma(shapes[k])
+        a[k] = np.random.normal(size=na)
+    return b, g, a
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_native_legacy_stream_is_numpy_randoms(block):
+    """mimo_host_legacy_draws against numpy.random itself, bit for bit: the variates (normal, standard_gamma above / below /
+    at shape 1 and at 0) and the generator state afterwards (key, position, cached gaussian), from seeded states with and
+    without a pending gaussian — 8 x 40 random block layouts."""
+    from mimo_amd.distributions.wishart import legacy_draws
+    assert _lib.load().mimo_host_legacy_draws is not None
+    for seed in range(40 * block, 40 * block + 40):
+        rs = np.random.default_rng(seed)
+        K, G, nb, na = int(rs.integers(2, 40)), int(rs.integers(0, 9)), int(rs.integers(0, 30)), int(rs.integers(0, 12))
+        kind = seed % 4
+        if kind == 0:
+            shapes = rs.uniform(0.01, 1.0, (K, G))
+        elif kind == 1:
+            shapes = rs.uniform(0.5, 300., (K, G))
+        elif kind == 2:
+            shapes = np.where(rs.random((K, G)) < 0.3, 1.0, rs.uniform(0., 3., (K, G)))
+        else:
+            shapes = (rs.integers(1, 60, (K, 1)) - np.arange(G)[None, :] * 0.5).clip(0.0)
+        outs = []
+        for fn in (_legacy_reference, legacy_draws):
+            np.random.seed(seed)
+            if seed % 3 == 0:
+                np.random.normal()                     # leaves the second variate of the pair cached
+            got = fn(nb, shapes, na)
+            st = np.random.get_state()
+            outs.append((got, st, np.random.random(3), np.random.normal(size=2)))
+        (w, sw, uw, nw), (g, sg, ug, ng) = outs
+        assert all(np.array_equal(x, y) for x, y in zip(w, g)), seed
+        assert np.array_equal(sw[1], sg[1]) and sw[2:] == sg[2:] and np.array_equal(uw, ug) and np.array_equal(nw, ng), seed
+
+
+def test_reference_order_draws_are_the_per_component_calls():
+    """The two identities the batched draws rest on, and the Bartlett variates against the reference's own call sequence
+    (wishart.py:72-92: normal(n_tril), then chisquare(nu - i, size=1) per i; then the caller's normal(extra))."""
+    from mimo_amd.distributions.wishart import bartlett_variates_in_reference_order
+    np.random.seed(5)
+    a = [np.random.chisquare(17.3 - np.arange(8)) for _ in range(4)]
+    np.random.seed(5)
+    b = [2.0 * np.random.standard_gamma((17.3 - np.arange(8)) / 2.0) for _ in range(4)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    np.random.seed(5)
+    a = [np.random.gamma(np.array([0.3, 2., 7.]), np.array([.5, 3., 1.7])) for _ in range(4)]
+    np.random.seed(5)
+    b = [np.array([.5, 3., 1.7]) * np.random.standard_gamma(np.array([0.3, 2., 7.])) for _ in range(4)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    K, D, extra = 9, 5, 7
+    nus = np.random.default_rng(1).uniform(D + 0.5, 40., K)
+    np.random.seed(11)
+    lower, diag, eps = bartlett_variates_in_reference_order(nus, D, extra)
+    state = np.random.get_state()
+    np.random.seed(11)
+    for k in range(K):
+        assert np.array_equal(lower[k], np.random.normal(size=D * (D - 1) // 2))
+        assert np.array_equal(diag[k], np.array([np.random.chisquare(nus[k] - i, size=1)[0] ** 0.5 for i in range(D)]))
+        assert np.array_equal(eps[k], np.random.normal(size=extra))
+    assert np.array_equal(state[1], np.random.get_state()[1]) and state[2:] == np.random.get_state()[2:]
