@@ -98,6 +98,21 @@ _sweeps(5)
 t0 = time.perf_counter(); _sweeps(60); t = (time.perf_counter() - t0) / 60
 report("diagonal-precision GMM, Gibbs sweep (Philox labels)", t, N * K, N * K * FEd + N * FSd)
 
+# full-covariance Gibbs sweeps with the posterior draws in the reference's numpy.random order (seeded runs reproduce the reference's
+# chain) against the batched draws from a Generator: since round 4 the former are one native call per sweep (mimo_host_legacy_draws)
+full.resample(X, maxiter=2, progress_bar=False, label_rng='philox', seed=1, init_labels='posterior')
+for name, prng in (("numpy.random in the reference's per-component order", None),
+                   ("batched draws from a numpy Generator", np.random.Generator(np.random.Philox(7)))):
+    st = [eng.label_stats(full.labels_, K)]
+
+    def _fs(n):
+        for it in range(n):
+            st[0] = full.gibbs_iteration(full._bind(X), st[0], it + 1, 'philox', 1, prng)[1]
+
+    _fs(5)
+    t0 = time.perf_counter(); _fs(40); t = (time.perf_counter() - t0) / 40
+    report("full-covariance GMM, Gibbs sweep (Philox labels), posterior draws: " + name, t, N * K, N * K * FE + N * FS)
+
 hyper = NormalWishart(D, np.zeros(D), 1e-2, np.eye(D), D + 2.)
 hp = TiedGaussiansWithScaledPrecision(K, D, kappas=1e-2 * np.ones(K))
 hier = BayesianMixtureOfGaussiansWithHierarchicalPrior(
