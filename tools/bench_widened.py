@@ -103,11 +103,12 @@ report("diagonal-precision GMM, Gibbs sweep (Philox labels)", t, N * K, N * K * 
 full.resample(X, maxiter=2, progress_bar=False, label_rng='philox', seed=1, init_labels='posterior')
 for name, prng in (("numpy.random in the reference's per-component order", None),
                    ("batched draws from a numpy Generator", np.random.Generator(np.random.Philox(7)))):
-    st = [eng.label_stats(full.labels_, K)]
+    _feng = full._bind(X)
+    st = [_feng.label_stats(full.labels_, K)]
 
     def _fs(n):
         for it in range(n):
-            st[0] = full.gibbs_iteration(full._bind(X), st[0], it + 1, 'philox', 1, prng)[1]
+            st[0] = full.gibbs_iteration(_feng, st[0], it + 1, 'philox', 1, prng)[1]
 
     _fs(5)
     t0 = time.perf_counter(); _fs(40); t = (time.perf_counter() - t0) / 40
