@@ -37,12 +37,17 @@ def wishart_rvs(psi, nu):
     D = psi.shape[0]
     n_tril = D * (D - 1) // 2
     covariances = npr.normal(size=n_tril).reshape((n_tril,))
-    variances = np.array([npr.chisquare(nu - i, size=1)[0] ** 0.5 for i in range(D)])
+    # (array ** 0.5 as in the reference: numpy turns it into sqrt — correctly rounded; a float64 SCALAR ** 0.5 goes to libm's pow
+    # and differs from it in the last bit once in a few hundred values)
+    variances = np.array([(npr.chisquare(nu - i, size=1) ** 0.5)[0] for i in range(D)])
     A = np.zeros((D, D))
     A[np.tril_indices(D, k=-1)] = covariances
     A[np.diag_indices(D)] = variances
     T = np.linalg.cholesky(psi) @ A
     return T @ T.T
+
+
+_NATIVE_MIN_VARIATES = 1000
 
 
 def legacy_draws(n_before, shapes, n_after):
@@ -54,7 +59,8 @@ def legacy_draws(n_before, shapes, n_after):
     K, G = shapes.shape
     before, gam, after = np.empty((K, n_before)), np.empty((K, G)), np.empty((K, n_after))
     lib = _native_lib()
-    if lib is not None and K > 1 and np.all(shapes >= 0.):
+    # (handing numpy's state over and back costs ~0.1 ms: below ~1000 variates the K Python calls are cheaper)
+    if lib is not None and K * (n_before + G + n_after) >= _NATIVE_MIN_VARIATES and np.all(shapes >= 0.):
         st = npr.get_state()
         if st[0] == 'MT19937':
             key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()

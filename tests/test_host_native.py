@@ -462,12 +462,14 @@ def _legacy_reference(nb, shapes, na):
 
 
 @pytest.mark.parametrize("block", range(8))
-def test_native_legacy_stream_is_numpy_randoms(block):
+def test_native_legacy_stream_is_numpy_randoms(block, monkeypatch):
     """mimo_host_legacy_draws against numpy.random itself, bit for bit: the variates (normal, standard_gamma above / below /
     at shape 1 and at 0) and the generator state afterwards (key, position, cached gaussian), from seeded states with and
     without a pending gaussian — 8 x 40 random block layouts."""
+    from mimo_amd.distributions import wishart
     from mimo_amd.distributions.wishart import legacy_draws
     assert _lib.load().mimo_host_legacy_draws is not None
+    monkeypatch.setattr(wishart, "_NATIVE_MIN_VARIATES", 0)          # (small blocks take the Python calls by default)
     for seed in range(40 * block, 40 * block + 40):
         rs = np.random.default_rng(seed)
         K, G, nb, na = int(rs.integers(2, 40)), int(rs.integers(0, 9)), int(rs.integers(0, 30)), int(rs.integers(0, 12))
@@ -507,7 +509,7 @@ def test_reference_order_draws_are_the_per_component_calls():
     np.random.seed(5)
     b = [np.array([.5, 3., 1.7]) * np.random.standard_gamma(np.array([0.3, 2., 7.])) for _ in range(4)]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
-    K, D, extra = 9, 5, 7
+    K, D, extra = 60, 5, 7                               # (1320 variates: the native route)
     nus = np.random.default_rng(1).uniform(D + 0.5, 40., K)
     np.random.seed(11)
     lower, diag, eps = bartlett_variates_in_reference_order(nus, D, extra)
@@ -515,6 +517,6 @@ def test_reference_order_draws_are_the_per_component_calls():
     np.random.seed(11)
     for k in range(K):
         assert np.array_equal(lower[k], np.random.normal(size=D * (D - 1) // 2))
-        assert np.array_equal(diag[k], np.array([np.random.chisquare(nus[k] - i, size=1)[0] ** 0.5 for i in range(D)]))
+        assert np.array_equal(diag[k], np.array([(np.random.chisquare(nus[k] - i, size=1) ** 0.5)[0] for i in range(D)]))
         assert np.array_equal(eps[k], np.random.normal(size=extra))
     assert np.array_equal(state[1], np.random.get_state()[1]) and state[2:] == np.random.get_state()[2:]
