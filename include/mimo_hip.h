@@ -451,6 +451,8 @@ int mimo_data_checksum(mimo_ctx* ctx, uint64_t out[2]);
  *                  they take every shape they exist for with Dz >= mid_min_d (default 5; > 32: the route is off), and the narrow
  *                  kernels keep the shapes both cover with K < mid_narrow_k (default 33).
  *   "mid_labels_min_d" (process-wide) smallest Dz whose label pass (K <= 48) runs on the mid kernel's label mode; 0: where it measured ahead.
+ *   "narrow_big_vi" (process-wide) largest K (129 .. 256) whose softmax pass over at most two contraction steps runs on the narrow
+ *                  kernels of mimo_narrow_big.hip; 0: where they measured ahead (256 for one step, 192 for two).
  * Results do not depend on either value beyond the documented summation order of the partial blocks.  MIMO_E_INVALID for
  * an unknown key or a value out of range.  The reference has no counterpart (launch geometry is ours). */
 int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value);

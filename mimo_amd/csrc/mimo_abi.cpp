@@ -1641,6 +1641,11 @@ int mimo_tune(mimo_ctx* ctx, const char* key, int64_t value) {
       set_sorted_range_cap((int)value);
       return MIMO_OK;
     }
+    if (!strcmp(key, "narrow_big_vi")) {
+      if (value < 0 || value > 256) return fail(ctx, MIMO_E_INVALID, "mimo_tune: narrow_big_vi = %lld outside [0, 256]", (long long)value);
+      set_narrow_big_vi((int)value);
+      return MIMO_OK;
+    }
     if (!strcmp(key, "mid_labels_narrow_k")) {
       if (value < 0 || value > 64) return fail(ctx, MIMO_E_INVALID, "mimo_tune: mid_labels_narrow_k = %lld outside [0, 64]", (long long)value);
       g_mid_labels_narrow_k = (int)value;

@@ -55,6 +55,7 @@ int narrow_v(int K);                 // component slots per lane (4 V >= K), 0: 
 int narrow_nsf(int F);               // contraction steps: ceil(F / 4)
 // (gibbs: 0 softmax + statistics pass, 1 label draw, 2 label draw + statistics of the labels in the same pass)
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs);
+void set_narrow_big_vi(int k);      // mimo_tune "narrow_big_vi": largest K of the softmax pass on mimo_narrow_big.hip (0: measured rule)
 // the grouped variant (full feature map, Dz = 5 .. 32; rows of the upper triangle padded to whole steps): Dz if it serves the
 // shape, else 0; contraction steps of the image either way; position of feature (a, b) in the grouped order
 int narrow_dt(int K, int F, int D, int gibbs);

@@ -9,7 +9,8 @@ namespace mimo {
 // ------------------------------------------------------------------------------------------
 // component slots per lane the kernels are instantiated for (4 V >= K); every multiple of 4 is there, so 4 V never exceeds
 // the 16-padded component count of the partial block
-static const int kNarrowV[] = {1, 2, 3, 4, 6, 8, 10, 12, 13, 14, 16, 18, 20, 22, 24, 25, 26, 28, 30, 32};
+static const int kNarrowV[] = {1, 2, 3, 4, 6, 8, 10, 12, 13, 14, 16, 18, 20, 22, 24, 25, 26, 28, 30, 32,
+                               36, 40, 44, 48, 52, 56, 60, 64};      // (above 32: mimo_narrow_big.hip, at most two contraction steps)
 int narrow_v(int K) {
   const int need = (K + 3) / 4;
   for (int v : kNarrowV) if (v >= need) return v;
@@ -34,8 +35,10 @@ static narrow_fn pick_narrow_nsf(int nsf, int gibbs, int zi) {
   return nullptr;
 }
 narrow_fn pick_narrow_table(int V, int nsf, int gibbs, int zi);     // mimo_narrow_table.hip
+narrow_fn pick_narrow_big(int V, int nsf, int gibbs, int zi);       // mimo_narrow_big.hip
 static narrow_fn pick_narrow(int V, int nsf, int gibbs, int zi) {
-  if (nsf > 4) return pick_narrow_table(V, nsf, gibbs, zi);
+  if (nsf > 4) return V > 32 ? nullptr : pick_narrow_table(V, nsf, gibbs, zi);
+  if (V > 32) return nsf <= 2 ? pick_narrow_big(V, nsf, gibbs, zi) : nullptr;
   switch (V) {
 #define MIMO_NV(v) case v: return pick_narrow_nsf<v>(nsf, gibbs, zi);
     MIMO_NV(1) MIMO_NV(2) MIMO_NV(3) MIMO_NV(4) MIMO_NV(6) MIMO_NV(8) MIMO_NV(10) MIMO_NV(12) MIMO_NV(13) MIMO_NV(14)
@@ -78,6 +81,9 @@ void narrow_group_pos(int D, int a, int b, int* step, int* j) {
 
 // Which (K, feature count F, Dz) the narrow kernels take (full structure or a reduced map alike: they read the feature
 // table).  MIMO_NARROW=0 switches the route off, MIMO_NARROW_MIN_K / MIMO_NARROW_MAX_K move its K range (tuning knobs).
+static int g_narrow_big_vi = 0;
+void set_narrow_big_vi(int k) { g_narrow_big_vi = k; }
+
 bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   static const bool on = [] { const char* e = getenv("MIMO_NARROW"); return !e || atoi(e) != 0; }();
   static const int kmin_env = [] { const char* e = getenv("MIMO_NARROW_MIN_K"); return e ? atoi(e) : 0; }();
@@ -85,7 +91,18 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   // pass / sweep (profiles/r03_small_vs_narrow.txt): Dz=2 K=16 57 / 79 against 59 / 88, K=20 112 / 156 against 77 / 112, K=32 113 / 159 against 95 / 124;
   // Dz=3 K=12 86 / 146 against 61 / 88, K=24 171 / 166 against 87 / 130; Dz=4 K=8 55 / 81 against 59 / 91, K=16 110 / 163 against 83 / 105; Dz=1 K=32 83 / 126 against 73 / 110
   const int kmin = kmin_env > 0 ? kmin_env : D <= 2 ? 17 : D == 3 ? 9 : 12;
-  static const int kmax = [] { const char* e = getenv("MIMO_NARROW_MAX_K"); return e ? atoi(e) : 128; }();
+  static const int kmax = [] { const char* e = getenv("MIMO_NARROW_MAX_K"); return e ? atoi(e) : 256; }();
+  // 129 .. 256 components over at most two contraction steps (mimo_narrow_big.hip), N = 2e6, ms per pass / sweep against the tile kernels
+  // (profiles/r04_narrow_big.txt): one step (Dz = 1) K=144 0.33 / 0.27 against 0.76 / 0.43, K=256 0.70 / 0.43 against 1.14 / 0.62; two steps (Dz = 2)
+  // K=160 0.43 / 0.33 against 0.82 / 0.43, K=192 0.79 / 0.39 against 0.92 / 0.52, K=224 1.28 / 0.45 against 1.25 / 0.56, K=256 3.48 / 0.50 against
+  // 1.20 / 0.62 — the softmax pass of 52+ slots x 2 steps spills (64 l values + 128 accumulators + ~90 registers > 512): it stops at K = 192;
+  // the label pass has no accumulators (two waves per SIMD, no scratch) and takes every K.  MIMO_NARROW_BIG_VI / _LABELS: tuning knobs
+  auto big_kmax = [](int g, int nsf) {
+    static const int vi_env = [] { const char* e = getenv("MIMO_NARROW_BIG_VI"); return e ? atoi(e) : 0; }();
+    const int vi = g_narrow_big_vi > 0 ? g_narrow_big_vi : vi_env;      // (mimo_tune "narrow_big_vi")
+    static const int lab = [] { const char* e = getenv("MIMO_NARROW_BIG_LABELS"); return e ? atoi(e) : 256; }();
+    return g == 1 ? lab : vi > 0 ? vi : nsf <= 1 ? 256 : 192;
+  };
   static const bool wide_on = [] { const char* e = getenv("MIMO_NARROW_WIDE"); return !e || atoi(e) != 0; }();
   static const int wide_kmax = [] { const char* e = getenv("MIMO_NARROW_WIDE_MAX_K"); return e ? atoi(e) : 0; }();
   if (!on) return false;
@@ -103,7 +120,7 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
     return false;
   } else if (D > 4) {            // a reduced map of at most 16 features over wider rows
     if (!wide_on || D > 16 || K < 1 || K > 64) return false;
-  } else if (K < kmin || K > kmax || K > 128) {
+  } else if (K < kmin || K > kmax || K > 256 || (K > 128 && (narrow_nsf(F) > 2 || K > big_kmax(gibbs, narrow_nsf(F))))) {
     return false;
   }
   const int V = narrow_v(K);

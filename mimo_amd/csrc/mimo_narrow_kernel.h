@@ -75,11 +75,16 @@ constexpr int kQuadLast = 0xFF;     // [3, 3, 3, 3]
 // 4, 3, 2 and 1 waves).  Registers: V l values + V NSF accumulators (doubles) + 70 .. 100 besides; a bound that is too tight
 // spills and costs far more than the lost wave: V = 16, NSF = 2 forced to three waves (168 registers, 220 bytes of scratch)
 // ran 285 us where the two-wave build runs 152 us (N = 2e6).
+#ifndef MIMO_NARROW_BIG_LABEL_WAVES
+#define MIMO_NARROW_BIG_LABEL_WAVES 2
+#endif
 #ifdef MIMO_NARROW_FORCE_WAVES
 constexpr int narrow_waves(int, int, int) { return MIMO_NARROW_FORCE_WAVES; }
 #else
 // (the table covers NSF <= 4 — its key does not separate larger NSF; the table-driven loops take what the allocator gives them)
-constexpr int narrow_waves(int V, int NSF, int MODE) { return NSF > 4 ? 1 : narrow_occ(V, NSF, MODE) & 7; }
+// (V > 32 — 129 .. 256 components over one or two contraction steps, Dz <= 2: mimo_narrow_big.hip — is not in the table: V l values
+// and V NSF accumulators take the whole unified register file of one wave per SIMD in the softmax pass; the label pass has no accumulators)
+constexpr int narrow_waves(int V, int NSF, int MODE) { return NSF > 4 ? 1 : V > 32 ? (MODE == 1 ? MIMO_NARROW_BIG_LABEL_WAVES : 1) : narrow_occ(V, NSF, MODE) & 7; }
 #endif
 // ... and which of the two loop bodies: "lean" (bit 3 of the table entry) keeps the exponentials inline and reads the operand
 // factors at the top of a step — fewer live registers, what the large slot counts need; the other one batches the table reads
@@ -87,7 +92,7 @@ constexpr int narrow_waves(int V, int NSF, int MODE) { return NSF > 4 ? 1 : narr
 #ifdef MIMO_NARROW_FORCE_LEAN
 constexpr bool narrow_lean(int, int, int) { return MIMO_NARROW_FORCE_LEAN != 0; }
 #else
-constexpr bool narrow_lean(int V, int NSF, int MODE) { return NSF > 4 || (narrow_occ(V, NSF, MODE) & 8) != 0; }
+constexpr bool narrow_lean(int V, int NSF, int MODE) { return NSF > 4 || V > 32 || (narrow_occ(V, NSF, MODE) & 8) != 0; }
 #endif
 
 // The GROUPED feature order of the Dz-templated variant (DT = Dz >= 5, full map): row a of the upper triangle of z~ z~' —

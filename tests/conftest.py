@@ -71,4 +71,5 @@ def engine(_session_engine):
     _session_engine.tune("mid_narrow_k", 0)
     _session_engine.tune("mid_labels_min_d", 0)
     _session_engine.tune("mid_labels_narrow_k", 0)
+    _session_engine.tune("narrow_big_vi", 0)
     return _session_engine

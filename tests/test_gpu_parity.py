@@ -704,7 +704,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
     mid = K <= 48 and (D >= 14 if K >= 33 else D >= 20 if K >= 17 else D >= 17)          # the mid kernel's label mode (round 4)
-    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "mid" if mid else "rowwave")
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D <= 2 and 128 < K <= 256) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "mid" if mid else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
@@ -968,7 +968,9 @@ def test_empty_data_on_the_row_owner_kernels(engine):
 
 NARROW_SHAPES = [(2, 50), (2, 64), (2, 33), (2, 100), (2, 128), (1, 50), (1, 97), (1, 128), (3, 50), (3, 64), (3, 96), (3, 127),
                  (4, 48), (4, 50), (4, 64), (4, 100), (4, 128), (2, 37), (2, 41), (2, 53), (2, 57), (2, 69), (2, 77), (2, 85),
-                 (2, 93), (2, 101), (2, 109), (2, 117), (2, 125)]
+                 (2, 93), (2, 101), (2, 109), (2, 117), (2, 125),
+                 # 129 .. 256 components over at most two contraction steps (mimo_narrow_big.hip: one slot count per 16-component band)
+                 (2, 129), (2, 144), (2, 150), (2, 176), (2, 192), (2, 200), (2, 224), (2, 240), (2, 256), (1, 160), (1, 256)]
 
 
 # ... and few components over many features (Dz = 5 .. 16, K <= 16: the table-driven loops; every contraction length once)
@@ -993,6 +995,7 @@ def test_narrow_kernels_vs_oracle(engine, D, K, N):
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
     engine.tune("mid_min_d", 64)          # (the mid kernels are preferred for some of these shapes since round 4: every narrow instantiation stays tested)
+    engine.tune("narrow_big_vi", 256)     # (... and the softmax pass of 193 .. 256 components over two steps stays on the tile kernels by default)
     assert engine.plan(K)["kind"] == "narrow" and (D > 16 or engine.plan(K, gibbs=True)["kind"] == "narrow")
     L = O.canonical_eval(Z, c, b, W)
     lse = logsumexp(L, axis=0)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-SOURCES = [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30), ("mimo_wide.hip", 10), ("mimo_narrow.hip", 100), ("mimo_narrow_table.hip", 100), ("mimo_narrow_grouped.hip", 50)]
+SOURCES = [("mimo_kernels.hip", 100), ("mimo_small.hip", 60), ("mimo_rowwave.hip", 30), ("mimo_wide.hip", 10), ("mimo_narrow.hip", 100), ("mimo_narrow_table.hip", 100), ("mimo_narrow_grouped.hip", 50), ("mimo_narrow_big.hip", 30), ("mimo_mid.hip", 30), ("mimo_predict.hip", 5)]
 
 
 @pytest.fixture(scope="module")

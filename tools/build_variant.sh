@@ -7,7 +7,7 @@ name=$1; defs=$2; shift 2
 files=${@:-mimo_kernels.hip}
 mkdir -p ../../tools/variants /tmp/variant_$name
 objs=""
-for o in mimo_kernels mimo_small mimo_rowwave mimo_wide mimo_narrow mimo_narrow_table mimo_narrow_grouped mimo_mid mimo_predict; do
+for o in mimo_kernels mimo_small mimo_rowwave mimo_wide mimo_narrow mimo_narrow_table mimo_narrow_grouped mimo_narrow_big mimo_mid mimo_predict; do
   if [[ " $files " == *" $o.hip "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-honor-nans $defs -c $o.hip -o /tmp/variant_$name/$o.o
     objs="$objs /tmp/variant_$name/$o.o"
