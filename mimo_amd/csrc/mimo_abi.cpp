@@ -490,6 +490,9 @@ static bool use_mid(const mimo_ctx* ctx, int K, bool plain) {
 // Label pass of the mid shapes (mimo_mid.hip, label mode + the label-statistics kernels): K <= 48 at Dz >= 10, plain requests, where it
 // measured ahead of the row-owner label kernels (profiles/r04_mid_label_sweep.txt); "mid_labels_min_d" (mimo_tune) moves the lower end
 static int g_mid_labels_min_d = [] { const char* e = getenv("MIMO_MID_LABELS_MIN_D"); return e ? atoi(e) : 0; }();
+static int g_bound_promote_mid_k = 16;     // largest K of a mid-kernel shape whose bound-only pass runs as the plain pass (profiles/r04_bound_pass.txt: N = 2e6, ms generic / plain:
+                                           // Dz=20 K=16 1.02 / 0.73, Dz=32 K=16 1.73 / 1.51 — but Dz=24 K=32 1.51 / 1.68, Dz=16 K=48 0.99 / 1.31; every narrow shape gains: Dz=2 K=50
+                                           // 0.37 / 0.16, Dz=1 K=100 0.77 / 0.20, Dz=4 K=128 0.75 / 0.62, Dz=16 K=4 0.65 / 0.23, Dz=32 K=4 1.73 / 0.81)
 static int g_mid_labels_narrow_k = 0;      // (mimo_tune "mid_labels_narrow_k": K from which the label mode goes before the narrow label kernels; 0: measured rule)
 static bool use_mid_labels(const mimo_ctx* ctx, int K, bool wants_tables) {
   if (wants_tables || !mid_labels_covers(K, ctx->D, ctx->structure) || !label_stats_covers(K, ctx->D, ctx->structure)) return false;
@@ -1128,6 +1131,16 @@ static int keep_tables(mimo_ctx* ctx, int K, int flags, KernelArgs* a) {
   return MIMO_OK;
 }
 
+// Which bound-only requests run as the plain pass (mimo_estep).  MIMO_BOUND_PROMOTE = 0: none, 2: every shape of the narrow / mid kernels.
+static bool bound_promote(const mimo_ctx* ctx, int K) {
+  static const int mode = [] { const char* e = getenv("MIMO_BOUND_PROMOTE"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return false;
+  const bool md = use_mid(ctx, K, true);
+  const bool nv = !md && use_narrow(ctx, K, false, true, true) != 0;
+  if (mode == 2) return md || nv;
+  return (md && K <= g_bound_promote_mid_k) || nv;
+}
+
 int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W, int K,
                int flags, double* S, double* scalars) {
   return guarded(ctx, [&]() -> int {
@@ -1139,11 +1152,17 @@ int mimo_estep(mimo_ctx* ctx, const double* c, const double* b, const double* W,
     return fail(ctx, MIMO_E_INVALID, "mimo_estep: S is NULL without MIMO_F_NO_STATS / MIMO_F_ASYNC");
   KernelArgs a;
   fill_args(ctx, K, &a);
-  a.do_stats = no_stats ? 0 : 1;
+  const bool tables = (flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT)) != 0;
+  // A bound-only request (no statistics, no tables: the full-data pass of every SVI outer iteration, gmm.py:319-326 / ilr.py:270-277
+  // of the reference) used to take the generic tile kernels whatever the shape; where the plain pass runs on the narrow or mid kernels
+  // those pay for 16 x 16 padding the plain pass does not have, and the plain pass with its statistics left in the partial blocks is
+  // the faster bound (bound_promote(): measured rule).
+  const bool promote = no_stats && !tables && !(flags & MIMO_F_DEVICE_OUT) && bound_promote(ctx, K);
+  a.do_stats = (no_stats && !promote) ? 0 : 1;
   a.split = (flags & MIMO_F_ENTROPY_SPLIT) ? 1 : 0;
   if ((rc = keep_tables(ctx, K, flags, &a))) return rc;
   // plain softmax + statistics pass at K <= 64, Dz <= 9: the row-owner kernel (Theta in the row-owner image)
-  const bool plain = !no_stats && !(flags & (MIMO_F_KEEP_RESP | MIMO_F_KEEP_LOGP | MIMO_F_KEEP_LSE | MIMO_F_ENTROPY_SPLIT));
+  const bool plain = (!no_stats || promote) && !tables;
   const bool md = use_mid(ctx, K, plain);                     // mid shapes (K <= 32 over wide rows): mimo_mid.hip
   const bool nv = !md && use_narrow(ctx, K, false, plain, true) != 0;      // narrow shapes (Dz <= 4, 32 < K <= 128; few components over many features): mimo_narrow.hip
   const bool rv = !nv && !md && plain && ctx->n_bad == 0 && ctx->D <= 16 && !use_small(ctx, K) && vi_rowwave_covers(K, ctx->F16, a.ZS);

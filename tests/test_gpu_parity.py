@@ -1142,3 +1142,35 @@ def test_label_kernels_that_count_their_labels(engine, D, K):
     assert np.array_equal(S.n, G.n) and rel_err(S.sxx, G.sxx) < 1e-12
     if (D, K) != (6, 17):              # (6, 17): the sweep takes its statistics inside the narrow label kernel — another summation order
         assert np.array_equal(S.sxx, G.sxx)
+
+
+@pytest.mark.parametrize("D,K", [(2, 50), (1, 100), (2, 160), (4, 64), (8, 4), (16, 4), (32, 4), (20, 16), (17, 9), (24, 32), (8, 64), (16, 64), (3, 8)])
+@pytest.mark.parametrize("N", [1, 5003, 70001])
+def test_bound_only_pass(engine, D, K, N):
+    """MIMO_F_NO_STATS without tables — the full-data bound of every SVI outer iteration (gmm.py:319-326, ilr.py:270-277 of the
+    reference): sum_n lse_n against the oracle, equal to the scalar of the full pass of the same shape, synchronous and asynchronous
+    form, with rows that hold a NaN; on the narrow kernels and on the mid kernels up to K = 16 it runs as the plain pass of the
+    shape's own family (mimo_estep: bound_promote), elsewhere as the generic request on the tile kernels."""
+    from oracle import mimo_oracle as O
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(31000 + 10 * D + K)
+    Z, c, b, W = _random_problem(rng, N, D, K)
+    engine.upload(Z)
+    want = float(logsumexp(O.canonical_eval(Z, c, b, W), axis=0).sum())
+    S, sc_full = engine.estep(c, b, W)
+    none, sc = engine.estep(c, b, W, stats=False)
+    assert none is None and abs(sc[0] - want) < 1e-12 * max(1., abs(want)) and abs(sc[0] - sc_full[0]) <= 1e-13 * max(1., abs(want))
+    engine.estep_async(c, b, W, stats=False)
+    none, sc2 = engine.estep_wait()
+    assert none is None and sc2[0] == sc[0]
+    S2, sc3 = engine.estep(c, b, W)                              # the next full pass is not disturbed by the statistics left behind
+    assert np.array_equal(S2.sxx, S.sxx) and sc3[0] == sc_full[0]
+    if N > 100:
+        Zn = Z.copy()
+        bad = rng.choice(N, size=7, replace=False)
+        Zn[bad, rng.integers(0, D, size=7)] = np.nan
+        engine.upload(Zn)
+        Ln = O.canonical_eval(np.nan_to_num(Zn) * (~np.isnan(Zn).any(axis=1))[:, None], c, b, W)
+        _, scn = engine.estep(c, b, W, stats=False)
+        _, scn_full = engine.estep(c, b, W)
+        assert abs(scn[0] - scn_full[0]) <= 1e-12 * max(1., abs(scn_full[0]))
