@@ -47,7 +47,7 @@ def wishart_rvs(psi, nu):
     return T @ T.T
 
 
-_NATIVE_MIN_VARIATES = 1000
+_NATIVE_MIN_BLOCKS = 16
 
 
 def legacy_draws(n_before, shapes, n_after):
@@ -59,8 +59,9 @@ def legacy_draws(n_before, shapes, n_after):
     K, G = shapes.shape
     before, gam, after = np.empty((K, n_before)), np.empty((K, G)), np.empty((K, n_after))
     lib = _native_lib()
-    # (handing numpy's state over and back costs ~0.1 ms: below ~1000 variates the K Python calls are cheaper)
-    if lib is not None and K * (n_before + G + n_after) >= _NATIVE_MIN_VARIATES and np.all(shapes >= 0.):
+    # (handing numpy's state over and back costs ~0.1 ms — numpy copies the 624 key words element by element — and a block costs three
+    # Python calls of ~2.4 us: below ~16 blocks the calls are cheaper)
+    if lib is not None and K >= _NATIVE_MIN_BLOCKS and np.all(shapes >= 0.):
         st = npr.get_state()
         if st[0] == 'MT19937':
             key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()

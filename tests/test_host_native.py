@@ -469,7 +469,7 @@ def test_native_legacy_stream_is_numpy_randoms(block, monkeypatch):
     from mimo_amd.distributions import wishart
     from mimo_amd.distributions.wishart import legacy_draws
     assert _lib.load().mimo_host_legacy_draws is not None
-    monkeypatch.setattr(wishart, "_NATIVE_MIN_VARIATES", 0)          # (small blocks take the Python calls by default)
+    monkeypatch.setattr(wishart, "_NATIVE_MIN_BLOCKS", 2)            # (a few blocks take the Python calls by default)
     for seed in range(40 * block, 40 * block + 40):
         rs = np.random.default_rng(seed)
         K, G, nb, na = int(rs.integers(2, 40)), int(rs.integers(0, 9)), int(rs.integers(0, 30)), int(rs.integers(0, 12))
@@ -509,7 +509,7 @@ def test_reference_order_draws_are_the_per_component_calls():
     np.random.seed(5)
     b = [np.array([.5, 3., 1.7]) * np.random.standard_gamma(np.array([0.3, 2., 7.])) for _ in range(4)]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
-    K, D, extra = 60, 5, 7                               # (1320 variates: the native route)
+    K, D, extra = 60, 5, 7                               # (60 blocks: the native route)
     nus = np.random.default_rng(1).uniform(D + 0.5, 40., K)
     np.random.seed(11)
     lower, diag, eps = bartlett_variates_in_reference_order(nus, D, extra)
