@@ -357,6 +357,17 @@ int mimo_host_legacy_draws(uint32_t* mt_key, int* mt_pos, int* has_gauss, double
                            int n_gamma, int n_after, const double* shapes, double* before, double* gammas,
                            double* after);
 
+/* The mean-field update of the hierarchical block (K Gaussians whose means share a Normal-Wishart hyper-posterior): nb_iter rounds of
+ * "component means given the hyper-posterior mean, pooled hyper-posterior given the means" —
+ * TiedGaussiansWithHierarchicalNormalWisharts.meanfield_update, bayesian.py:661-689 with the pooled block of :670-682.
+ *   in : kap (K) the prior's kappas; the hyper-prior (m0 (D), kappa0, psi0_inv (D,D) = inv(psi0), nu0); xk (K,D), nk (K),
+ *        sxx_sum (D,D) = sum_k sum_n r_kn x x' — the statistics of the last pass; mu_q (D) the hyper-posterior mean to start from
+ *   out: mu_q (D), kappa_q, psi_q (D,D), nu_q — the hyper-posterior; post_mus (K,D), post_kappas (K) — the components' posterior.
+ * MIMO_E_INVALID if a pooled block is not positive definite (the caller then takes the NumPy route). */
+int mimo_host_hier_vi(int K, int D, int nb_iter, const double* kap, const double* m0, double kappa0, const double* psi0_inv,
+                      double nu0, const double* xk, const double* nk, const double* sxx_sum, double* mu_q, double* post_mus,
+                      double* post_kappas, double* kappa_q, double* psi_q, double* nu_q);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

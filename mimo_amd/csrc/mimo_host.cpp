@@ -511,6 +511,59 @@ MIMO_NO_CONTRACT_FN int mimo_host_legacy_draws(uint32_t* mt_key, int* mt_pos, in
   });
 }
 
+int mimo_host_hier_vi(int K, int D, int nb_iter, const double* kap, const double* m0, double kappa0, const double* psi0_inv,
+                      double nu0, const double* xk, const double* nk, const double* sxx_sum, double* mu_q, double* post_mus,
+                      double* post_kappas, double* kappa_q, double* psi_q, double* nu_q) {
+  return guarded_host([&]() -> int {
+  if (K < 1 || D < 1 || nb_iter < 1 || !kap || !m0 || !psi0_inv || !xk || !nk || !sxx_sum || !mu_q || !post_mus || !post_kappas ||
+      !kappa_q || !psi_q || !nu_q)
+    return MIMO_E_INVALID;
+  const size_t DD = (size_t)D * D;
+  std::vector<double> pooled(DD), A(DD), scratch(3 * DD), wsh(K), num(D);
+  std::vector<v4d> work(2 * DD);
+  double ksum = 0.0, nusum = 0.0;
+  for (int k = 0; k < K; ++k) {
+    post_kappas[k] = kap[k] + nk[k];
+    wsh[k] = kappa0 * kap[k] / (kappa0 + kap[k]);
+    ksum += kap[k] + kappa0;
+    nusum += nu0 + nk[k] + 1.0;
+  }
+  for (size_t i = 0; i < DD; ++i) pooled[i] = psi0_inv[i] + sxx_sum[i] / K;
+  for (int it = 0; it < nb_iter; ++it) {
+    // component means given the hyper-posterior mean, then the pooled hyper-posterior given the means (bayesian.py:661-689)
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < D; ++i)
+        post_mus[(size_t)k * D + i] = (kap[k] * mu_q[i] + xk[(size_t)k * D + i]) / post_kappas[k];
+    for (int i = 0; i < D; ++i) num[i] = 0.0;
+    for (size_t i = 0; i < DD; ++i) A[i] = 0.0;
+    std::vector<double> dv(D);
+    for (int k = 0; k < K; ++k) {
+      const double* __restrict__ m = post_mus + (size_t)k * D;
+      const double* __restrict__ x = xk + (size_t)k * D;
+      double* __restrict__ d = dv.data();
+      for (int i = 0; i < D; ++i) { num[i] += kap[k] * m[i] + kappa0 * m0[i]; d[i] = m0[i] - m[i]; }
+      for (int i = 0; i < D; ++i) {
+        const double wd = wsh[k] * d[i], mi = m[i], xi = x[i], nm = nk[k] * m[i];
+        double* __restrict__ Ai = A.data() + (size_t)i * D;
+        for (int j = i; j < D; ++j)      // upper triangle of shrink - cross - cross' + sum_k n_k m m'
+          Ai[j] += wd * d[j] - mi * x[j] - xi * m[j] + nm * m[j];
+      }
+    }
+    for (int i = 0; i < D; ++i) mu_q[i] = num[i] / ksum;
+    for (int i = 0; i < D; ++i)
+      for (int j = i; j < D; ++j) A[i * D + j] = pooled[i * D + j] + A[i * D + j] / K;
+    const double* Ain[4] = {A.data(), A.data(), A.data(), A.data()};
+    double* Aout[4] = {psi_q, scratch.data(), scratch.data() + DD, scratch.data() + 2 * DD};
+    double sl[4];
+    spd_inverse4(Ain, D, Aout, sl, work.data());
+    if (std::isnan(sl[0])) return MIMO_E_INVALID;
+  }
+  *kappa_q = ksum / K;
+  *nu_q = nusum / K;
+  return MIMO_OK;
+  });
+}
+
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {

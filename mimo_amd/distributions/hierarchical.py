@@ -13,6 +13,8 @@ canonical form  c_k + b_k.x - 1/2 x'W x  with one shared W = nu psi, so the E-st
 """
 import copy
 
+import ctypes as C
+
 import numpy as np
 import numpy.random as npr
 import scipy.linalg as sla
@@ -252,15 +254,38 @@ class TiedGaussiansWithHierarchicalNormalWisharts:
     # ---- mean field (bayesian.py:661-689) -----------------------------------------------------------
     def meanfield_update(self, data, weights=None, nb_iter=25, stats=None):
         xk, nk, xxTk, _ = self._stats(data, weights, stats)
-        kap = self.prior.kappas
-        pooled = self._pooled(xxTk)
-        for _ in range(nb_iter):
-            self.posterior.kappas = kap + nk
-            self.posterior.mus = (kap[:, None] * self.hyper_posterior.gaussian.mu[None, :] + xk) / (kap + nk)[:, None]
-            self.hyper_posterior.params = self._hyper_params(self.posterior.mus, xk, nk, xxTk, pooled)
+        if not self._meanfield_native(xk, nk, xxTk, nb_iter):
+            kap = self.prior.kappas
+            pooled = self._pooled(xxTk)
+            for _ in range(nb_iter):
+                self.posterior.kappas = kap + nk
+                self.posterior.mus = (kap[:, None] * self.hyper_posterior.gaussian.mu[None, :] + xk) / (kap + nk)[:, None]
+                self.hyper_posterior.params = self._hyper_params(self.posterior.mus, xk, nk, xxTk, pooled)
         _, lmbda = self.hyper_posterior.mode()
         self.likelihood.mus = self.posterior.mode()
         self.likelihood.lmbdas = np.stack(self.size * [lmbda])
+
+    def _meanfield_native(self, xk, nk, xxTk, nb_iter):
+        """mimo_host_hier_vi: the nb_iter rounds in one native call (the loop above costs ~0.1 ms of NumPy per round)."""
+        from mimo_amd.distributions.composite import _native, _c64, _p
+        lib = _native()
+        hp, hq, K, D = self.hyper_prior, self.hyper_posterior, self.size, self.dim
+        if lib is None or nb_iter < 1 or type(hp) is not NormalWishart or type(hq) is not NormalWishart:
+            return False
+        kap, m0, xk, nk = _c64(self.prior.kappas), _c64(hp.gaussian.mu), _c64(xk), _c64(nk)
+        sxx = _c64(np.sum(xxTk, axis=0))
+        psi0_inv = _c64(np.linalg.inv(hp.wishart.psi))
+        mu_q = np.array(hq.gaussian.mu, dtype=np.float64)
+        if kap.shape != (K,) or m0.shape != (D,) or xk.shape != (K, D) or nk.shape != (K,) or sxx.shape != (D, D) or mu_q.shape != (D,):
+            return False
+        mus, kappas, psi = np.empty((K, D)), np.empty(K), np.empty((D, D))
+        kq, nq = C.c_double(), C.c_double()
+        if lib.mimo_host_hier_vi(K, D, int(nb_iter), _p(kap), _p(m0), float(hp.kappa), _p(psi0_inv), float(hp.wishart.nu), _p(xk),
+                                 _p(nk), _p(sxx), _p(mu_q), _p(mus), _p(kappas), C.addressof(kq), _p(psi), C.addressof(nq)) != 0:
+            return False
+        self.posterior.kappas, self.posterior.mus = kappas, mus
+        hq.params = (mu_q, kq.value, psi, nq.value)
+        return True
 
     # ---- stochastic mean field (bayesian.py:691-732) --------------------------------------------------
     def meanfield_sgd(self, data, weights, nb_iter, scale, step_size, stats=None):

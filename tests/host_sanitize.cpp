@@ -42,6 +42,16 @@ int main() {
                                     b2.data(), e2.data(), W2.data(), e4.data(), vlb.data());
       if (rc != 0 || !std::isfinite(vlb[0] + vlb[1] + ct[K - 1])) { printf("sweep K=%d D=%d tied=%d rc=%d\n", K, D, tied, rc); return 1; }
     }
+    {   // hierarchical update: five rounds from the statistics above (xk := a, nk := b, sum of second moments := the first block of c, scaled)
+      const size_t DD = (size_t)D * D;
+      std::vector<double> kp(K, 0.3), m0(D, 0.1), p0(DD, 0.0), sx2(DD), muq(D, 0.0), pm(K * D), pk(K), psq(DD);
+      double kq = 0, nq = 0;
+      for (int i = 0; i < D; ++i) p0[(size_t)i * D + i] = 1.0;
+      for (size_t i = 0; i < DD; ++i) sx2[i] = c[i] * K;
+      rc = mimo_host_hier_vi(K, D, 5, kp.data(), m0.data(), 0.5, p0.data(), D + 2.0, a.data(), b.data(), sx2.data(), muq.data(), pm.data(),
+                             pk.data(), &kq, psq.data(), &nq);
+      if (rc != 0 && rc != -1) { printf("hier K=%d D=%d rc=%d\n", K, D, rc); return 1; }      // (not positive definite is a legal answer here)
+    }
     {   // the tied flavour on the same natural parameters (its pooled block is an average of SPD blocks)
       std::vector<double> natc((size_t)K * D * D), tp((size_t)K * D * D), tm(K * D), tn(K), th(K);
       rc = mimo_host_nw_vi_tied(K, D, a.data(), b.data(), c.data(), d.data(), tm.data(), tp.data(), tn.data(), th.data(),

@@ -520,3 +520,36 @@ def test_reference_order_draws_are_the_per_component_calls():
         assert np.array_equal(diag[k], np.array([(np.random.chisquare(nus[k] - i, size=1) ** 0.5)[0] for i in range(D)]))
         assert np.array_equal(eps[k], np.random.normal(size=extra))
     assert np.array_equal(state[1], np.random.get_state()[1]) and state[2:] == np.random.get_state()[2:]
+
+
+@pytest.mark.parametrize("K,D,nb_iter", [(1, 1, 1), (4, 2, 5), (64, 16, 5), (7, 9, 25), (50, 3, 2)])
+def test_hierarchical_update_native_equals_numpy(K, D, nb_iter):
+    """mimo_host_hier_vi against the NumPy rounds of TiedGaussiansWithHierarchicalNormalWisharts.meanfield_update
+    (bayesian.py:661-689 of the reference, pinned by the hierarchical golden traces)."""
+    from mimo_amd.distributions import (NormalWishart, TiedGaussiansWithScaledPrecision,
+                                        TiedGaussiansWithHierarchicalNormalWisharts)
+    rs = np.random.default_rng(K * 31 + D)
+    A = rs.standard_normal((D, D))
+    outs = []
+    for native in (True, False):
+        np.random.seed(3)
+        hyper = NormalWishart(D, rs.standard_normal(D) * 0 + 0.3, 0.7, A @ A.T / D + np.eye(D), D + 2.5)
+        prior = TiedGaussiansWithScaledPrecision(K, D, kappas=np.linspace(0.01, 2., K))
+        m = TiedGaussiansWithHierarchicalNormalWisharts(K, D, hyper, prior)
+        X = np.random.default_rng(5).standard_normal((40 * K, D)) * 1.5 + 0.5
+        lab = np.random.default_rng(6).integers(0, K, size=len(X))
+        R = np.zeros((K, len(X))); R[lab, np.arange(len(X))] = 1.
+        xk = R @ X
+        nk = R.sum(axis=1)
+        xxT = np.einsum('kn,nd,nl->kdl', R, X, X)
+        old = composite.NATIVE_HOST
+        composite.NATIVE_HOST = native
+        try:
+            m.meanfield_update(None, stats=Stats([xk, nk, xxT, nk]), nb_iter=nb_iter)
+            m.meanfield_update(None, stats=Stats([xk, nk, xxT, nk]), nb_iter=nb_iter)      # (starts from the previous hyper-posterior)
+        finally:
+            composite.NATIVE_HOST = old
+        outs.append((m.posterior.mus, m.posterior.kappas) + tuple(m.hyper_posterior.params) + tuple(m.canonical_expected())
+                    + (m.likelihood.mus, m.likelihood.lmbdas))
+    for a, b in zip(*outs):
+        assert rel_err(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) < 1e-11
