@@ -278,3 +278,17 @@ def test_plan_with_data_agrees_with_the_shape_router(engine):
                 assert lib.mimo_plan_shape(D, K, 0, N, 1 if gibbs else 0, out, None, 0) == 0
                 p = engine.plan(K, gibbs=gibbs)
                 assert p["kind"] == kinds[out[0]] and p["kernels_per_pass"] == out[1] and p["data_passes"] == out[4], (D, K, gibbs, p, list(out))
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() — what the driver runs on a fresh box before the bench — inside the suite: its routing assertions
+    (which kernel family serves which of its shapes) go stale silently otherwise, as they did when the mid kernels took Dz = 20, K = 80."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
