@@ -58,7 +58,7 @@ def legacy_draws(n_before, shapes, n_after):
     shapes = np.ascontiguousarray(shapes, dtype=np.float64)
     K, G = shapes.shape
     before, gam, after = np.empty((K, n_before)), np.empty((K, G)), np.empty((K, n_after))
-    lib = _native_lib()
+    lib = _native_lib() if K >= _NATIVE_MIN_BLOCKS else None
     # (handing numpy's state over and back costs ~0.1 ms — numpy copies the 624 key words element by element — and a block costs three
     # Python calls of ~2.4 us: below ~16 blocks the calls are cheaper)
     if lib is not None and K >= _NATIVE_MIN_BLOCKS and np.all(shapes >= 0.):
@@ -90,7 +90,15 @@ def bartlett_variates_in_reference_order(nus, D, extra):
     generator (both operations exact in float64), and a vector of shapes is walked in order, so the K blocks are one
     `legacy_draws` call (tests/test_host_native.py holds the stream against the per-call form).
     Returns (lower (K, n_tril), diag (K, D), eps (K, extra))."""
-    n_tril = D * (D - 1) // 2
+    K, n_tril = len(nus), D * (D - 1) // 2
+    if K < _NATIVE_MIN_BLOCKS:            # a handful of blocks: the calls themselves (no wrapper in front of a 0.1 ms sweep)
+        lower, diag, eps = np.empty((K, n_tril)), np.empty((K, D)), np.empty((K, extra))
+        dof_off = np.arange(D)
+        for k in range(K):
+            lower[k] = npr.normal(size=n_tril)
+            diag[k] = npr.chisquare(nus[k] - dof_off)
+            eps[k] = npr.normal(size=extra)
+        return lower, np.sqrt(diag), eps
     dof = np.asarray(nus, dtype=float)[:, None] - np.arange(D)[None, :]
     lower, gam, eps = legacy_draws(n_tril, dof / 2.0, extra)
     return lower, np.sqrt(2.0 * gam), eps
