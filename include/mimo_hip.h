@@ -368,6 +368,19 @@ int mimo_host_hier_vi(int K, int D, int nb_iter, const double* kap, const double
                       double nu0, const double* xk, const double* nk, const double* sxx_sum, double* mu_q, double* post_mus,
                       double* post_kappas, double* kappa_q, double* psi_q, double* nu_q);
 
+/* The same draws on numpy's generator IN PLACE: mt_key / mt_pos point into the bit generator's own state
+ * (numpy.random.mtrand._rand._bit_generator.ctypes.state_address: uint32 key[624], int pos), so nothing is copied in or out
+ * (get_state / set_state cost 0.1 ms together — numpy converts the key element by element).  The cached second gaussian lives in
+ * RandomState, out of reach: the caller passes what it found there (has_gauss, gauss — after emptying the cache), and when the
+ * draws end with a gaussian cached, the call writes the state it reached to final_state (key[624], pos), leaves the key / position
+ * where the PAIR behind that gaussian was begun and sets *redraw: one numpy.random.standard_normal() by the caller reproduces the
+ * pair, returns the half that was used and caches the other; the caller then copies final_state over the generator's state (uniforms
+ * drawn after the pair) — numpy ends in exactly the state the per-component calls would have left
+ * (mimo_amd/distributions/wishart.py: legacy_draws). */
+int mimo_host_legacy_draws_inplace(uint32_t* mt_key, int* mt_pos, int has_gauss, double gauss, int K, int n_before,
+                                   int n_gamma, int n_after, const double* shapes, double* before, double* gammas,
+                                   double* after, int* redraw, uint32_t* final_state);
+
 /* Matrix-Normal-Wishart blocks (experts y | x).  Replaces per sweep: MatrixNormalWishart.nat_to_std
  * (composite.py:594-599), expected_statistics (composite.py:635-647) and the canonical form of
  * StackedLinearGaussiansWithMatrixNormalWisharts.expected_log_likelihood (bayesian.py:933-947).

@@ -190,8 +190,14 @@ struct LegacyStream {
   int pos;
   int has_gauss;
   double gauss;
+  // where the generator stood when the pair behind the cached gaussian was begun (mimo_host_legacy_draws_inplace hands the cached
+  // value back to numpy by rewinding to that point and letting numpy draw the pair again): position, refills seen so far, and the
+  // key as it was before the latest refill (one 2.5 KB copy per 624 outputs)
+  uint32_t* backup = nullptr;     // [624] or null: no bookkeeping
+  int refills = 0, pair_pos = 0, pair_refills = 0, pairs = 0;
 
   void refill() {
+    if (backup) { std::memcpy(backup, key, 624 * sizeof(uint32_t)); ++refills; }
     constexpr int N = 624, M = 397;
     constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
     int kk = 0;
@@ -231,6 +237,7 @@ struct LegacyStream {
       return t;
     }
     double f, x1, x2, r2;
+    pair_pos = pos; pair_refills = refills; ++pairs;
     do {
       x1 = 2.0 * next_double() - 1.0;
       x2 = 2.0 * next_double() - 1.0;
@@ -560,6 +567,44 @@ int mimo_host_hier_vi(int K, int D, int nb_iter, const double* kap, const double
   }
   *kappa_q = ksum / K;
   *nu_q = nusum / K;
+  return MIMO_OK;
+  });
+}
+
+MIMO_NO_CONTRACT_FN int mimo_host_legacy_draws_inplace(uint32_t* mt_key, int* mt_pos, int has_gauss, double gauss, int K, int n_before,
+                                                       int n_gamma, int n_after, const double* shapes, double* before, double* gammas,
+                                                       double* after, int* redraw, uint32_t* final_state) {
+  return guarded_host([&]() -> int {
+  MIMO_NO_CONTRACT
+  if (!mt_key || !mt_pos || !redraw || !final_state || K < 0 || n_before < 0 || n_gamma < 0 || n_after < 0 || *mt_pos < 0 || *mt_pos > 624 ||
+      (n_gamma && !shapes) || (n_before && !before) || (n_gamma && !gammas) || (n_after && !after))
+    return MIMO_E_INVALID;
+  for (size_t i = 0; i < (size_t)K * n_gamma; ++i)
+    if (!(shapes[i] >= 0.0)) return MIMO_E_INVALID;
+  std::vector<uint32_t> backup(624);
+  LegacyStream g{mt_key, *mt_pos, has_gauss, gauss};
+  g.backup = backup.data();
+  for (int k = 0; k < K; ++k) {
+    for (int i = 0; i < n_before; ++i) before[(size_t)k * n_before + i] = 0.0 + 1.0 * g.gauss_next();
+    for (int i = 0; i < n_gamma; ++i) gammas[(size_t)k * n_gamma + i] = g.standard_gamma(shapes[(size_t)k * n_gamma + i]);
+    for (int i = 0; i < n_after; ++i) after[(size_t)k * n_after + i] = 0.0 + 1.0 * g.gauss_next();
+  }
+  *redraw = 0;
+  if (g.has_gauss) {
+    // a gaussian is left cached: numpy must hold it.  Rewind to where its pair was begun; the caller draws one normal from numpy,
+    // which produces the pair again, returns the half already used here and caches this one.  (No pair begun here: the cached value
+    // is the caller's own, untouched — a request without a single gaussian, which the caller keeps away from this entry point.)
+    if (g.pairs == 0) return MIMO_E_STATE;
+    // (uniforms may have been drawn after that pair: the state reached is handed out in final_state — key[624], pos — for the caller
+    // to write back once numpy holds the gaussian)
+    std::memcpy(final_state, mt_key, 624 * sizeof(uint32_t));
+    final_state[624] = (uint32_t)g.pos;
+    if (g.refills > g.pair_refills) std::memcpy(mt_key, backup.data(), 624 * sizeof(uint32_t));   // (at most one refill since the pair began:
+    *mt_pos = g.pair_pos;                                                                          //  a refill yields 624 outputs)
+    *redraw = 1;
+    return MIMO_OK;
+  }
+  *mt_pos = g.pos;
   return MIMO_OK;
   });
 }

@@ -47,26 +47,53 @@ def wishart_rvs(psi, nu):
     return T @ T.T
 
 
-_NATIVE_MIN_BLOCKS = 16
+_NATIVE_MIN_BLOCKS = 4
 
 
 def legacy_draws(n_before, shapes, n_after):
     """Per block k of `shapes` (K, G): numpy.random.normal(size=n_before), numpy.random.standard_gamma(shapes[k]) (G values, in
     order), numpy.random.normal(size=n_after) — the variates and the final state of numpy.random's global generator are those of
-    the 3 K Python calls; computed by mimo_host_legacy_draws (a restatement of numpy's legacy MT19937 stream) when the library is
-    there and the global generator is the stock one.  -> (before (K, n_before), gammas (K, G), after (K, n_after))."""
+    the 3 K Python calls; computed by mimo_host_legacy_draws_inplace (a restatement of numpy's legacy MT19937 stream, working on the
+    bit generator's own key: 5 us of hand-over) when the library is there and the global generator is the stock one — else by
+    mimo_host_legacy_draws through get_state / set_state (0.1 ms: numpy converts the key element by element), else by the calls
+    themselves.  Not atomic against other threads drawing from numpy.random meanwhile — like the loop it replaces.
+    -> (before (K, n_before), gammas (K, G), after (K, n_after))."""
     shapes = np.ascontiguousarray(shapes, dtype=np.float64)
     K, G = shapes.shape
     before, gam, after = np.empty((K, n_before)), np.empty((K, G)), np.empty((K, n_after))
     lib = _native_lib() if K >= _NATIVE_MIN_BLOCKS else None
-    # (handing numpy's state over and back costs ~0.1 ms — numpy copies the 624 key words element by element — and a block costs three
-    # Python calls of ~2.4 us: below ~16 blocks the calls are cheaper)
-    if lib is not None and K >= _NATIVE_MIN_BLOCKS and np.all(shapes >= 0.):
+    if lib is not None and np.all(shapes >= 0.):
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        mt = _numpy_mt()
+        if mt is not None and (n_before or n_after or np.any(shapes > 1.)):       # (at least one gaussian will be drawn)
+            # numpy's own state, in place: empty RandomState's gaussian cache (learning what was in it), draw natively on the bit
+            # generator's key, hand a gaussian that is left over back by letting numpy draw its pair again (mimo_hip.h)
+            rs, addr = mt
+            state = _MTState.from_address(addr)
+            saved, pos0, word0 = C.string_at(addr, C.sizeof(_MTState)), state.pos, state.key[0]
+            g0 = rs.standard_normal()
+            if state.pos == pos0 and state.key[0] == word0:
+                had = 1                                   # nothing was consumed: g0 was the cached value, the cache is empty now
+            else:
+                rs.standard_normal()                      # a pair was drawn: take its second half out of the cache, ...
+                C.memmove(addr, saved, len(saved))        # ... and put the generator back where it stood
+                had, g0 = 0, 0.0
+            redraw, final = C.c_int(0), _MTState()
+            rc = lib.mimo_host_legacy_draws_inplace(addr, addr + _MTState.pos.offset, had, g0, K, n_before, G, n_after,
+                                                    ptr(shapes), ptr(before), ptr(gam), ptr(after), C.byref(redraw), C.addressof(final))
+            if rc == 0:
+                if redraw.value:
+                    rs.standard_normal()                  # numpy draws the last pair again and keeps its second half ...
+                    C.memmove(addr, C.addressof(final), C.sizeof(_MTState))     # ... then stands where the draws ended
+                return before, gam, after
+            C.memmove(addr, saved, len(saved))            # (never seen: back to the state found, cached gaussian included, ...
+            if had:                                       # ... and to the copying route below)
+                st = npr.get_state()
+                npr.set_state((st[0], st[1], st[2], 1, g0))
         st = npr.get_state()
         if st[0] == 'MT19937':
             key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
             pos, has, g = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
-            ptr = lambda a: a.ctypes.data_as(C.c_void_p)
             if lib.mimo_host_legacy_draws(ptr(key), C.byref(pos), C.byref(has), C.byref(g), K, n_before, G, n_after,
                                           ptr(shapes), ptr(before), ptr(gam), ptr(after)) == 0:
                 npr.set_state(('MT19937', key, pos.value, has.value, g.value))
@@ -76,6 +103,23 @@ def legacy_draws(n_before, shapes, n_after):
         gam[k] = npr.standard_gamma(shapes[k])
         after[k] = npr.normal(size=n_after)
     return before, gam, after
+
+
+class _MTState(C.Structure):
+    """numpy/random/src/mt19937/mt19937.h: mt19937_state."""
+    _fields_ = [("key", C.c_uint32 * 624), ("pos", C.c_int)]
+
+
+def _numpy_mt():
+    """(numpy.random's global RandomState, address of its bit generator's MT19937 state) while both are the stock ones, else None."""
+    rs = getattr(npr.mtrand, '_rand', None)
+    bg = getattr(rs, '_bit_generator', None)
+    if type(rs) is not npr.RandomState or type(bg) is not np.random.MT19937:
+        return None
+    try:
+        return rs, int(bg.ctypes.state_address)
+    except Exception:
+        return None
 
 
 def _native_lib():

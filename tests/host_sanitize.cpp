@@ -95,6 +95,14 @@ int main() {
     for (int k = 0; k < K; ++k) for (int i = 0; i < ng; ++i) sh[(size_t)k * ng + i] = i == 0 ? 1.0 : i == 1 ? 0.0 : i == 2 ? 0.07 * (k + 1) : 0.4 * k + i;
     int rc = mimo_host_legacy_draws(key.data(), &pos, &has, &gs, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data());
     if (rc != 0 || !std::isfinite(og[(size_t)K * ng - 1]) || pos < 0 || pos > 624) { printf("legacy draws rc=%d\n", rc); return 1; }
+    {   // ... and the in-place form: the pair rewind with and without a refill since the pair began
+      for (int start : {0, 3, 617, 621, 624}) {
+        std::vector<uint32_t> k2(key), fin(625);
+        int p2 = start, redraw = -1;
+        rc = mimo_host_legacy_draws_inplace(k2.data(), &p2, start & 1, 0.25, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data(), &redraw, fin.data());
+        if (rc != 0 || redraw < 0 || redraw > 1 || p2 < 0 || p2 > 624) { printf("legacy in place start=%d rc=%d\n", start, rc); return 1; }
+      }
+    }
     sh[3] = -1.0;
     if (mimo_host_legacy_draws(key.data(), &pos, &has, &gs, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data()) >= 0) { printf("negative shape accepted\n"); return 1; }
   }

@@ -553,3 +553,32 @@ def test_hierarchical_update_native_equals_numpy(K, D, nb_iter):
                     + (m.likelihood.mus, m.likelihood.lmbdas))
     for a, b in zip(*outs):
         assert rel_err(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) < 1e-11
+
+
+def test_native_legacy_stream_in_place_from_arbitrary_generator_positions(monkeypatch):
+    """The in-place route (mimo_host_legacy_draws_inplace on numpy's own key; the cached gaussian handed back by letting numpy draw
+    its pair again) from generator positions all over the 624-word cycle — refills inside the draws, inside the last pair, cached
+    gaussians going in and coming out — 600 layouts against numpy.random itself: variates and state."""
+    from mimo_amd.distributions import wishart
+    from mimo_amd.distributions.wishart import legacy_draws
+    monkeypatch.setattr(wishart, "_NATIVE_MIN_BLOCKS", 1)
+    assert wishart._numpy_mt() is not None
+    for seed in range(600):
+        rs = np.random.default_rng(10_000 + seed)
+        K, G, nb, na = int(rs.integers(1, 30)), int(rs.integers(0, 6)), int(rs.integers(0, 9)), int(rs.integers(0, 5))
+        kind = seed % 5
+        shapes = (rs.uniform(0.01, 1.0, (K, G)) if kind == 0 else rs.uniform(0.5, 30., (K, G)) if kind == 1 else
+                  np.where(rs.random((K, G)) < 0.3, 1.0, rs.uniform(0., 3., (K, G))) if kind == 2 else
+                  rs.uniform(1.0, 1.2, (K, G)) if kind == 3 else (rs.integers(1, 60, (K, 1)) - np.arange(G)[None, :] * 0.5).clip(0.0))
+        pre = int(rs.integers(0, 700))
+        outs = []
+        for fn in (_legacy_reference, legacy_draws):
+            np.random.seed(seed)
+            np.random.random(pre)
+            if seed % 3 == 0:
+                np.random.normal()
+            got = fn(nb, shapes, na)
+            outs.append((got, np.random.get_state(), np.random.random(2), np.random.normal(size=3)))
+        (w, sw, uw, nw), (g, sg, ug, ng) = outs
+        assert all(np.array_equal(x, y) for x, y in zip(w, g)), seed
+        assert np.array_equal(sw[1], sg[1]) and sw[2:] == sg[2:] and np.array_equal(uw, ug) and np.array_equal(nw, ng), seed
