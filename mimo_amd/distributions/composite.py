@@ -99,6 +99,16 @@ class StackedNormalWisharts:
             v = memo[name] = fn()
             return v
 
+    def _set_memo(self, **values):
+        """the derived quantities of the parameters just assigned, in one go (what a sequence of _cached(name, lambda: value)
+        calls would store; each of those recomputes the key of the four parameter arrays)."""
+        params = self.params
+        key = tuple(map(id, params))
+        memo = self.__dict__.get('_memo')
+        if memo is None or memo.get('key') != key:
+            memo = self._memo = {'key': key, 'refs': params}
+        memo.update(values)
+
     @property
     def nat_param(self):
         return self._cached('nat', lambda: self.std_to_nat(self.params))
@@ -107,7 +117,7 @@ class StackedNormalWisharts:
     def nat_param(self, natparam):
         if not self._assign_native(natparam):
             self.params = self.nat_to_std(natparam)
-        self._cached('nat', lambda: Stats(natparam))   # the exact natural parameters just assigned
+        self._set_memo(nat=Stats(natparam))   # the exact natural parameters just assigned
 
     def _assign_native(self, natparam):
         """mimo_host_nw_vi: standard parameters + every derived quantity the sweep needs, in one call."""
@@ -124,10 +134,7 @@ class StackedNormalWisharts:
                                _p(cc), _p(bb), _p(W), _p(E2), _p(E4)) != 0:
             return False
         self.params = (mus, b.copy(), psis, nus)
-        self._cached('hld', lambda: hld)
-        self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
-        self._cached('canon', lambda: (cc, bb, W))
-        self._cached('native', lambda: True)
+        self._set_memo(hld=hld, estats=(bb, E2, - 0.5 * W, E4), canon=(cc, bb, W), native=True)
         return True
 
     def native_vlb(self, prior):
@@ -317,6 +324,7 @@ class StackedMatrixNormalWisharts:
         self.Ms, self.Ks, self.psis, self.nus = (np.asarray(v, dtype=float) for v in values)
 
     _cached = StackedNormalWisharts._cached
+    _set_memo = StackedNormalWisharts._set_memo
 
     @property
     def nat_param(self):
@@ -326,7 +334,7 @@ class StackedMatrixNormalWisharts:
     def nat_param(self, natparam):
         if not self._assign_native(natparam):
             self.params = self.nat_to_std(natparam)
-        self._cached('nat', lambda: Stats(natparam))
+        self._set_memo(nat=Stats(natparam))
 
     def _assign_native(self, natparam):
         """mimo_host_mnw_vi (affine and non-affine canonical forms are both kept)."""
@@ -345,9 +353,7 @@ class StackedMatrixNormalWisharts:
                                 _p(cc), _p(bb), _p(W), _p(E1), _p(E2), _p(E4)) != 0:
             return False
         self.params = (Ms, b.copy(), psis, nus)
-        self._cached('hld', lambda: hld)
-        self._cached('estats', lambda: (E1, E2, - 0.5 * nus[:, None, None] * psis, E4))
-        self._cached('canon_affine', lambda: (cc, bb, W))
+        self._set_memo(hld=hld, estats=(E1, E2, - 0.5 * nus[:, None, None] * psis, E4), canon_affine=(cc, bb, W))
         return True
 
     def std_to_nat(self, params):
@@ -509,11 +515,8 @@ class TiedNormalWisharts(_TiedNatParam, StackedNormalWisharts):
             return False
         kap = b.copy()
         self.params = (mus, kap, psis, nus)
-        self._cached('nat', lambda: Stats([kap[:, None] * mus, kap, nat_c, nus - D]))
-        self._cached('hld', lambda: hld)
-        self._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
-        self._cached('canon', lambda: (cc, bb, W))
-        self._cached('native', lambda: True)
+        self._set_memo(nat=Stats([kap[:, None] * mus, kap, nat_c, nus - D]), hld=hld, estats=(bb, E2, - 0.5 * W, E4),
+                       canon=(cc, bb, W), native=True)
         return True
 
 

@@ -60,14 +60,8 @@ def gmm_vi_sweep(gating, components, stats, counts):
     qc, psis, W = qc.reshape(K, D, D), psis.reshape(K, D, D), W.reshape(K, D, D)
     gating.posterior.alphas = alpha
     post.params = (mus, qb, psis, nus)
-    if tied:
-        post._cached('nat', lambda: Stats([qb[:, None] * mus, qb, nat_c.reshape(K, D, D), nus - D]))
-    else:
-        post._cached('nat', lambda: Stats([qa, qb, qc, qd]))
-    post._cached('hld', lambda: hld)
-    post._cached('estats', lambda: (bb, E2, - 0.5 * W, E4))
-    post._cached('canon', lambda: (cc, bb, W))
-    post._cached('native', lambda: True)
+    nat = Stats([qb[:, None] * mus, qb, nat_c.reshape(K, D, D), nus - D]) if tied else Stats([qa, qb, qc, qd])
+    post._set_memo(nat=nat, hld=hld, estats=(bb, E2, - 0.5 * W, E4), canon=(cc, bb, W), native=True)
 
     def prior_terms():
         rc = lib.mimo_host_gmm_vi_bound(K, D, int(tied), _p(alpha0), p_alpha, p_elp, _p(pa), _p(pb), _p(pc), _p(pd), _p(plz),
