@@ -8,8 +8,13 @@
 // Reference semantics: mimo/distributions/composite.py:50-72,106-118 (Normal-Wishart),
 // :577-599,635-647 (Matrix-Normal-Wishart), wishart.py:139-143, bayesian.py:287-301,933-947.
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
+#include <pthread.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -119,23 +124,101 @@ int guarded_host(F&& f) noexcept {
 
 std::atomic<int> g_fail_thread_start{0};   // mimo_host_debug_fault(4): the next helper-thread start throws
 
+// ---- helper threads of the batched routines --------------------------------------------------------------------------------
+// The K small dense problems of a sweep are split over threads when there is enough of them (K = 128, D = 32: 0.72 ms on one thread,
+// 0.37 ms on eight).  The helpers persist: a pool created on first use (at most 7), asleep on a condition variable between calls; a call
+// wakes what it needs with one notify, hands the groups out through one counter and waits for the helpers that took part (creating
+// std::threads per call cost the CALLER ~15 us each).  The pool is a leaked singleton (threads
+// blocked in it die with the process); after fork() the child starts its own on first use (pthread_atfork: the parent's threads do not
+// exist there); a helper that cannot be created, or cannot allocate its scratch, leaves its share to the others.
+class HelperPool {
+ public:
+  static HelperPool* get(int want) {
+    std::lock_guard<std::mutex> lk(create_mu());
+    HelperPool*& p = instance();
+    if (!p) {
+      static std::once_flag once;
+      std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance() = nullptr; new (&create_mu()) std::mutex(); }); });
+      p = new (std::nothrow) HelperPool();
+    }
+    if (p) p->grow(want);
+    return p;
+  }
+  int size() const { return (int)threads_.size(); }
+  // runs job() on the caller and on up to `helpers` pool threads (<= size()); returns when every thread that took it is done.
+  // job() returns when there is nothing left to hand out, so helpers that have not woken by the time the caller's own share is
+  // finished are left asleep.  A second caller (another Python thread inside another routine) finds the pool busy and runs alone.
+  void run(int helpers, const std::function<void()>& job) {
+    std::unique_lock<std::mutex> call(call_mu_, std::try_to_lock);
+    if (!call.owns_lock()) { job(); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &job; wanted_ = helpers; taken_ = 0; finished_ = 0; ++generation_;
+    }
+    cv_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lk(mu_);
+    wanted_ = taken_;                                      // late wakers find nothing to take
+    done_cv_.wait(lk, [&] { return finished_ == taken_; });
+    job_ = nullptr;
+  }
+
+ private:
+  static HelperPool*& instance() { static HelperPool* p = nullptr; return p; }
+  static std::mutex& create_mu() { static std::mutex* m = new std::mutex(); return *m; }
+  void grow(int want) {
+    want = std::min(want, 7);
+    while ((int)threads_.size() < want) {
+      try {
+        threads_.emplace_back([this] { loop(); });
+        threads_.back().detach();
+      } catch (...) { break; }                             // fewer helpers than wanted: the callers cope
+    }
+  }
+  void loop() {
+    int seen = 0;
+    for (;;) {
+      const std::function<void()>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen && taken_ < wanted_; });
+        seen = generation_;
+        ++taken_;
+        job = job_;
+      }
+      if (job) (*job)();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        ++finished_;
+      }
+      done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void()>* job_ = nullptr;
+  int wanted_ = 0, taken_ = 0, finished_ = 0, generation_ = 0;
+};
+
 // body(k0, count, work, Cbuf) handles components k0 .. k0+count-1 (count <= 4) with per-thread scratch
 // (work: 2 n n v4d, Cbuf: 4 n n doubles) and returns false on a non-SPD block.
-// The groups are handed out through one counter, so the call completes on however many threads did start: a
-// helper that cannot be created (std::system_error) or cannot allocate its scratch leaves its share to the
-// others, and every thread that was started is joined before the function returns or rethrows — a joinable
-// std::thread is never destroyed (that would be std::terminate).  Groups are independent, so the result does
-// not depend on which thread ran which group.
+// The groups are handed out through one counter, so the call completes on however many threads take part: a helper that is
+// missing (pool smaller than asked, mimo_host_debug_fault(4)) or cannot allocate its scratch leaves its share to the others.
+// Groups are independent, so the result does not depend on which thread ran which group.
 template <typename F>
 int for_component_groups(int K, int n, double work_per_component, F&& body) {
   const int G = (K + 3) / 4;
-  int nt = 1;   // a thread costs ~15 us to start: one per ~2.5e5 (4-lane) multiply-adds, at most 8
+  int nt = 1;   // ~1.4 ns per (4-lane) multiply-add; waking a helper costs 30 - 50 us until it runs (measured: K = 64, D = 16, 90 us of work,
+                // ran 89 / 96 / 121 / 165 us on 1 / 2 / 4 / 8 threads): a helper per ~100 us of work = 7e4 multiply-adds, at most 8 threads
   {
     const unsigned hc = std::thread::hardware_concurrency();
-    const double want = work_per_component * G / 2.5e5;
-    nt = (int)std::min<double>(std::min<double>(hc ? hc : 1, 8), std::min<double>(G, want));
+    static const double per_thread = [] { const char* e = getenv("MIMO_HOST_WORK_PER_THREAD"); return e ? atof(e) : 7e4; }();   // tuning knobs
+    static const int max_threads = [] { const char* e = getenv("MIMO_HOST_MAX_THREADS"); return e ? atoi(e) : 8; }();
+    const double want = work_per_component * G / per_thread;
+    nt = (int)std::min<double>(std::min<double>(hc ? hc : 1, max_threads), std::min<double>(G, want));
     if (nt < 1) nt = 1;
-    if (g_fail_thread_start.load() && nt < 2 && G >= 2) nt = 2;   // the test hook wants a helper to fail
+    if (g_fail_thread_start.load() && nt < 2 && G >= 2) nt = 2;   // the test hook wants a helper to be missing
   }
   std::atomic<int> next{0}, bad{0}, processed{0};
   auto run = [&]() noexcept {
@@ -150,18 +233,16 @@ int for_component_groups(int K, int n, double work_per_component, F&& body) {
       // scratch allocation failed on this thread: the others take its groups (none processed here)
     }
   };
-  std::vector<std::thread> th;
-  try {
-    th.reserve((size_t)(nt > 1 ? nt - 1 : 0));
-    for (int t = 1; t < nt; ++t) {
-      if (g_fail_thread_start.exchange(0)) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-      th.emplace_back(run);
-    }
-  } catch (...) {
-    // fewer helpers than planned (or none): the calling thread picks the remaining groups up below
+  int helpers = nt - 1;
+  if (helpers > 0 && g_fail_thread_start.exchange(0)) helpers = 0;      // (test hook: the helpers "could not be started")
+  HelperPool* pool = helpers > 0 ? HelperPool::get(helpers) : nullptr;
+  if (pool) helpers = std::min(helpers, pool->size());
+  if (pool && helpers > 0) {
+    const std::function<void()> job = run;
+    pool->run(helpers, job);
+  } else {
+    run();
   }
-  run();
-  for (auto& x : th) x.join();
   if (processed.load() != G) return MIMO_E_NOMEM;   // no thread could allocate its scratch
   return bad.load() ? MIMO_E_INVALID : MIMO_OK;
 }

@@ -2,6 +2,7 @@
 libmimo_hip.so) against the NumPy route of the same classes, which is pinned to the reference by the
 golden-vector tests."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -582,3 +583,51 @@ def test_native_legacy_stream_in_place_from_arbitrary_generator_positions(monkey
         (w, sw, uw, nw), (g, sg, ug, ng) = outs
         assert all(np.array_equal(x, y) for x, y in zip(w, g)), seed
         assert np.array_equal(sw[1], sg[1]) and sw[2:] == sg[2:] and np.array_equal(uw, ug) and np.array_equal(nw, ng), seed
+
+
+def test_helper_pool_survives_fork_and_concurrent_callers():
+    """The persistent helper threads of the batched routines (mimo_host.cpp: HelperPool): a child process created by fork() after the
+    pool exists has none of its threads and starts its own; two Python threads inside the routines at once get the same numbers (the
+    second finds the pool busy and runs alone)."""
+    import threading
+    K, D = 128, 32                                   # enough work for the pool
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((K, D, D))
+    kappas = rng.uniform(0.5, 200., K)
+    mus = rng.standard_normal((K, D))
+    nat = [kappas[:, None] * mus, kappas, A @ A.transpose(0, 2, 1) + D * np.eye(D)
+           + kappas[:, None, None] * np.einsum('kd,kl->kdl', mus, mus), rng.uniform(1., 5000., K)]
+
+    def solve():
+        p = StackedNormalWisharts(K, D)
+        assert p._assign_native([v.copy() for v in nat])
+        return p.canonical_expected()[2]
+
+    old = composite.NATIVE_HOST
+    composite.NATIVE_HOST = True
+    try:
+        ref = solve()
+        out = [None] * 4
+        ts = [threading.Thread(target=lambda i=i: out.__setitem__(i, solve())) for i in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert all(np.array_equal(o, ref) for o in out)
+        pid = os.fork()
+        if pid == 0:                                # child: the parent's helpers are gone
+            code = 1
+            try:
+                code = 0 if np.array_equal(solve(), ref) and np.array_equal(solve(), ref) else 2
+            finally:
+                os._exit(code)
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            done, status = os.waitpid(pid, os.WNOHANG)
+            if done:
+                break
+            time.sleep(0.05)
+        else:
+            os.kill(pid, 9)
+            raise AssertionError("the forked child hung in the batched routine")
+        assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    finally:
+        composite.NATIVE_HOST = old
