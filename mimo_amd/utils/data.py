@@ -70,14 +70,13 @@ def batches(batch_size, data_size):
 
 
 def one_hot(z, K):
-    """mimo/utils/data.py:160-169 — dense (K, N) table.  Provided for API parity on small inputs;
-    the mixture drivers never build it: hard labels go to HipEngine.label_stats instead."""
-    z = np.atleast_1d(z).astype(int)
-    assert np.all(z >= 0) and np.all(z < K)
-    N, shp = z.size, z.shape
-    zoh = np.zeros((K, N))
-    zoh[np.ravel(z), np.arange(N)] = 1
-    return np.reshape(zoh, (K,) + shp)
+    """Dense indicator table of a label array: out[k, ...] = 1 where z[...] == k (the reference's `one_hot`,
+    mimo/utils/data.py:160-169, returns the same (K,) + z.shape array).  For API parity on small inputs only: the mixture
+    drivers never build it — hard labels go to HipEngine.label_stats."""
+    labels = np.atleast_1d(np.asarray(z)).astype(int)
+    if labels.size and (labels.min() < 0 or labels.max() >= K):
+        raise AssertionError("labels outside [0, K)")
+    return (np.arange(K).reshape((K,) + (1,) * labels.ndim) == labels[None, ...]).astype(float)
 
 
 def islist(*args):
