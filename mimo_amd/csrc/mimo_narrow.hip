@@ -38,7 +38,7 @@ narrow_fn pick_narrow_table(int V, int nsf, int gibbs, int zi);     // mimo_narr
 narrow_fn pick_narrow_big(int V, int nsf, int gibbs, int zi);       // mimo_narrow_big.hip
 static narrow_fn pick_narrow(int V, int nsf, int gibbs, int zi) {
   if (nsf > 4) return V > 32 ? nullptr : pick_narrow_table(V, nsf, gibbs, zi);
-  if (V > 32) return nsf <= 2 ? pick_narrow_big(V, nsf, gibbs, zi) : nullptr;
+  if (V > 32) return (nsf <= 2 || gibbs == 1) ? pick_narrow_big(V, nsf, gibbs, zi) : nullptr;
   switch (V) {
 #define MIMO_NV(v) case v: return pick_narrow_nsf<v>(nsf, gibbs, zi);
     MIMO_NV(1) MIMO_NV(2) MIMO_NV(3) MIMO_NV(4) MIMO_NV(6) MIMO_NV(8) MIMO_NV(10) MIMO_NV(12) MIMO_NV(13) MIMO_NV(14)
@@ -97,6 +97,9 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
   // K=160 0.43 / 0.33 against 0.82 / 0.43, K=192 0.79 / 0.39 against 0.92 / 0.52, K=224 1.28 / 0.45 against 1.25 / 0.56, K=256 3.48 / 0.50 against
   // 1.20 / 0.62 — the softmax pass of 52+ slots x 2 steps spills (64 l values + 128 accumulators + ~90 registers > 512): it stops at K = 192;
   // the label pass has no accumulators (two waves per SIMD, no scratch) and takes every K.  MIMO_NARROW_BIG_VI / _LABELS: tuning knobs
+  // label pass (no accumulators: every slot count fits) over three steps (Dz = 3): 0.37 - 0.58 against 0.45 - 0.64 ms on the row-owner kernels,
+  // K = 144 .. 256, N = 2e6 (profiles/r04_narrow_big.txt); four steps (Dz = 4) measured level with them (0.42 - 0.69 against 0.46 - 0.66) and stay there
+  auto big_labels_steps = [] { static const int n = [] { const char* e = getenv("MIMO_NARROW_BIG_LABEL_STEPS"); return e ? atoi(e) : 3; }(); return n; };
   auto big_kmax = [](int g, int nsf) {
     static const int vi_env = [] { const char* e = getenv("MIMO_NARROW_BIG_VI"); return e ? atoi(e) : 0; }();
     const int vi = g_narrow_big_vi > 0 ? g_narrow_big_vi : vi_env;      // (mimo_tune "narrow_big_vi")
@@ -120,7 +123,7 @@ bool narrow_covers(int K, int F, int D, int ZS, int gibbs) {
     return false;
   } else if (D > 4) {            // a reduced map of at most 16 features over wider rows
     if (!wide_on || D > 16 || K < 1 || K > 64) return false;
-  } else if (K < kmin || K > kmax || K > 256 || (K > 128 && (narrow_nsf(F) > 2 || K > big_kmax(gibbs, narrow_nsf(F))))) {
+  } else if (K < kmin || K > kmax || K > 256 || (K > 128 && (narrow_nsf(F) > (gibbs == 1 ? big_labels_steps() : 2) || K > big_kmax(gibbs, narrow_nsf(F))))) {
     return false;
   }
   const int V = narrow_v(K);

@@ -11,6 +11,9 @@ static narrow_fn pick_narrow_big_nsf(int nsf, int gibbs, int zi) {
   switch (nsf) {
     case 1: return pick_narrow_mode<V, 1>(gibbs, zi);
     case 2: return pick_narrow_mode<V, 2>(gibbs, zi);
+    // three / four steps (Dz = 3, 4): the label pass only — it has no accumulators; V NSF accumulators of the softmax pass do not fit
+    case 3: return gibbs == 1 ? narrow_kernel<V, 3, 1, 1> : nullptr;
+    case 4: return gibbs == 1 ? narrow_kernel<V, 4, 1, 1> : nullptr;
   }
   return nullptr;
 }

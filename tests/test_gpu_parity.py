@@ -689,7 +689,7 @@ def test_small_shape_kernel_structures(engine, D, K):
         engine.set_structure('full')
 
 
-@pytest.mark.parametrize("D,K", [(8, 256), (8, 65), (8, 96), (8, 97), (5, 130), (9, 160), (9, 256), (1, 200), (3, 224),
+@pytest.mark.parametrize("D,K", [(8, 256), (8, 65), (8, 96), (8, 97), (5, 130), (9, 160), (9, 256), (1, 200), (3, 224), (3, 144), (3, 256), (3, 170), (4, 200),
                                  (7, 128), (2, 255), (6, 100), (8, 17), (8, 32), (5, 40), (9, 64), (3, 64), (7, 33), (6, 48),
                                  (8, 1), (8, 5), (7, 16), (5, 2), (9, 10), (6, 13),
                                  (16, 64), (12, 100), (10, 17), (16, 5), (13, 40), (12, 128), (11, 70), (15, 33), (14, 64), (10, 128)])
@@ -704,7 +704,7 @@ def test_large_k_label_pass_and_label_statistics(engine, D, K, N):
     Z, c, b, W = _random_problem(rng, N, D, K)
     engine.upload(Z)
     mid = K <= 48 and (D >= 14 if K >= 33 else D >= 20 if K >= 17 else D >= 17)          # the mid kernel's label mode (round 4)
-    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D <= 2 and 128 < K <= 256) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "mid" if mid else "rowwave")
+    assert engine.plan(K, gibbs=True)["kind"] == ("narrow" if (D <= 4 and 33 <= K <= 128) or (D <= 3 and 128 < K <= 256) or (D == 5 and K <= 64) or (5 <= D <= 16 and K <= (24 if D <= 8 else 16)) else "mid" if mid else "rowwave")
     L = O.canonical_eval(Z, c, b, W)
     u = rng.random(N)
     lab, S = engine.gibbs_labels(c, b, W, u=u)
