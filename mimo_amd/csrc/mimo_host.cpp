@@ -144,7 +144,7 @@ class HelperPool {
     if (p) p->grow(want);
     return p;
   }
-  int size() const { return (int)threads_.size(); }
+  int size() const { return size_.load(); }
   // runs job() on the caller and on up to `helpers` pool threads (<= size()); returns when every thread that took it is done.
   // job() returns when there is nothing left to hand out, so helpers that have not woken by the time the caller's own share is
   // finished are left asleep.  A second caller (another Python thread inside another routine) finds the pool busy and runs alone.
@@ -172,6 +172,7 @@ class HelperPool {
       try {
         threads_.emplace_back([this] { loop(); });
         threads_.back().detach();
+        size_.store((int)threads_.size());
       } catch (...) { break; }                             // fewer helpers than wanted: the callers cope
     }
   }
@@ -194,7 +195,8 @@ class HelperPool {
       done_cv_.notify_one();
     }
   }
-  std::vector<std::thread> threads_;
+  std::vector<std::thread> threads_;       // (grown under create_mu() only)
+  std::atomic<int> size_{0};
   std::mutex mu_, call_mu_;
   std::condition_variable cv_, done_cv_;
   const std::function<void()>* job_ = nullptr;
