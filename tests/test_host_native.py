@@ -148,6 +148,30 @@ def test_host_routines_under_asan_ubsan(tmp_path):
     assert run.returncode == 0 and "sanitizer run ok" in run.stdout, run.stdout[-1000:] + run.stderr[-3000:]
 
 
+def test_host_routines_under_thread_sanitizer(tmp_path):
+    """The same driver under ThreadSanitizer: the persistent helper pool of the batched routines (several callers' worth of wake-ups,
+    the group counter, the scratch each thread owns)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_tsan")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-mavx2", "-mfma", "-pthread",
+           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "host_sanitize.cpp"),
+           os.path.join(root, "mimo_amd", "csrc", "mimo_host.cpp"), "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if run.returncode != 0 and "unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory here")
+    assert run.returncode == 0 and "sanitizer run ok" in run.stdout and "WARNING: ThreadSanitizer" not in run.stderr, \
+        run.stdout[-1000:] + run.stderr[-3000:]
+
+
 def _random_nw(K, D, seed):
     rs = np.random.default_rng(seed)
     A = rs.standard_normal((K, D, D))
