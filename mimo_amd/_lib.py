@@ -47,6 +47,7 @@ SIGNATURES = {
     "mimo_host_nw_vlb": (C.c_int, [C.c_int, C.c_int] + [_vp] * 16),
     "mimo_host_legacy_draws_inplace": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp]),
+    "mimo_host_py_sample": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int64, C.c_int64, C.c_int, _vp]),
     "mimo_host_hier_vi": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, C.c_double] + [_vp] * 9),
     "mimo_host_legacy_draws": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                          C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

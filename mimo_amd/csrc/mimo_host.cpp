@@ -692,6 +692,46 @@ MIMO_NO_CONTRACT_FN int mimo_host_legacy_draws_inplace(uint32_t* mt_key, int* mt
   });
 }
 
+int mimo_host_py_sample(uint32_t* mt_key, int* mt_pos, int64_t n, int64_t k, int use_pool, int64_t* out) {
+  return guarded_host([&]() -> int {
+  if (!mt_key || !mt_pos || !out || k < 0 || k > n || n < 1 || n >= ((int64_t)1 << 32) || *mt_pos < 0 || *mt_pos > 624) return MIMO_E_INVALID;
+  LegacyStream g{mt_key, *mt_pos, 0, 0.0};
+  auto randbelow = [&](uint64_t m) -> uint64_t {        // Random._randbelow_with_getrandbits (m >= 1): getrandbits(m.bit_length()) until < m
+    int bits = 0;
+    for (uint64_t t = m; t; t >>= 1) ++bits;
+    uint64_t r;
+    do { r = (uint64_t)(g.next32() >> (32 - bits)); } while (r >= m);
+    return r;
+  };
+  if (use_pool) {                                       // "an n-length list is smaller than a k-length set"
+    std::vector<int64_t> pool((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i;
+    for (int64_t i = 0; i < k; ++i) {
+      const uint64_t j = randbelow((uint64_t)(n - i));
+      out[i] = pool[(size_t)j];
+      pool[(size_t)j] = pool[(size_t)(n - i - 1)];      // move the non-selected item into the vacancy
+    }
+  } else {                                              // selections tracked in a set: open addressing, load <= 1/2
+    size_t cap = 16;
+    while (cap < (size_t)(2 * k + 1)) cap <<= 1;
+    std::vector<int64_t> table(cap, -1);
+    auto insert = [&](int64_t v) -> bool {              // false: already there
+      size_t h = (size_t)((uint64_t)v * 0x9E3779B97F4A7C15ull) & (cap - 1);
+      while (table[h] >= 0) { if (table[h] == v) return false; h = (h + 1) & (cap - 1); }
+      table[h] = v;
+      return true;
+    };
+    for (int64_t i = 0; i < k; ++i) {
+      int64_t j = (int64_t)randbelow((uint64_t)n);
+      while (!insert(j)) j = (int64_t)randbelow((uint64_t)n);
+      out[i] = j;
+    }
+  }
+  *mt_pos = g.pos;
+  return MIMO_OK;
+  });
+}
+
 int mimo_host_mnw_vi(int K, int dy, int dc, int affine, const double* a, const double* b, const double* c,
                      const double* d, double* Ms, double* psis, double* nus, double* half_logdet_psi,
                      double* Kinv, double* cc, double* bb, double* W, double* E1, double* E2, double* E4) {

@@ -103,6 +103,13 @@ int main() {
         if (rc != 0 || redraw < 0 || redraw > 1 || p2 < 0 || p2 > 624) { printf("legacy in place start=%d rc=%d\n", start, rc); return 1; }
       }
     }
+    {   // random.sample's two branches
+      std::vector<int64_t> idx(300);
+      std::vector<uint32_t> k3(key);
+      int p3 = 624;
+      if (mimo_host_py_sample(k3.data(), &p3, 300, 300, 1, idx.data()) != 0 || mimo_host_py_sample(k3.data(), &p3, 100000, 300, 0, idx.data()) != 0 ||
+          mimo_host_py_sample(k3.data(), &p3, 10, 11, 0, idx.data()) >= 0) { printf("py sample\n"); return 1; }
+    }
     sh[3] = -1.0;
     if (mimo_host_legacy_draws(key.data(), &pos, &has, &gs, K, nb, ng, na, sh.data(), ob.data(), og.data(), oa.data()) >= 0) { printf("negative shape accepted\n"); return 1; }
   }

@@ -251,7 +251,8 @@ def test_rows_with_nan_in_a_linear_gaussian_mixture():
 
 @pytest.mark.parametrize("n,k", [(4_000_000, 4096), (10_000_000, 128), (5000, 4096), (4097, 4096), (1 << 31, 1000),
                                  (100000, 99990), (1000, 70), (300, 64), (20000, 4096), ((1 << 32) - 1, 5000),
-                                 (1 << 32, 5000), (50, 10), (4_000_000, 5)])
+                                 (1 << 32, 5000), (50, 10), (4_000_000, 5), (300, 300), (257, 256), (70000, 17000), (16405, 4096),
+                                 (16406, 4096), (1000, 999)])
 def test_sample_indices_is_random_sample(n, k):
     """utils.data.sample_indices (the minibatch draw of the SVI drivers, data.py:9-12 of the reference) returns what
     random.sample(range(n), k) returns and leaves Python's generator in the same state — on the NumPy block route and on
