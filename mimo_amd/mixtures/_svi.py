@@ -13,7 +13,7 @@ device.  numpy.random / random are consumed in the plain form's order (draws of 
 import numpy as np
 import numpy.random as npr
 
-from mimo_amd.utils.data import batches
+from mimo_amd.utils.data import batches, sample_indices
 
 
 def _start_stats(beng, size, nbatch):
@@ -41,9 +41,8 @@ def run(eng, beng, nrows, maxiter, batch_size, randomize, size, upload, canonica
         return vlb
 
     def next_batch():
-        batch = None
-        for batch in batches(batch_size, nrows):        # (one batch per call)
-            upload(batch)
+        batch = sample_indices(nrows, batch_size, as_array=True)      # what batches() yields, as an index array (no list round trip)
+        upload(batch)
         return batch
 
     batch = next_batch()

@@ -15,7 +15,11 @@ def _native_lib():
     return composite._native()
 
 
-def sample_indices(n, k):
+def _maybe_array(idx, as_array):
+    return np.asarray(idx, dtype=np.int64) if as_array else idx
+
+
+def sample_indices(n, k, as_array=False):
     """random.sample(range(n), k): the same list and the same state of Python's global generator afterwards, computed natively
     (mimo_host_py_sample: both branches of CPython's `sample`; 0.13 ms for 4096 of 4e6) or, without the library, on blocks of the raw
     Mersenne-Twister stream with NumPy (0.35 ms) — CPython's loop costs 0.25 us per getrandbits call through three Python frames:
@@ -28,10 +32,10 @@ def sample_indices(n, k):
     bits = int(n).bit_length()
     setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
     if type(inst) is not random.Random or not 0 < k <= n or bits > 32 or k < 256:      # (the state hand-over costs ~55 us: 130 indices' worth)
-        return random.sample(range(n), k)
+        return _maybe_array(random.sample(range(n), k), as_array)
     version, internal, gauss_next = inst.getstate()
     if version != 3 or len(internal) != 625:
-        return random.sample(range(n), k)
+        return _maybe_array(random.sample(range(n), k), as_array)
     lib = _native_lib()
     if lib is not None:                                    # both branches of CPython's sample, natively (mimo_host_py_sample)
         key = np.array(internal[:-1], dtype=np.uint32)
@@ -39,9 +43,9 @@ def sample_indices(n, k):
         if lib.mimo_host_py_sample(key.ctypes.data_as(C.c_void_p), C.byref(pos), int(n), int(k), 1 if n <= setsize else 0,
                                    out.ctypes.data_as(C.c_void_p)) == 0:
             inst.setstate((version, tuple(key.tolist()) + (pos.value,), gauss_next))
-            return out.tolist()
+            return out if as_array else out.tolist()
     if n <= setsize or k < 64:
-        return random.sample(range(n), k)
+        return _maybe_array(random.sample(range(n), k), as_array)
     global _mt
     if _mt is None:
         _mt = np.random.MT19937()                          # (constructing one seeds it from the OS: 0.1 ms)
@@ -74,7 +78,8 @@ def sample_indices(n, k):
     bg.random_raw(consumed)
     st = bg.state['state']
     inst.setstate((version, tuple(st['key'].tolist()) + (int(st['pos']),), gauss_next))
-    return out.astype(np.int64).tolist()
+    out = out.astype(np.int64)
+    return out if as_array else out.tolist()
 
 
 def batches(batch_size, data_size):
